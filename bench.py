@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batch-1 decode tokens/s (+ prefill tokens/s at 4k context) of the forward_partial hot path.
+
+Workload (BASELINE.json configs[1]): Mistral-7B-v0.3 dimensions, all 32 layers, random-init bf16 weights,
+sliding_window=4096, one 4096-token prefill, then greedy batch-1 decode.  A "step" is one decode token:
+`Transformer.forward(next_token, [1], cache)` = one `mi_forward` call = 32 x 5 weight-streaming launches + LM head,
+with the ring full (4096 keys per layer).  Inputs (weights, K/V rings, token ids) are resident in HBM.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W        # pipeline stages over RCCL (strong scaling)
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md section 6 for the roofline / cpu_baseline definitions).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mistral-inference_amd"))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+MISTRAL_7B = dict(dim=4096, n_layers=32, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                  vocab_size=32768, rope_theta=1e6, sliding_window=4096)
+
+
+def init_weights_(model, seed: int) -> None:
+    """Random init of the reference tests' kind (U(+-1/sqrt(fan_in)) linears, N(0,1) embedding, unit norms),
+    generated on the device tensor by tensor."""
+    g = torch.Generator(device=model.device).manual_seed(seed)
+    for name, p in model.named_parameters():
+        with torch.no_grad():
+            if name.endswith("norm.weight"):
+                p.fill_(1.0)
+            elif name.startswith("tok_embeddings"):
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32))
+            else:
+                bound = 1.0 / math.sqrt(p.shape[1])
+                for r0 in range(0, p.shape[0], 8192):  # bounded fp32 temporaries
+                    blk = p[r0:r0 + 8192]
+                    blk.copy_((torch.rand(blk.shape, generator=g, device=p.device, dtype=torch.float32) * 2 - 1) * bound)
+
+
+def build_model(params: dict, rank: int, world: int, device: str):
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.transformer import Transformer
+    args = TransformerArgs.from_dict(params)
+    args.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(args, pipeline_rank=rank, num_pipeline_ranks=world)
+    model = model.to(torch.bfloat16).to_empty(device=device)
+    init_weights_(model, seed=42 + rank)
+    model._backend.invalidate()
+    return model.eval()
+
+
+def decode_bytes_per_token(p: dict, ctx: int) -> int:
+    """weights read once + K/V window read once (bf16)."""
+    D, L, H, Hkv, Dh, F, V = p["dim"], p["n_layers"], p["n_heads"], p["n_kv_heads"], p["head_dim"], p["hidden_dim"], p["vocab_size"]
+    per_layer = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + 2 * D + 3 * D * F
+    w = 2 * (L * per_layer + V * D + D)
+    W = p.get("sliding_window") or ctx
+    kv = L * 2 * min(ctx, W) * Hkv * Dh * 2
+    return w + kv
+
+
+def prefill_flops(p: dict, T: int) -> float:
+    D, L, H, Hkv, Dh, F, V = p["dim"], p["n_layers"], p["n_heads"], p["n_kv_heads"], p["head_dim"], p["hidden_dim"], p["vocab_size"]
+    lin = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + 3 * D * F
+    W = p.get("sliding_window") or T
+    pairs = sum(min(i + 1, W) for i in range(T))
+    return 2.0 * T * (L * lin + V * D) + L * 4.0 * H * Dh * pairs
+
+
+def dominant_kernel_roofline(model, iters: int) -> dict:
+    """The W1|W3 gate/up GEMV (54 % of the decode bytes): algorithmic bytes per launch / average launch
+    duration, timed live with HIP events on the launch stream, cycling through all local layers' weights so
+    no launch re-reads what the previous one left in the 256 MiB Infinity Cache."""
+    from mistral_inference import _hip
+    a = model.args
+    dev = model.device
+    x = torch.randn(1, a.dim, device=dev).to(torch.bfloat16)
+    out = torch.empty(1, a.hidden_dim, device=dev, dtype=torch.bfloat16)
+    blocks = list(model.layers.values())
+    stream = torch.cuda.current_stream(dev)
+
+    def run(n):
+        for i in range(n):
+            b = blocks[i % len(blocks)]
+            _hip.linear(x, (b.feed_forward.w1.weight, b.feed_forward.w3.weight), _hip.EPI_SWIGLU,
+                        norm_w=b.ffn_norm.weight, eps=a.norm_eps, out=out)
+
+    run(len(blocks))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = iters * len(blocks)
+    e0.record(stream)   # torch's current stream IS the stream mi_linear launches on (see _hip.stream_ptr)
+    run(n)
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    bytes_per_launch = 2 * a.hidden_dim * a.dim * 2 + 2 * a.dim * 2 + a.hidden_dim * 2
+    gbs = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "gemv_kernel<1,SWIGLU> (RMSNorm + W1|W3 GEMV + SiLU*mul)", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2), "launches_timed": n}
+
+
+def cpu_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
+    """The oracle (CPU restatement of the reference, oracle/mistral_oracle.py) timed on this box's host cores on
+    a bounded sample: the same decode step at the same context but with 2 of the 32 layers (+ LM head), scaled
+    linearly in the layer count."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.nn.functional as F
+    import mistral_oracle as mo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p2 = dict(params, n_layers=2)
+    oargs = mo.OracleArgs.from_params(p2)
+    w = mo.synth_weights(oargs, seed=1)
+    om = mo.OracleModel(oargs, w)
+    W = params.get("sliding_window") or ctx
+    cache = mo.OracleCache(2, 1, ctx + steps + 2, oargs.n_kv_heads, oargs.head_dim, params.get("sliding_window"),
+                           dtype=torch.bfloat16)
+    for l in range(2):  # a full ring, as after the 4096-token prefill
+        cache.k[l].copy_(torch.randn(cache.k[l].shape).to(torch.bfloat16))
+        cache.v[l].copy_(torch.randn(cache.v[l].shape).to(torch.bfloat16))
+    cache.seen = [ctx]
+    tok = torch.tensor([1])
+    with torch.inference_mode():
+        om.forward(tok, [1], cache)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            om.forward(tok, [1], cache)
+        t_full = (time.perf_counter() - t0) / steps
+        h = torch.randn(1, oargs.dim).to(torch.bfloat16)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            F.linear(mo.rms_norm(h, w["norm.weight"], 1e-5), w["output.weight"]).float()
+        t_head = (time.perf_counter() - t0) / steps
+    per_layer = max(1e-9, (t_full - t_head) / 2)
+    t_model = t_head + params["n_layers"] * per_layer
+    return {"value": round(1.0 / t_model, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle decode step at ctx {ctx} (W={W}) with 2 of {params['n_layers']} layers + LM head, "
+                      f"{steps} steps, bf16, {cores} threads; per-layer time x{params['n_layers']} + head "
+                      f"({per_layer * 1e3:.1f} ms/layer, {t_head * 1e3:.1f} ms head)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--prefill", type=int, default=4096, help="prompt tokens (BASELINE configs[1]: 4096)")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers => NOT the named config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    opt = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == opt.gpus, f"--gpus {opt.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        torch.distributed.init_process_group("nccl")  # RCCL
+
+    params = dict(MISTRAL_7B)
+    if opt.layers:
+        params["n_layers"] = opt.layers
+    model = build_model(params, rank, world, dev)
+
+    from mistral_inference.cache import BufferCache
+    a = model.args
+    T0, K, Wm = opt.prefill, opt.steps, opt.warmup
+    cache = BufferCache(model.n_local_layers, 1, T0 + K + Wm + 8, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
+                        dtype=torch.bfloat16)
+    cache.reset()
+    prompt = torch.randint(0, a.vocab_size, (T0,), generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        # ---- prefill (timed once; includes the [T, V] fp32 LM head the API contract requires)
+        sync()
+        t0 = time.perf_counter()
+        logits = model.forward(prompt, [T0], cache)
+        sync()
+        prefill_s = time.perf_counter() - t0
+        nxt = torch.argmax(logits[-1:], dim=-1)
+        del logits
+        # ---- decode
+        for _ in range(Wm):
+            nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+        sync()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt, prefill_s], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt, prefill_s = tmax.tolist()
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    ctx = T0 + Wm + K // 2
+    step_bytes = decode_bytes_per_token(params, ctx)
+    ms = dt / K * 1e3
+    step_gbs = step_bytes / (dt / K) / 1e9
+    out = {
+        "metric": "decode tokens/sec/GPU (batch=1, seq=1)", "value": round(K / dt, 2), "unit": "tokens/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Mistral-7B-v0.3 dims, {params['n_layers']} layers, random-init bf16, "
+                               f"{T0}-token prefill then batch-1 greedy decode, sliding_window=4096",
+                   "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx,
+                   "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
+        "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
+                              "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
+        "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),
+                    "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
+                    "note": "first call: includes one-time workspace allocation"},
+    }
+    if world == 1:
+        out["roofline"] = dominant_kernel_roofline(model, iters=4)
+        if not opt.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, T0)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

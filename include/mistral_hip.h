@@ -1,0 +1,184 @@
+/*
+ * mistral_hip.h -- C ABI of libmistral_hip.so: the MI355X (gfx950) implementation of
+ * mistral-inference's `Transformer.forward_partial` hot path.
+ *
+ * The reference (mistralai/mistral-inference v1.6.0) has NO FFI/plugin layer of its own: its hot
+ * path calls torch/xformers kernels from Python.  This header is therefore the boundary a
+ * maintainer would bind (ctypes stub in INTEGRATION.md); every entry point names the reference
+ * lines whose work it replaces.  Paths are relative to src/mistral_inference/ of the reference.
+ *
+ * Conventions
+ *   - plain C types only; all tensor arguments are raw DEVICE pointers unless marked "host";
+ *   - storage dtype is bf16 (uint16 payload), row-major, innermost dimension contiguous;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
+ *     frees or synchronises, and keeps no state between calls (scratch comes from the caller);
+ *   - return value: 0 = ok, >0 = hipError_t of a failed launch, <0 = MI_ERR_* argument check;
+ *     `mi_error_string` turns any of them into text.  The Python host raises RuntimeError.
+ *   - numerics contract (rounding points): SURVEY.md Appendix A / DESIGN.md section 4.
+ */
+#ifndef MISTRAL_HIP_H
+#define MISTRAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+#define MI_OK 0
+#define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
+#define MI_ERR_SHAPE (-2)      /* shape not supported by the gfx950 kernels (see message) */
+#define MI_ERR_WORKSPACE (-3)  /* caller workspace too small                              */
+#define MI_ERR_UNSUPPORTED (-4)
+
+typedef void* mi_stream_t; /* hipStream_t */
+
+int mi_abi_version(void);
+const char* mi_error_string(int code);
+/* text of the last MI_ERR_* raised on this thread (empty string if none) */
+const char* mi_last_error_detail(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Leaf operators (each replaces one group of torch/xformers launches of the reference)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* transformer.py:193  h = tok_embeddings(input_ids).  out[T,D] = table[ids[t], :] */
+int mi_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, mi_stream_t stream);
+
+/* transformer_layers.py:115-120 RMSNorm.forward: out = bf16(bf16(x_f32 * rsqrt(mean(x^2)+eps)) * w).
+ * In-place (out == x) is allowed. */
+int mi_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, mi_stream_t stream);
+
+/* rope.py:13-23 apply_rotary_emb, in place on the q and k column blocks of a fused activation
+ * buffer qkv[T, ld] = [ q (n_heads*Dh) | k (n_kv_heads*Dh) | v ... ].
+ * rope_cs: fp32 [rope_len, Dh/2, 2] = (cos, sin), i.e. view_as_real of the reference's complex64
+ * freqs_cis table (rope.py:6-10, transformer.py:113-116); tok_pos[T] absolute positions. */
+int mi_rope_inplace(void* qkv, int ld, int T, int n_heads, int n_kv_heads, int head_dim, const float* rope_cs,
+                    int rope_len, const int32_t* tok_pos, mi_stream_t stream);
+
+/* cache.py:83-92 CacheView.update with to_cache_mask / cache_positions of cache.py:226-235:
+ * token t (sequence b = tok_seq[t], index i = t - q_start[b] of s_b = q_start[b+1]-q_start[b] new
+ * tokens) is stored iff i >= s_b - W, into ring slot tok_pos[t] % W of row b.
+ * k/v: [T, ld] activation views (already at the k / v column), cache_k/v: [max_batch, W, n_kv*Dh]. */
+int mi_kv_write(void* cache_k, void* cache_v, int W, const void* k, const void* v, int ld, int T, int kv_dim,
+                const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, mi_stream_t stream);
+
+/* Epilogues of the dense contractions */
+enum mi_epilogue {
+  MI_EPI_STORE = 0,    /* out = bf16(acc)                                  nn.Linear                       */
+  MI_EPI_RESIDUAL = 1, /* out = bf16(residual + bf16(acc))                 transformer_layers.py:166,168   */
+  MI_EPI_SWIGLU = 2,   /* out = bf16(bf16(silu(bf16(acc1))) * bf16(acc3))  transformer_layers.py:105-106   */
+  MI_EPI_LOGITS = 3    /* out_f32 = float(bf16(acc))                       transformer.py:235,239-242      */
+};
+
+/* out[M,N] = epilogue(x[M,K] @ W^T).  W is given as up to three row blocks (w[i] has n_rows[i]
+ * rows of K bf16; used for the fused Wq|Wk|Wv projection, transformer_layers.py:66) except for
+ * MI_EPI_SWIGLU where w[0]=W1, w[1]=W3 (both [N,K]).  M <= 8 runs the weight-streaming GEMV kernels
+ * (HBM-bound), M > 8 the MFMA GEMM.  norm_w != NULL fuses RMSNorm(x; norm_w, eps) in front
+ * (GEMV path only; the GEMM path requires norm_w == NULL).
+ * residual: [M, ldo] (may alias out).  out is bf16 [M, ldo] (fp32 for MI_EPI_LOGITS). */
+int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const void* const w[3], const int n_rows[3],
+              int epilogue, const void* residual, const void* norm_w, float eps, mi_stream_t stream);
+
+/* Decode-branch attention (transformer_layers.py:77-89 with the mask of cache.py:249-254):
+ * one query per sequence, keys = ring slots [0, min(pos+1, W)) of its row, GQA by kv = h / (H/Hkv)
+ * (replaces repeat_kv, transformer_layers.py:16-19,84).  q: [B, ldq] (H*Dh used), out: [B, H*Dh].
+ * tok_pos[b] = position of the new token (already written to the ring).  scratch: fp32, at least
+ * mi_attn_decode_scratch_bytes(...) bytes; its first `B*Hkv` int32 words are arrival counters that
+ * must be zero at the first call (the kernel leaves them zero). */
+size_t mi_attn_decode_scratch_bytes(int B, int n_heads, int n_kv_heads, int head_dim, int W);
+int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const void* cache_v, int W, int B,
+                   int n_heads, int n_kv_heads, int head_dim, const int32_t* tok_pos, void* scratch,
+                   mi_stream_t stream);
+
+/* Prefill-branch attention (transformer_layers.py:74-76,84-89; keys of cache.py:94-117 interleave_kv;
+ * masks of cache.py:238-248).  For sequence b with s_b new tokens (rows q_start[b]..) and p_b =
+ * kv_before[b] tokens already seen, key position kp is visible to query position qp iff
+ * qp - W < kp <= qp; keys kp < p_b are read from the ring (slot kp % W, only the last min(p_b,W)
+ * exist), keys kp >= p_b from the activation rows.  qkv: [T, ld] fused buffer (post-RoPE).
+ * causal == 0 is the cache=None quirk (transformer_layers.py:165): one segment, no mask.
+ * out: [T, H*Dh]. */
+int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, const void* cache_v, int W, int B,
+                    int max_q_len, int n_heads, int n_kv_heads, int head_dim, const int32_t* q_start,
+                    const int32_t* kv_before, int causal, mi_stream_t stream);
+
+/* moe.py:25-27: logits = bf16(x @ Wg^T); top-k on them; fp32 softmax over the k picked, rounded to
+ * bf16.  x is [T, D] (norm_w != NULL fuses the RMSNorm).  sel_idx int32 [T, k], sel_w fp32 [T, k]
+ * (bf16-rounded values).  Ties: the lowest expert id wins (torch.topk leaves tie order unspecified). */
+int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate, int E,
+                  int top_k, const void* norm_w, float eps, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole local layer stack: Transformer.forward_partial (transformer.py:163-219) + the LM head of
+ * Transformer.forward (transformer.py:229-242)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mi_layer {
+  const void* attention_norm; /* [D]            transformer_layers.py:143 */
+  const void* wq;             /* [H*Dh, D]      transformer_layers.py:51  */
+  const void* wk;             /* [Hkv*Dh, D]                         :52  */
+  const void* wv;             /* [Hkv*Dh, D]                         :53  */
+  const void* wo;             /* [D, H*Dh]                           :54  */
+  const void* ffn_norm;       /* [D]                                 :144 */
+  const void* w1;             /* [F, D]  dense FFN (NULL when MoE)   :101 */
+  const void* w2;             /* [D, F]                              :102 */
+  const void* w3;             /* [F, D]                              :103 */
+  const void* gate;           /* [E, D]  MoE router (NULL when dense) moe.py:20 */
+  const void* const* expert_w_dev;  /* DEVICE array [E][3] of (w1,w2,w3) pointers, moe.py:19 */
+  const void* const* expert_w_host; /* the same table in host memory */
+} mi_layer_t;
+
+typedef struct mi_model {
+  int32_t dim, n_heads, n_kv_heads, head_dim, hidden_dim, vocab_size;
+  int32_t n_layers;               /* layers local to this pipeline rank (transformer.py:94-98) */
+  int32_t num_experts, top_k;     /* 0,0 for dense */
+  float norm_eps;
+  const void* tok_embeddings;     /* [V, D] or NULL when pipeline_rank > 0 (transformer.py:56-57) */
+  const void* final_norm;         /* [D]    or NULL when not the last rank (transformer.py:77-79) */
+  const void* output;             /* [V, D] or NULL */
+  const float* rope_cs;           /* fp32 [rope_len, Dh/2, 2] */
+  int32_t rope_len;
+  const mi_layer_t* layers;       /* host array [n_layers] */
+} mi_model_t;
+
+enum mi_branch {
+  MI_BRANCH_NOCACHE = 0, /* cache=None: positions restart per sequence, attention unmasked         */
+  MI_BRANCH_PREFILL = 1, /* first or subsequent prefill chunk (cache.py:236-248)                   */
+  MI_BRANCH_DECODE = 2   /* all seqlens == 1 and tokens already cached (cache.py:249-254)          */
+};
+
+typedef struct mi_batch {
+  int32_t T, B, branch;
+  int32_t max_q_len;            /* host: max(seqlens) */
+  const int64_t* input_ids;     /* dev [T]; used when model->tok_embeddings != NULL */
+  /* sequence metadata, device int32.  PREFILL/NOCACHE: written by the host (one H2D copy per
+   * forward -- the reference rebuilds five tensors per LAYER, cache.py:226-263).
+   * DECODE: filled on the device from kv_seqlens by the first kernel of the step. */
+  int32_t* q_start;             /* [B+1] */
+  int32_t* kv_before;           /* [B]   */
+  int32_t* tok_seq;             /* [T]   */
+  int32_t* tok_pos;             /* [T]   */
+  int64_t* kv_seqlens;          /* dev [B] BufferCache.kv_seqlens (cache.py:170,193-195); DECODE reads
+                                   positions from it and adds 1 on the device; NULL for NOCACHE */
+  void* const* cache_k;         /* host array [n_layers] of dev [max_batch, W_l, Hkv, Dh] (cache.py:163-167) */
+  void* const* cache_v;
+  const int32_t* cache_sizes;   /* host [n_layers] W_l (cache.py:13-24) */
+  void* h;                      /* dev [T, D] bf16, in/out: the residual stream.  rank 0: overwritten by
+                                   the embedding; rank>0: holds the received activations.  On return: the
+                                   block-stack output, RMS-normalised when final_norm != NULL and
+                                   logits == NULL (transformer.py:213-219) */
+  float* logits;                /* dev [T, V] fp32 or NULL (transformer.py:235-242) */
+  void* workspace;              /* dev scratch, >= mi_workspace_bytes(model, T, B, max W) */
+  size_t workspace_bytes;
+} mi_batch_t;
+
+size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);
+/* The first 4 KiB of the workspace hold split-KV arrival counters: zero them once after allocation. */
+int mi_forward(const mi_model_t* model, const mi_batch_t* batch, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISTRAL_HIP_H */

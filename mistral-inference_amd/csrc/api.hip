@@ -1,0 +1,425 @@
+// C-ABI entry points of libmistral_hip.so (include/mistral_hip.h) and the layer-stack runner.
+//
+// mi_forward sequences, for every local layer, the launches that replace TransformerBlock.forward
+// (reference transformer_layers.py:158-169) and, around the stack, Transformer.forward_partial /
+// forward (transformer.py:163-242).  Per decode token and dense layer that is 5 launches:
+//   [RMSNorm + Wq|Wk|Wv GEMV + RoPE + ring write] [split-KV GQA attention] [Wo GEMV + residual]
+//   [RMSNorm + W1|W3 GEMV + SiLU*mul] [W2 GEMV + residual]
+// with no host synchronisation and no per-step host metadata (positions come from the device-resident
+// kv_seqlens), so a decode step can also be captured in a hipGraph by the caller.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mistral_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_detail[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_detail, sizeof(g_detail), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int hip_rc(hipError_t e, const char* what) {
+  if (e == hipSuccess) return MI_OK;
+  snprintf(g_detail, sizeof(g_detail), "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+#define MI_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != MI_OK) return _rc; \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+constexpr size_t TICKET_BYTES = 4096;
+
+struct Workspace {
+  int32_t* tickets;
+  bf16_t* xn;       // [T, D]
+  bf16_t* qkv;      // [T, (H + 2 Hkv) Dh]
+  bf16_t* attn;     // [T, H Dh]
+  bf16_t* hid;      // [T * max(1, top_k), F]
+  float* partial;   // decode attention partials
+  int32_t* sel_idx; // MoE
+  float* sel_w;
+  int32_t* counts;
+  int32_t* offsets;
+  int32_t* tok_of;
+  float* w_of;
+  bf16_t* moe_res;  // [T, D]
+  size_t total;
+};
+
+Workspace carve(const mi_model_t* m, int T, int B, int maxW, char* base) {
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  };
+  const int qkv_cols = (m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
+  const int slots = m->top_k > 0 ? m->top_k : 1;
+  w.tickets = (int32_t*)take(TICKET_BYTES);
+  w.xn = (bf16_t*)take((size_t)T * m->dim * 2);
+  w.qkv = (bf16_t*)take((size_t)T * qkv_cols * 2);
+  w.attn = (bf16_t*)take((size_t)T * m->n_heads * m->head_dim * 2);
+  w.hid = (bf16_t*)take((size_t)T * slots * m->hidden_dim * 2);
+  w.partial = (float*)take(attn_decode_partial_floats(B, m->n_heads, m->n_kv_heads, m->head_dim, maxW) * sizeof(float));
+  w.sel_idx = (int32_t*)take((size_t)T * slots * 4);
+  w.sel_w = (float*)take((size_t)T * slots * 4);
+  w.counts = (int32_t*)take(64 * 4);
+  w.offsets = (int32_t*)take(64 * 4);
+  w.tok_of = (int32_t*)take((size_t)T * slots * 4);
+  w.w_of = (float*)take((size_t)T * slots * 4);
+  w.moe_res = (bf16_t*)take(m->num_experts > 0 ? (size_t)T * m->dim * 2 : 0);
+  w.total = off;
+  return w;
+}
+
+// GEMV over T <= 8 tokens, in passes when T * K does not fit the LDS budget.
+int gemv_passes(GemvArgs a, int T, hipStream_t s, const char* what) {
+  const int cap = gemv_max_tokens(a.K);
+  const size_t out_elt = (a.mode == GEMV_LOGITS) ? 4 : 2;
+  for (int t0 = 0; t0 < T; t0 += cap) {
+    GemvArgs p = a;
+    p.T = (T - t0 < cap) ? T - t0 : cap;
+    p.x = a.x + (size_t)t0 * a.ldx;
+    p.out = (char*)a.out + (size_t)t0 * a.ldo * out_elt;
+    if (a.residual) p.residual = a.residual + (size_t)t0 * a.ldo;
+    if (a.tok_pos) p.tok_pos = a.tok_pos + t0;
+    if (a.tok_seq) p.tok_seq = a.tok_seq + t0;
+    MI_TRY(hip_rc(launch_gemv(p, s), what));
+  }
+  return MI_OK;
+}
+
+int check_model(const mi_model_t* m) {
+  if (!m || !m->layers) return fail(MI_ERR_ARG, "null model");
+  if (m->head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim %d: kernels are built for 128", m->head_dim);
+  if (m->n_heads % m->n_kv_heads) return fail(MI_ERR_SHAPE, "n_heads %% n_kv_heads != 0");
+  const int R = m->n_heads / m->n_kv_heads;
+  if (!(R == 1 || R == 2 || R == 4 || R == 6 || R == 8)) return fail(MI_ERR_SHAPE, "GQA ratio %d unsupported", R);
+  if (m->dim % 8 || m->hidden_dim % 8) return fail(MI_ERR_SHAPE, "dim/hidden_dim must be multiples of 8");
+  if (m->dim > 16384) return fail(MI_ERR_SHAPE, "dim > 16384");
+  if (m->num_experts > 16 || m->top_k > 4 || (m->top_k == 3)) return fail(MI_ERR_SHAPE, "MoE: E <= 16, top_k in {1,2,4}");
+  if (m->num_experts > 0 && (size_t)m->top_k * m->hidden_dim * 2 > 65536)
+    return fail(MI_ERR_SHAPE, "MoE: top_k * hidden_dim too large for the decode combine kernel");
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_abi_version(void) { return MI_ABI_VERSION; }
+
+const char* mi_last_error_detail(void) { return g_detail; }
+
+const char* mi_error_string(int code) {
+  switch (code) {
+    case MI_OK: return "ok";
+    case MI_ERR_ARG: return "invalid argument";
+    case MI_ERR_SHAPE: return "shape not supported by the gfx950 kernels";
+    case MI_ERR_WORKSPACE: return "workspace too small";
+    case MI_ERR_UNSUPPORTED: return "unsupported";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int mi_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, mi_stream_t stream) {
+  if (!out || !table || !ids || T <= 0 || D <= 0 || D % 8) return fail(MI_ERR_ARG, "mi_embedding");
+  return hip_rc(launch_embedding(out, table, ids, T, D, vocab, (hipStream_t)stream), "embedding");
+}
+
+int mi_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, mi_stream_t stream) {
+  if (!out || !x || !w || T <= 0 || D <= 0 || D % 8) return fail(MI_ERR_ARG, "mi_rmsnorm");
+  return hip_rc(launch_rmsnorm(out, x, w, T, D, eps, (hipStream_t)stream), "rmsnorm");
+}
+
+int mi_rope_inplace(void* qkv, int ld, int T, int n_heads, int n_kv_heads, int head_dim, const float* rope_cs,
+                    int rope_len, const int32_t* tok_pos, mi_stream_t stream) {
+  if (!qkv || !rope_cs || !tok_pos || T <= 0 || head_dim % 8 || rope_len <= 0) return fail(MI_ERR_ARG, "mi_rope_inplace");
+  return hip_rc(launch_rope(qkv, ld, T, n_heads, n_kv_heads, head_dim, rope_cs, tok_pos, (hipStream_t)stream), "rope");
+}
+
+int mi_kv_write(void* cache_k, void* cache_v, int W, const void* k, const void* v, int ld, int T, int kv_dim,
+                const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, mi_stream_t stream) {
+  if (!cache_k || !cache_v || !k || !v || !tok_seq || !tok_pos || !q_start || W <= 0 || T <= 0 || kv_dim % 8)
+    return fail(MI_ERR_ARG, "mi_kv_write");
+  return hip_rc(launch_kv_write(cache_k, cache_v, W, k, v, ld, T, kv_dim, tok_seq, tok_pos, q_start, (hipStream_t)stream),
+                "kv_write");
+}
+
+int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const void* const w[3], const int n_rows[3],
+              int epilogue, const void* residual, const void* norm_w, float eps, mi_stream_t stream) {
+  if (!out || !x || !w || !n_rows || !w[0] || M <= 0 || K <= 0 || K % 8) return fail(MI_ERR_ARG, "mi_linear");
+  if (epilogue == MI_EPI_RESIDUAL && !residual) return fail(MI_ERR_ARG, "mi_linear: residual epilogue without residual");
+  if (epilogue == MI_EPI_SWIGLU && (!w[1] || n_rows[0] != n_rows[1])) return fail(MI_ERR_ARG, "mi_linear: swiglu needs W1, W3");
+  hipStream_t s = (hipStream_t)stream;
+  const int n0 = n_rows[0], n1 = n0 + (w[1] ? n_rows[1] : 0), n2 = n1 + (w[2] ? n_rows[2] : 0);
+  if (M <= GEMV_MAX_T) {
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = K; a.x = (const bf16_t*)x; a.ldx = ldx; a.norm_w = (const bf16_t*)norm_w; a.eps = eps;
+    a.w0 = (const bf16_t*)w[0]; a.w1 = (const bf16_t*)w[1]; a.w2 = (const bf16_t*)w[2];
+    a.out = out; a.ldo = ldo; a.residual = (const bf16_t*)residual;
+    if (epilogue == MI_EPI_SWIGLU) {
+      a.mode = GEMV_SWIGLU; a.N = n0; a.n0 = a.n1 = n0;
+    } else {
+      a.mode = epilogue == MI_EPI_STORE ? GEMV_STORE : epilogue == MI_EPI_RESIDUAL ? GEMV_RESIDUAL : GEMV_LOGITS;
+      a.N = n2; a.n0 = n0; a.n1 = n1;
+    }
+    return gemv_passes(a, M, s, "gemv");
+  }
+  if (norm_w) return fail(MI_ERR_UNSUPPORTED, "mi_linear: fused RMSNorm only on the M <= 8 path");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.K = K; g.a = (const bf16_t*)x; g.lda = ldx;
+  g.w0 = (const bf16_t*)w[0]; g.w1 = (const bf16_t*)w[1]; g.w2 = (const bf16_t*)w[2];
+  g.out = out; g.ldo = ldo; g.residual = (const bf16_t*)residual;
+  if (epilogue == MI_EPI_SWIGLU) {
+    g.epi = GEMM_SWIGLU; g.N = n0; g.n0 = g.n1 = n0;
+  } else {
+    g.epi = epilogue == MI_EPI_STORE ? GEMM_STORE : epilogue == MI_EPI_RESIDUAL ? GEMM_RESIDUAL : GEMM_LOGITS;
+    g.N = n2; g.n0 = n0; g.n1 = n1;
+  }
+  return hip_rc(launch_gemm(g, s), "gemm");
+}
+
+size_t mi_attn_decode_scratch_bytes(int B, int n_heads, int n_kv_heads, int head_dim, int W) {
+  return TICKET_BYTES + align_up(attn_decode_partial_floats(B, n_heads, n_kv_heads, head_dim, W) * sizeof(float));
+}
+
+int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const void* cache_v, int W, int B,
+                   int n_heads, int n_kv_heads, int head_dim, const int32_t* tok_pos, void* scratch,
+                   mi_stream_t stream) {
+  if (!out || !q || !cache_k || !cache_v || !tok_pos || !scratch || W <= 0 || B <= 0) return fail(MI_ERR_ARG, "mi_attn_decode");
+  if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
+  if ((size_t)B * n_kv_heads * 4 > TICKET_BYTES) return fail(MI_ERR_SHAPE, "B * n_kv_heads > 1024");
+  AttnDecodeArgs a;
+  a.out = out; a.q = (const bf16_t*)q; a.ldq = ldq; a.cache_k = (const bf16_t*)cache_k; a.cache_v = (const bf16_t*)cache_v;
+  a.W = W; a.B = B; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim; a.tok_pos = tok_pos;
+  a.tickets = (int32_t*)scratch; a.partial = (float*)((char*)scratch + TICKET_BYTES);
+  a.n_splits = attn_decode_splits(W);
+  return hip_rc(launch_attn_decode(a, (hipStream_t)stream), "attn_decode");
+}
+
+int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, const void* cache_v, int W, int B,
+                    int max_q_len, int n_heads, int n_kv_heads, int head_dim, const int32_t* q_start,
+                    const int32_t* kv_before, int causal, mi_stream_t stream) {
+  if (!out || !qkv || B <= 0 || max_q_len <= 0 || W <= 0) return fail(MI_ERR_ARG, "mi_attn_prefill");
+  if (causal && (!q_start || !kv_before)) return fail(MI_ERR_ARG, "mi_attn_prefill: metadata");
+  if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
+  AttnPrefillArgs a;
+  a.out = out; a.qkv = (const bf16_t*)qkv; a.ld = ld; a.cache_k = (const bf16_t*)cache_k; a.cache_v = (const bf16_t*)cache_v;
+  a.W = W; a.B = B; a.max_q_len = max_q_len; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim;
+  a.q_start = q_start; a.kv_before = kv_before; a.causal = causal;
+  return hip_rc(launch_attn_prefill(a, (hipStream_t)stream), "attn_prefill");
+}
+
+int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate, int E,
+                  int top_k, const void* norm_w, float eps, mi_stream_t stream) {
+  if (!sel_idx || !sel_w || !x || !gate || T <= 0 || D % 8) return fail(MI_ERR_ARG, "mi_moe_router");
+  if (E > 16 || top_k > 4 || top_k > E || top_k < 1) return fail(MI_ERR_SHAPE, "router: E <= 16, top_k <= 4");
+  return hip_rc(launch_moe_router(sel_idx, sel_w, x, ldx, T, D, gate, E, top_k, norm_w, eps, (hipStream_t)stream), "moe_router");
+}
+
+size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size) {
+  if (!model || T <= 0 || B <= 0) return 0;
+  return carve(model, T, B, max_cache_size > 0 ? max_cache_size : 1, nullptr).total;
+}
+
+int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
+  MI_TRY(check_model(m));
+  if (!bt || bt->T <= 0 || bt->B <= 0 || !bt->h || !bt->workspace) return fail(MI_ERR_ARG, "mi_forward: batch");
+  if (!bt->q_start || !bt->kv_before || !bt->tok_seq || !bt->tok_pos) return fail(MI_ERR_ARG, "mi_forward: metadata");
+  const int T = bt->T, B = bt->B, branch = bt->branch;
+  const bool has_cache = branch != MI_BRANCH_NOCACHE;
+  if (has_cache && (!bt->cache_k || !bt->cache_v || !bt->cache_sizes)) return fail(MI_ERR_ARG, "mi_forward: cache");
+  if (branch == MI_BRANCH_DECODE && (T != B || !bt->kv_seqlens)) return fail(MI_ERR_ARG, "mi_forward: decode needs T == B");
+  if ((size_t)B * m->n_kv_heads * 4 > TICKET_BYTES) return fail(MI_ERR_SHAPE, "B * n_kv_heads > 1024");
+  if (m->tok_embeddings && !bt->input_ids) return fail(MI_ERR_ARG, "mi_forward: input_ids");
+  if (bt->logits && (!m->final_norm || !m->output)) return fail(MI_ERR_ARG, "mi_forward: logits on a rank without LM head");
+  hipStream_t s = (hipStream_t)stream;
+
+  int maxW = 1;
+  if (has_cache)
+    for (int l = 0; l < m->n_layers; ++l) maxW = bt->cache_sizes[l] > maxW ? bt->cache_sizes[l] : maxW;
+  Workspace ws = carve(m, T, B, maxW, (char*)bt->workspace);
+  if (ws.total > bt->workspace_bytes)
+    return fail(MI_ERR_WORKSPACE, "workspace %zu < required %zu", bt->workspace_bytes, ws.total);
+
+  const int D = m->dim, H = m->n_heads, Hkv = m->n_kv_heads, Dh = m->head_dim, F = m->hidden_dim;
+  const int nq = H * Dh, nkv = Hkv * Dh, qkv_cols = nq + 2 * nkv;
+  const bool gemv = T <= GEMV_MAX_T;
+  bf16_t* h = (bf16_t*)bt->h;
+
+  if (branch == MI_BRANCH_DECODE)
+    MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, s), "decode_prep"));
+  if (m->tok_embeddings)
+    MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, s), "embedding"));
+
+  for (int l = 0; l < m->n_layers; ++l) {
+    const mi_layer_t& L = m->layers[l];
+    const int W = has_cache ? bt->cache_sizes[l] : 1;
+    void* ck = has_cache ? bt->cache_k[l] : nullptr;
+    void* cv = has_cache ? bt->cache_v[l] : nullptr;
+
+    // ---- attention_norm + q|k|v + RoPE (+ ring write at decode)
+    if (gemv) {
+      GemvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.mode = GEMV_QKV_ROPE; a.K = D; a.N = qkv_cols; a.x = h; a.ldx = D;
+      a.norm_w = (const bf16_t*)L.attention_norm; a.eps = m->norm_eps;
+      a.w0 = (const bf16_t*)L.wq; a.w1 = (const bf16_t*)L.wk; a.w2 = (const bf16_t*)L.wv; a.n0 = nq; a.n1 = nq + nkv;
+      a.out = ws.qkv; a.ldo = qkv_cols;
+      a.rope_cs = m->rope_cs; a.tok_pos = bt->tok_pos; a.tok_seq = bt->tok_seq; a.head_dim = Dh;
+      a.write_kv = branch == MI_BRANCH_DECODE; a.cache_k = ck; a.cache_v = cv; a.W = W;
+      MI_TRY(gemv_passes(a, T, s, "qkv gemv"));
+    } else {
+      MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, L.attention_norm, T, D, m->norm_eps, s), "attention_norm"));
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.epi = GEMM_STORE; g.M = T; g.N = qkv_cols; g.K = D; g.a = ws.xn; g.lda = D;
+      g.w0 = (const bf16_t*)L.wq; g.w1 = (const bf16_t*)L.wk; g.w2 = (const bf16_t*)L.wv; g.n0 = nq; g.n1 = nq + nkv;
+      g.out = ws.qkv; g.ldo = qkv_cols;
+      MI_TRY(hip_rc(launch_gemm(g, s), "qkv gemm"));
+      MI_TRY(hip_rc(launch_rope(ws.qkv, qkv_cols, T, H, Hkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
+    }
+
+    // ---- attention
+    if (branch == MI_BRANCH_DECODE) {
+      AttnDecodeArgs a;
+      a.out = ws.attn; a.q = ws.qkv; a.ldq = qkv_cols; a.cache_k = (const bf16_t*)ck; a.cache_v = (const bf16_t*)cv;
+      a.W = W; a.B = B; a.H = H; a.Hkv = Hkv; a.Dh = Dh; a.tok_pos = bt->tok_pos;
+      a.partial = ws.partial; a.tickets = ws.tickets; a.n_splits = attn_decode_splits(W);
+      MI_TRY(hip_rc(launch_attn_decode(a, s), "attn_decode"));
+    } else {
+      AttnPrefillArgs a;
+      a.out = ws.attn; a.qkv = ws.qkv; a.ld = qkv_cols; a.cache_k = (const bf16_t*)ck; a.cache_v = (const bf16_t*)cv;
+      a.W = has_cache ? W : T; a.B = B; a.max_q_len = has_cache ? bt->max_q_len : T; a.H = H; a.Hkv = Hkv; a.Dh = Dh;
+      a.q_start = bt->q_start; a.kv_before = bt->kv_before; a.causal = has_cache ? 1 : 0;
+      MI_TRY(hip_rc(launch_attn_prefill(a, s), "attn_prefill"));
+      if (has_cache)
+        MI_TRY(hip_rc(launch_kv_write(ck, cv, W, ws.qkv + nq, ws.qkv + nq + nkv, qkv_cols, T, nkv, bt->tok_seq, bt->tok_pos,
+                                      bt->q_start, s), "kv_write"));
+    }
+
+    // ---- h = h + attn @ Wo^T
+    if (gemv) {
+      GemvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.mode = GEMV_RESIDUAL; a.K = nq; a.N = D; a.x = ws.attn; a.ldx = nq;
+      a.w0 = (const bf16_t*)L.wo; a.n0 = a.n1 = D; a.out = h; a.ldo = D; a.residual = h;
+      MI_TRY(gemv_passes(a, T, s, "wo gemv"));
+    } else {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.epi = GEMM_RESIDUAL; g.M = T; g.N = D; g.K = nq; g.a = ws.attn; g.lda = nq;
+      g.w0 = (const bf16_t*)L.wo; g.n0 = g.n1 = D; g.out = h; g.ldo = D; g.residual = h;
+      MI_TRY(hip_rc(launch_gemm(g, s), "wo gemm"));
+    }
+
+    // ---- h = h + FFN(ffn_norm(h))
+    const bool moe = m->num_experts > 0;
+    if (!moe) {
+      if (gemv) {
+        GemvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_SWIGLU; a.K = D; a.N = F; a.x = h; a.ldx = D;
+        a.norm_w = (const bf16_t*)L.ffn_norm; a.eps = m->norm_eps;
+        a.w0 = (const bf16_t*)L.w1; a.w1 = (const bf16_t*)L.w3; a.n0 = a.n1 = F; a.out = ws.hid; a.ldo = F;
+        MI_TRY(gemv_passes(a, T, s, "w13 gemv"));
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_RESIDUAL; a.K = F; a.N = D; a.x = ws.hid; a.ldx = F;
+        a.w0 = (const bf16_t*)L.w2; a.n0 = a.n1 = D; a.out = h; a.ldo = D; a.residual = h;
+        MI_TRY(gemv_passes(a, T, s, "w2 gemv"));
+      } else {
+        MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.epi = GEMM_SWIGLU; g.M = T; g.N = F; g.K = D; g.a = ws.xn; g.lda = D;
+        g.w0 = (const bf16_t*)L.w1; g.w1 = (const bf16_t*)L.w3; g.n0 = g.n1 = F; g.out = ws.hid; g.ldo = F;
+        MI_TRY(hip_rc(launch_gemm(g, s), "w13 gemm"));
+        memset(&g, 0, sizeof(g));
+        g.epi = GEMM_RESIDUAL; g.M = T; g.N = D; g.K = F; g.a = ws.hid; g.lda = F;
+        g.w0 = (const bf16_t*)L.w2; g.n0 = g.n1 = D; g.out = h; g.ldo = D; g.residual = h;
+        MI_TRY(hip_rc(launch_gemm(g, s), "w2 gemm"));
+      }
+    } else {
+      const int E = m->num_experts, k = m->top_k;
+      if (!L.gate || !L.expert_w_dev || !L.expert_w_host) return fail(MI_ERR_ARG, "mi_forward: MoE layer tables");
+      if (gemv) {
+        MI_TRY(hip_rc(launch_moe_router(ws.sel_idx, ws.sel_w, h, D, T, D, L.gate, E, k, L.ffn_norm, m->norm_eps, s), "moe_router"));
+        GemvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_MOE_W13; a.T = T; a.K = D; a.N = F; a.x = h; a.ldx = D;
+        a.norm_w = (const bf16_t*)L.ffn_norm; a.eps = m->norm_eps; a.out = ws.hid; a.ldo = F;
+        a.expert_tab = L.expert_w_dev; a.sel_idx = ws.sel_idx; a.sel_w = ws.sel_w; a.top_k = k;
+        MI_TRY(hip_rc(launch_gemv(a, s), "moe w13 gemv"));
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_MOE_W2; a.T = T; a.K = F; a.N = D; a.x = ws.hid; a.ldx = F; a.out = h; a.ldo = D; a.residual = h;
+        a.expert_tab = L.expert_w_dev; a.sel_idx = ws.sel_idx; a.sel_w = ws.sel_w; a.top_k = k;
+        MI_TRY(hip_rc(launch_gemv(a, s), "moe w2 gemv"));
+      } else {
+        MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
+        MI_TRY(hip_rc(launch_moe_router(ws.sel_idx, ws.sel_w, ws.xn, D, T, D, L.gate, E, k, nullptr, 0.f, s), "moe_router"));
+        MI_TRY(hip_rc(launch_moe_lists(ws.sel_idx, ws.sel_w, T, E, k, ws.counts, ws.offsets, ws.tok_of, ws.w_of, s), "moe_lists"));
+        MI_TRY(hip_rc(hipMemsetAsync(ws.moe_res, 0, (size_t)T * D * 2, s), "moe memset"));
+        for (int e = 0; e < E; ++e) {  // ascending expert id = the reference's accumulation order (moe.py:29)
+          GemmArgs g;
+          memset(&g, 0, sizeof(g));
+          g.epi = GEMM_SWIGLU; g.M = T; g.N = F; g.K = D; g.a = ws.xn; g.lda = D;
+          g.w0 = (const bf16_t*)L.expert_w_host[e * 3 + 0]; g.w1 = (const bf16_t*)L.expert_w_host[e * 3 + 2];
+          g.n0 = g.n1 = F; g.out = ws.hid; g.ldo = F;
+          g.m_count = ws.counts + e; g.row_base = ws.offsets + e; g.a_gather = ws.tok_of;
+          MI_TRY(hip_rc(launch_gemm(g, s), "moe w13 gemm"));
+          memset(&g, 0, sizeof(g));
+          g.epi = GEMM_MOE_ACCUM; g.M = T; g.N = D; g.K = F; g.a = ws.hid; g.lda = F;
+          g.w0 = (const bf16_t*)L.expert_w_host[e * 3 + 1]; g.n0 = g.n1 = D; g.out = ws.moe_res; g.ldo = D;
+          g.m_count = ws.counts + e; g.row_base = ws.offsets + e; g.out_scatter = ws.tok_of; g.row_scale = ws.w_of;
+          MI_TRY(hip_rc(launch_gemm(g, s), "moe w2 gemm"));
+        }
+        MI_TRY(hip_rc(launch_add_rows(h, h, ws.moe_res, (size_t)T * D, s), "moe residual"));
+      }
+    }
+  }
+
+  // ---- final norm (+ LM head)
+  if (m->final_norm) {
+    if (bt->logits) {
+      if (gemv) {
+        GemvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_LOGITS; a.K = D; a.N = m->vocab_size; a.x = h; a.ldx = D;
+        a.norm_w = (const bf16_t*)m->final_norm; a.eps = m->norm_eps;
+        a.w0 = (const bf16_t*)m->output; a.n0 = a.n1 = m->vocab_size; a.out = bt->logits; a.ldo = m->vocab_size;
+        MI_TRY(gemv_passes(a, T, s, "lm head gemv"));
+      } else {
+        MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.epi = GEMM_LOGITS; g.M = T; g.N = m->vocab_size; g.K = D; g.a = ws.xn; g.lda = D;
+        g.w0 = (const bf16_t*)m->output; g.n0 = g.n1 = m->vocab_size; g.out = bt->logits; g.ldo = m->vocab_size;
+        MI_TRY(hip_rc(launch_gemm(g, s), "lm head gemm"));
+      }
+    } else {
+      MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+    }
+  }
+  return MI_OK;
+}
+
+}  // extern "C"

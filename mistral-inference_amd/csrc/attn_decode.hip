@@ -1,0 +1,222 @@
+// Decode-branch attention: one query per sequence against its rotating K/V ring.
+//
+// Replaces transformer_layers.py:77-89 at decode: `repeat_kv` (the reference materialises R copies of
+// the whole padded ring per token, :16-19,84) plus xformers FMHA under
+// BlockDiagonalCausalWithOffsetPaddedKeysMask (cache.py:249-254): sequence b sees ring slots
+// [0, min(pos_b + 1, W)) of its own row; slot order is irrelevant (RoPE applied before caching).
+//
+// HBM-bound (K and V of the ring are read exactly once): grid = (splits, kv_head, sequence); each
+// block streams a contiguous slot range for ONE kv head and serves all R = H/Hkv query heads from
+// the same registers.  A wave-load covers 4 slots x 256 B; 16 lanes share a slot, scores are reduced
+// with DPP row rotations; online softmax is kept per 16-lane group (no cross-lane sync in the loop)
+// and merged once at the end: lanes -> waves (LDS) -> splits (global fp32 partials; the last block to
+// arrive for a (sequence, kv head) combines them - agent-scope release/acquire, guide section 6 G16).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int DH = 128;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int R>
+struct State {
+  float m[R], l[R], acc[R][8];
+};
+
+template <int R>
+__device__ __forceinline__ void merge_from(State<R>& s, int off) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float mo = __shfl_xor(s.m[r], off, 64);
+    const float lo = __shfl_xor(s.l[r], off, 64);
+    const float M = fmaxf(s.m[r], mo);
+    const float a1 = exp2f(s.m[r] - M), a2 = exp2f(mo - M);
+    s.l[r] = s.l[r] * a1 + lo * a2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float ao = __shfl_xor(s.acc[r][i], off, 64);
+      s.acc[r][i] = s.acc[r][i] * a1 + ao * a2;
+    }
+    s.m[r] = M;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
+  __shared__ float sm_m[4][R];
+  __shared__ float sm_l[4][R];
+  __shared__ float sm_acc[4][R][DH];
+  __shared__ int sm_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, dl = lane & 15;
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int pos = a.tok_pos[b];
+  const int kv_len = min(pos + 1, a.W);
+  int chunk = (a.W + a.n_splits - 1) / a.n_splits;
+  chunk = (chunk + 15) & ~15;
+  const int s_begin = split * chunk;
+  const int s_end = min(s_begin + chunk, kv_len);
+  const float sc = rsqrtf((float)DH) * LOG2E;
+
+  float qf[R][8];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32x4 v = ld16(a.q + (size_t)b * a.ldq + (size_t)(kvh * R + r) * DH + dl * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qf[r][2 * i] = bf_lo(v[i]) * sc;
+      qf[r][2 * i + 1] = bf_hi(v[i]) * sc;
+    }
+  }
+  State<R> st;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    st.m[r] = -1e30f;
+    st.l[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st.acc[r][i] = 0.f;
+  }
+
+  const size_t row_stride = (size_t)a.Hkv * DH;  // elements between consecutive slots
+  const bf16_t* kbase = a.cache_k + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
+  const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
+
+  int s = s_begin + wid * 4 + g;
+  u32x4 kc = {0u, 0u, 0u, 0u}, vc = {0u, 0u, 0u, 0u};
+  if (s < s_end) {
+    kc = ld16_nt(kbase + (size_t)s * row_stride);
+    vc = ld16_nt(vbase + (size_t)s * row_stride);
+  }
+  for (int s0 = s_begin; s0 < s_end; s0 += 16) {
+    const bool valid = s < s_end;
+    const int sn = s + 16;
+    u32x4 kn = {0u, 0u, 0u, 0u}, vn = {0u, 0u, 0u, 0u};
+    if (sn < s_end) {
+      kn = ld16_nt(kbase + (size_t)sn * row_stride);
+      vn = ld16_nt(vbase + (size_t)sn * row_stride);
+    }
+    float kf[8], vf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kf[2 * i] = bf_lo(kc[i]);
+      kf[2 * i + 1] = bf_hi(kc[i]);
+      vf[2 * i] = bf_lo(vc[i]);
+      vf[2 * i + 1] = bf_hi(vc[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d = fmaf(qf[r][i], kf[i], d);
+      d = row16_sum(d);
+      const float mn = valid ? fmaxf(st.m[r], d) : st.m[r];
+      const float alpha = exp2f(st.m[r] - mn);
+      const float p = valid ? exp2f(d - mn) : 0.f;
+      st.m[r] = mn;
+      st.l[r] = st.l[r] * alpha + p;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i] * alpha);
+    }
+    kc = kn;
+    vc = vn;
+    s = sn;
+  }
+
+  // 4 lane groups -> wave
+  merge_from<R>(st, 16);
+  merge_from<R>(st, 32);
+  if (g == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (dl == 0) {
+        sm_m[wid][r] = st.m[r];
+        sm_l[wid][r] = st.l[r];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sm_acc[wid][r][dl * 8 + i] = st.acc[r][i];
+    }
+  }
+  __syncthreads();
+
+  // 4 waves -> block partial in global scratch
+  const int bh = b * a.Hkv + kvh;
+  float* p_acc = a.partial + ((size_t)bh * a.n_splits + split) * R * DH;
+  float* p_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + ((size_t)bh * a.n_splits + split) * R * 2;
+  for (int idx = tid; idx < R * DH; idx += 256) {
+    const int r = idx / DH, d = idx % DH;
+    const float M = fmaxf(fmaxf(sm_m[0][r], sm_m[1][r]), fmaxf(sm_m[2][r], sm_m[3][r]));
+    float L = 0.f, A = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = exp2f(sm_m[w][r] - M);
+      L += sm_l[w][r] * e;
+      A += sm_acc[w][r][d] * e;
+    }
+    p_acc[idx] = A;
+    if (d == 0) {
+      p_ml[r * 2] = M;
+      p_ml[r * 2 + 1] = L;
+    }
+  }
+
+  // arrival ticket; the last block of this (sequence, kv head) combines all splits
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&a.tickets[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (ticket == a.n_splits - 1);
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sm_last = last;
+  }
+  __syncthreads();
+  if (!sm_last) return;
+
+  const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH;
+  const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2;
+  for (int idx = tid; idx < R * DH; idx += 256) {
+    const int r = idx / DH, d = idx % DH;
+    float M = -1e30f;
+    for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, all_ml[(sp * R + r) * 2]);
+    float L = 0.f, A = 0.f;
+    for (int sp = 0; sp < a.n_splits; ++sp) {
+      const float e = exp2f(all_ml[(sp * R + r) * 2] - M);
+      L += all_ml[(sp * R + r) * 2 + 1] * e;
+      A += all_acc[(size_t)sp * R * DH + idx] * e;
+    }
+    reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)(kvh * R + r) * DH + d] = f_to_bf(A / L);
+  }
+  if (tid == 0) __hip_atomic_store(&a.tickets[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+int attn_decode_splits(int W) {
+  int n = (W + 127) / 128;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return n;
+}
+
+size_t attn_decode_partial_floats(int B, int H, int Hkv, int Dh, int W) {
+  const int R = H / Hkv;
+  return (size_t)B * Hkv * attn_decode_splits(W) * R * (Dh + 2);
+}
+
+hipError_t launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
+  if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
+  const int R = a.H / a.Hkv;
+  dim3 grid(a.n_splits, a.Hkv, a.B), block(256);
+  switch (R) {
+    case 1: hipLaunchKernelGGL((attn_decode_kernel<1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_decode_kernel<2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((attn_decode_kernel<4>), grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((attn_decode_kernel<6>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((attn_decode_kernel<8>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,66 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 payload
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MI_WAVE 64
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf_to_f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// fp32 -> bf16, round to nearest even (what torch's .to(bfloat16) does); NaN stays NaN.
+__device__ __forceinline__ uint32_t f_to_bf_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+  r = (f != f) ? (u | 0x00400000u) : r;
+  return r >> 16;
+}
+__device__ __forceinline__ bf16_t f_to_bf(float f) { return (bf16_t)f_to_bf_bits(f); }
+// value after a round trip through bf16 (a rounding point of the reference)
+__device__ __forceinline__ float bf_round(float f) { return __uint_as_float(f_to_bf_bits(f) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f_to_bf_bits(lo) | (f_to_bf_bits(hi) << 16); }
+
+// 16-byte loads.  `nt` marks streamed-once data (weights at decode): MI355X_MICROARCH "nt-weights".
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// Sum over the 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Sum over each aligned group of 16 lanes (a DPP "row"); every lane of the row gets the total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  v += __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, true);  // row_ror:4
+  v += __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, true);  // row_ror:2
+  v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, true);  // row_ror:1
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// The reference's SiLU runs on a bf16 tensor: silu evaluated in fp32, rounded to bf16; then the product
+// with the bf16 up-projection is rounded again (transformer_layers.py:105-106).
+__device__ __forceinline__ float swiglu_bf(float acc1, float acc3) {
+  float a = bf_round(acc1), b = bf_round(acc3);
+  float s = bf_round(a / (1.0f + expf(-a)));
+  return s * b;  // caller rounds to bf16
+}

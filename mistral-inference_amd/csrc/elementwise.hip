@@ -1,0 +1,304 @@
+// Memory-bound elementwise / row kernels of the hot path.  All bf16 traffic is 16 bytes per lane.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+// transformer.py:193
+__global__ __launch_bounds__(256) void embedding_kernel(bf16_t* out, const bf16_t* table, const int64_t* ids, int D,
+                                                        int vocab) {
+  const int t = blockIdx.x;
+  long id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // torch would raise; clamp instead of faulting
+  const bf16_t* src = table + (size_t)id * D;
+  bf16_t* dst = out + (size_t)t * D;
+  for (int p = threadIdx.x; p < (D >> 3); p += 256) st16(dst + p * 8, ld16(src + p * 8));
+}
+
+// transformer_layers.py:115-120.  One block per row; the row is kept in registers between the passes.
+constexpr int NORM_MAX_PIECES = 8;  // D <= 256 * 8 * 8 = 16384
+__global__ __launch_bounds__(256) void rmsnorm_kernel(bf16_t* out, const bf16_t* x, const bf16_t* w, int D, float eps) {
+  __shared__ float red[4];
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bf16_t* xr = x + (size_t)t * D;
+  const int np = D >> 3;
+  u32x4 v[NORM_MAX_PIECES];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NORM_MAX_PIECES; ++j) {
+    const int p = tid + j * 256;
+    v[j] = u32x4{0u, 0u, 0u, 0u};
+    if (p < np) {
+      v[j] = ld16(xr + p * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = bf_lo(v[j][i]), b = bf_hi(v[j][i]);
+        ss = fmaf(a, a, ss);
+        ss = fmaf(b, b, ss);
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wid] = ss;
+  __syncthreads();
+  const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+#pragma unroll
+  for (int j = 0; j < NORM_MAX_PIECES; ++j) {
+    const int p = tid + j * 256;
+    if (p < np) {
+      const u32x4 wv = ld16(w + p * 8);
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf2(bf_round(bf_lo(v[j][i]) * inv) * bf_lo(wv[i]), bf_round(bf_hi(v[j][i]) * inv) * bf_hi(wv[i]));
+      st16(out + (size_t)t * D + p * 8, o);
+    }
+  }
+}
+
+// rope.py:13-23, in place on the q|k columns of the fused buffer.  One thread rotates 4 adjacent pairs.
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* qkv, int ld, int T, int n_rot_cols, int Dh,
+                                                   const float* rope_cs, const int32_t* tok_pos) {
+  const int pieces_per_row = n_rot_cols >> 3;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)T * pieces_per_row) return;
+  const int t = (int)(gid / pieces_per_row), p = (int)(gid % pieces_per_row);
+  const int col = p * 8;
+  const int i0 = (col % Dh) >> 1;
+  bf16_t* ptr = qkv + (size_t)t * ld + col;
+  const u32x4 v = ld16(ptr);
+  const float* cs = rope_cs + ((size_t)tok_pos[t] * (Dh >> 1) + i0) * 2;
+  const f32x4 c01 = *reinterpret_cast<const f32x4*>(cs);
+  const f32x4 c23 = *reinterpret_cast<const f32x4*>(cs + 4);
+  const float cc[4] = {c01[0], c01[2], c23[0], c23[2]};
+  const float sn[4] = {c01[1], c01[3], c23[1], c23[3]};
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = bf_lo(v[i]), b = bf_hi(v[i]);
+    const float re = __fsub_rn(__fmul_rn(a, cc[i]), __fmul_rn(b, sn[i]));
+    const float im = __fadd_rn(__fmul_rn(a, sn[i]), __fmul_rn(b, cc[i]));
+    o[i] = pack_bf2(re, im);
+  }
+  st16(ptr, o);
+}
+
+// cache.py:83-92 + 226-235
+__global__ __launch_bounds__(256) void kv_write_kernel(bf16_t* ck, bf16_t* cv, int W, const bf16_t* k, const bf16_t* v,
+                                                       int ld, int T, int kv_dim, const int32_t* tok_seq,
+                                                       const int32_t* tok_pos, const int32_t* q_start) {
+  const int pieces = kv_dim >> 3;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)T * pieces) return;
+  const int t = (int)(gid / pieces), p = (int)(gid % pieces);
+  const int b = tok_seq[t];
+  const int i = t - q_start[b];
+  const int s = q_start[b + 1] - q_start[b];
+  if (i < s - W) return;  // to_cache_mask: only the last W tokens of the chunk are stored
+  const size_t slot = (size_t)b * W + (tok_pos[t] % W);
+  st16(ck + slot * kv_dim + p * 8, ld16(k + (size_t)t * ld + p * 8));
+  st16(cv + slot * kv_dim + p * 8, ld16(v + (size_t)t * ld + p * 8));
+}
+
+// Decode step metadata from the device-resident kv_seqlens (no host round trip), then
+// kv_seqlens += 1 (cache.py:193-195 update_seqlens for seqlens = [1]*B).
+__global__ void decode_prep_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
+                                   int32_t* tok_pos, int B) {
+  const int b = threadIdx.x;
+  if (b < B) {
+    const int p = (int)kv_seqlens[b];
+    kv_before[b] = p;
+    tok_pos[b] = p;
+    tok_seq[b] = b;
+    q_start[b] = b;
+    kv_seqlens[b] = p + 1;
+  }
+  if (b == 0) q_start[B] = B;
+}
+
+// out = bf16(a + b) (transformer_layers.py:168 for the MoE prefill path)
+__global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* out, const bf16_t* a, const bf16_t* b, size_t npieces) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npieces) return;
+  const u32x4 x = ld16(a + p * 8), y = ld16(b + p * 8);
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack_bf2(bf_lo(x[i]) + bf_lo(y[i]), bf_hi(x[i]) + bf_hi(y[i]));
+  st16(out + p * 8, o);
+}
+
+// moe.py:25-27.  One wave per token.  logits_e = bf16(x . Wg[e]) ; top-k ; softmax over the k ; bf16.
+constexpr int MOE_MAX_E = 16;
+__global__ __launch_bounds__(64) void moe_router_kernel(int32_t* sel_idx, float* sel_w, const bf16_t* x, int ldx, int D,
+                                                        const bf16_t* gate, int E, int top_k, const bf16_t* norm_w,
+                                                        float eps) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const bf16_t* xr = x + (size_t)t * ldx;
+  float inv = 1.f;
+  if (norm_w) {
+    float ss = 0.f;
+    for (int p = lane; p < (D >> 3); p += 64) {
+      const u32x4 v = ld16(xr + p * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = bf_lo(v[i]), b = bf_hi(v[i]);
+        ss = fmaf(a, a, ss);
+        ss = fmaf(b, b, ss);
+      }
+    }
+    ss = wave_sum(ss);
+    inv = 1.0f / sqrtf(ss / (float)D + eps);
+  }
+  float acc[MOE_MAX_E];
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e) acc[e] = 0.f;
+  for (int p = lane; p < (D >> 3); p += 64) {
+    const u32x4 v = ld16(xr + p * 8);
+    float xf[8];
+    if (norm_w) {
+      const u32x4 wv = ld16(norm_w + p * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[2 * i] = bf_round(bf_round(bf_lo(v[i]) * inv) * bf_lo(wv[i]));
+        xf[2 * i + 1] = bf_round(bf_round(bf_hi(v[i]) * inv) * bf_hi(wv[i]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[2 * i] = bf_lo(v[i]);
+        xf[2 * i + 1] = bf_hi(v[i]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) {
+      if (e < E) {
+        const u32x4 g = ld16(gate + (size_t)e * D + p * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[e] = fmaf(bf_lo(g[i]), xf[2 * i], acc[e]);
+          acc[e] = fmaf(bf_hi(g[i]), xf[2 * i + 1], acc[e]);
+        }
+      }
+    }
+  }
+  float logit[MOE_MAX_E];
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e) logit[e] = (e < E) ? bf_round(wave_sum(acc[e])) : -INFINITY;
+  if (lane == 0) {
+    float tw[4];
+    int ti[4];
+    unsigned taken = 0;
+    for (int k = 0; k < top_k; ++k) {
+      int best = -1;
+      float bv = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < MOE_MAX_E; ++e)
+        if (e < E && !((taken >> e) & 1u) && (best < 0 || logit[e] > bv)) {
+          best = e;
+          bv = logit[e];
+        }
+      taken |= 1u << best;
+      ti[k] = best;
+      tw[k] = bv;
+    }
+    float den = 0.f, ex[4];
+    for (int k = 0; k < top_k; ++k) {
+      ex[k] = expf(tw[k] - tw[0]);
+      den += ex[k];
+    }
+    for (int k = 0; k < top_k; ++k) {
+      sel_idx[t * top_k + k] = ti[k];
+      sel_w[t * top_k + k] = bf_round(ex[k] / den);
+    }
+  }
+}
+
+// Per-expert token lists for grouped prefill GEMMs: entries are ordered by token within an expert,
+// so every launch is deterministic.  Single block; T*top_k is at most a few tens of thousands.
+__global__ __launch_bounds__(256) void moe_lists_kernel(const int32_t* sel_idx, const float* sel_w, int T, int E,
+                                                        int top_k, int32_t* counts, int32_t* offsets, int32_t* tok_of,
+                                                        float* w_of) {
+  __shared__ int cnt[MOE_MAX_E];
+  __shared__ int off[MOE_MAX_E + 1];
+  const int tid = threadIdx.x;
+  // one wave per expert group would be faster; one thread per expert walking the tokens keeps order trivially
+  if (tid < E) {
+    int c = 0;
+    for (int i = 0; i < T * top_k; ++i) c += (sel_idx[i] == tid);
+    cnt[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int e = 0; e < E; ++e) {
+      off[e] = o;
+      o += cnt[e];
+    }
+    off[E] = o;
+  }
+  __syncthreads();
+  if (tid < E) {
+    counts[tid] = cnt[tid];
+    offsets[tid] = off[tid];
+    int o = off[tid];
+    for (int i = 0; i < T * top_k; ++i)
+      if (sel_idx[i] == tid) {
+        tok_of[o] = i / top_k;
+        w_of[o] = sel_w[i];
+        ++o;
+      }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s) {
+  hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)table, ids, D, vocab);
+  return hipGetLastError();
+}
+hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s) {
+  if (D > 256 * 8 * NORM_MAX_PIECES) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)x, (const bf16_t*)w, D, eps);
+  return hipGetLastError();
+}
+hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const float* rope_cs, const int32_t* tok_pos,
+                       hipStream_t s) {
+  const int cols = (H + Hkv) * Dh;
+  const long n = (long)T * (cols >> 3);
+  hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)qkv, ld, T, cols, Dh,
+                     rope_cs, tok_pos);
+  return hipGetLastError();
+}
+hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
+                           const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s) {
+  const long n = (long)T * (kv_dim >> 3);
+  hipLaunchKernelGGL(kv_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)ck, (bf16_t*)cv, W,
+                     (const bf16_t*)k, (const bf16_t*)v, ld, T, kv_dim, tok_seq, tok_pos, q_start);
+  return hipGetLastError();
+}
+hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
+                              int32_t* tok_pos, int B, hipStream_t s) {
+  if (B > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(decode_prep_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, s, kv_seqlens, q_start, kv_before,
+                     tok_seq, tok_pos, B);
+  return hipGetLastError();
+}
+hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s) {
+  const size_t np = n >> 3;
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (bf16_t*)out,
+                     (const bf16_t*)a, (const bf16_t*)b, np);
+  return hipGetLastError();
+}
+hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate,
+                             int E, int top_k, const void* norm_w, float eps, hipStream_t s) {
+  if (E > MOE_MAX_E || top_k > 4 || top_k > E) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moe_router_kernel, dim3(T), dim3(64), 0, s, sel_idx, sel_w, (const bf16_t*)x, ldx, D,
+                     (const bf16_t*)gate, E, top_k, (const bf16_t*)norm_w, eps);
+  return hipGetLastError();
+}
+hipError_t launch_moe_lists(const int32_t* sel_idx, const float* sel_w, int T, int E, int top_k, int32_t* counts,
+                            int32_t* offsets, int32_t* tok_of, float* w_of, hipStream_t s) {
+  hipLaunchKernelGGL(moe_lists_kernel, dim3(1), dim3(256), 0, s, sel_idx, sel_w, T, E, top_k, counts, offsets, tok_of,
+                     w_of);
+  return hipGetLastError();
+}

@@ -1,0 +1,184 @@
+// bf16 MFMA GEMM for the prefill branch (M > 8 tokens): out[M,N] = epilogue(A[M,K] . W[N,K]^T).
+//
+// Replaces the reference's nn.Linear GEMMs at prefill (transformer_layers.py:66,93,105-106;
+// transformer.py:235) with the residual add / SiLU*mul / bf16->fp32 widening fused into the epilogue,
+// and (grouped form) moe.py:28-32's per-expert gather -> FFN -> weighted scatter-add.
+//
+// Both operands are K-contiguous ("B^T input"), so A and W fragments are 16-byte row slices.
+// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.  Operands are
+// staged HBM -> VGPR -> LDS (double-buffered, one barrier per K step, next tile's global loads issued
+// before the current tile's MFMAs); the LDS image is XOR-swizzled on the 16-byte slot index
+// (slot ^= row & 7) so the ds_read_b128 fragment reads are conflict-free.
+//
+// SWIGLU form: the B tile holds 64 rows of W1 and the matching 64 rows of W3, every wave accumulates
+// both for the same (token, j) and the epilogue is elementwise in registers.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * (BK * 2) + ((slot ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ const bf16_t* seg_row(const GemmArgs& g, int r) {
+  if (r < g.n0) return g.w0 + (size_t)r * g.K;
+  if (r < g.n1) return g.w1 + (size_t)(r - g.n0) * g.K;
+  return g.w2 + (size_t)(r - g.n1) * g.K;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + 2 * TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int M = g.m_count ? *g.m_count : g.M;
+  const int base = g.row_base ? *g.row_base : 0;
+  const int m_tiles = (g.M + BM - 1) / BM;
+  const int m_tile = blockIdx.x % m_tiles, n_tile = blockIdx.x / m_tiles;
+  if (m_tile * BM >= M) return;
+  constexpr int NOUT = (EPI == GEMM_SWIGLU) ? 64 : 128;  // output columns per block
+
+  // ---- global -> LDS staging assignment: thread owns 16-byte slot (tid & 7) of rows (tid >> 3) + 32 j
+  const int slot = tid & 7;
+  const bf16_t* arow[4];
+  const bf16_t* brow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (tid >> 3) + 32 * j;
+    int m = base + min(m_tile * BM + r, M - 1);
+    if (g.a_gather) m = g.a_gather[m];
+    arow[j] = g.a + (size_t)m * g.lda + slot * 8;
+    if (EPI == GEMM_SWIGLU) {
+      const int jj = min(n_tile * 64 + (r & 63), g.N - 1);
+      brow[j] = ((r < 64) ? g.w0 : g.w1) + (size_t)jj * g.K + slot * 8;
+    } else {
+      brow[j] = seg_row(g, min(n_tile * BN + r, g.N - 1)) + slot * 8;
+    }
+  }
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int koff = kt * BK;
+    const bool ok = koff + slot * 8 < g.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      ra[j] = ok ? ld16(arow[j] + koff) : z;
+      rb[j] = ok ? ld16(brow[j] + koff) : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (tid >> 3) + 32 * j;
+      st16(sA + buf * TILE_BYTES + lds_off(r, slot), ra[j]);
+      st16(sB + buf * TILE_BYTES + lds_off(r, slot), rb[j]);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* a_s = sA + buf * TILE_BYTES;
+    const char* b_s = sB + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int fs = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int r = wm * 64 + mt * 16 + (lane & 15);
+        af[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_s + lds_off(r, fs)));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int r;
+        if (EPI == GEMM_SWIGLU) r = (nt >> 1) * 64 + wn * 32 + (nt & 1) * 16 + (lane & 15);
+        else r = wn * 64 + nt * 16 + (lane & 15);
+        bfr[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_s + lds_off(r, fs)));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[mt][nt][r] is row wm*64 + mt*16 + (lane>>4)*4 + r, column (lane & 15) of its tile
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m_tile * BM + wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
+      if (m >= M) continue;
+      if (EPI == GEMM_SWIGLU) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = n_tile * NOUT + wn * 32 + s * 16 + (lane & 15);
+          if (j < g.N)
+            reinterpret_cast<bf16_t*>(g.out)[(size_t)(base + m) * g.ldo + j] = f_to_bf(swiglu_bf(acc[mt][s][r], acc[mt][2 + s][r]));
+        }
+      } else {
+        size_t orow = (size_t)(base + m);
+        float scale = 1.f;
+        if (EPI == GEMM_MOE_ACCUM) {
+          scale = g.row_scale[base + m];
+          orow = (size_t)g.out_scatter[base + m];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = n_tile * BN + wn * 64 + nt * 16 + (lane & 15);
+          if (n >= g.N) continue;
+          const float y = bf_round(acc[mt][nt][r]);
+          if (EPI == GEMM_LOGITS) {
+            reinterpret_cast<float*>(g.out)[orow * g.ldo + n] = y;
+          } else if (EPI == GEMM_RESIDUAL) {
+            reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + n] = f_to_bf(bf_to_f(g.residual[orow * g.ldo + n]) + y);
+          } else if (EPI == GEMM_MOE_ACCUM) {
+            bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + orow * g.ldo + n;
+            *o = f_to_bf(bf_to_f(*o) + bf_round(scale * y));
+          } else {
+            reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + n] = f_to_bf(y);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+  if (g.K % 8 != 0 || g.M <= 0 || g.N <= 0) return hipErrorInvalidValue;
+  const int m_tiles = (g.M + BM - 1) / BM;
+  const int nout = (g.epi == GEMM_SWIGLU) ? 64 : 128;
+  const int n_tiles = (g.N + nout - 1) / nout;
+  const dim3 grid((unsigned)(m_tiles * n_tiles)), block(256);
+  const size_t lds = 4 * TILE_BYTES;
+  switch (g.epi) {
+    case GEMM_STORE: hipLaunchKernelGGL((gemm_kernel<GEMM_STORE>), grid, block, lds, s, g); break;
+    case GEMM_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<GEMM_RESIDUAL>), grid, block, lds, s, g); break;
+    case GEMM_SWIGLU: hipLaunchKernelGGL((gemm_kernel<GEMM_SWIGLU>), grid, block, lds, s, g); break;
+    case GEMM_LOGITS: hipLaunchKernelGGL((gemm_kernel<GEMM_LOGITS>), grid, block, lds, s, g); break;
+    case GEMM_MOE_ACCUM: hipLaunchKernelGGL((gemm_kernel<GEMM_MOE_ACCUM>), grid, block, lds, s, g); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

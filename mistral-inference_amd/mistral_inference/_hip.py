@@ -1,0 +1,217 @@
+"""ctypes binding of libmistral_hip.so (C ABI: include/mistral_hip.h).
+
+There is deliberately no fallback: if the library is missing or a tensor is not a contiguous bf16
+device tensor, the call raises.  torch is used only to own device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libmistral_hip.so"))
+
+MI_ABI_VERSION = 1
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
+BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
+GEMV_MAX_T = 8
+
+_vp = C.c_void_p
+
+
+class MiLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in ("attention_norm", "wq", "wk", "wv", "wo", "ffn_norm", "w1", "w2", "w3", "gate",
+                                   "expert_w_dev", "expert_w_host")]
+
+
+class MiModel(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("hidden_dim", C.c_int32), ("vocab_size", C.c_int32), ("n_layers", C.c_int32),
+        ("num_experts", C.c_int32), ("top_k", C.c_int32), ("norm_eps", C.c_float),
+        ("tok_embeddings", _vp), ("final_norm", _vp), ("output", _vp), ("rope_cs", _vp), ("rope_len", C.c_int32),
+        ("layers", C.POINTER(MiLayer)),
+    ]
+
+
+class MiBatch(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("B", C.c_int32), ("branch", C.c_int32), ("max_q_len", C.c_int32),
+        ("input_ids", _vp), ("q_start", _vp), ("kv_before", _vp), ("tok_seq", _vp), ("tok_pos", _vp),
+        ("kv_seqlens", _vp), ("cache_k", C.POINTER(_vp)), ("cache_v", C.POINTER(_vp)),
+        ("cache_sizes", C.POINTER(C.c_int32)), ("h", _vp), ("logits", _vp), ("workspace", _vp),
+        ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+_SIGS = {
+    "mi_abi_version": (C.c_int, []),
+    "mi_error_string": (C.c_char_p, [C.c_int]),
+    "mi_last_error_detail": (C.c_char_p, []),
+    "mi_embedding": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "mi_rmsnorm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "mi_rope_inplace": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "mi_kv_write": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "mi_linear": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.c_int,
+                            _vp, _vp, C.c_float, _vp]),
+    "mi_attn_decode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_attn_decode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mi_attn_prefill": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp,
+                                  _vp, C.c_int, _vp]),
+    "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
+    "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
+    "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib() -> C.CDLL:
+    """Load the library once.  Raises (never falls back) when it is absent or of the wrong ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python mistral-inference_amd/build_native.py` "
+                "(hipcc --offload-arch=gfx950).  mistral_inference has no CPU / eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.mi_abi_version() != MI_ABI_VERSION:
+            raise RuntimeError(f"libmistral_hip ABI {handle.mi_abi_version()} != expected {MI_ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        L = lib()
+        raise RuntimeError(f"libmistral_hip {what}: {L.mi_error_string(rc).decode()} "
+                           f"[{L.mi_last_error_detail().decode()}] (code {rc})")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dev_ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = torch.bfloat16) -> Optional[int]:
+    """Raw device pointer of a tensor the kernels may read as dense rows."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mistral_inference runs only on a HIP device; got a CPU tensor "
+                           "(there is no CPU fallback -- use the reference or oracle/ for CPU runs)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype} (the gfx950 kernels are bf16-storage only)")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise RuntimeError("innermost dimension must be contiguous")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# leaf operator wrappers (torch tensors in, torch tensors out; all work done by the library)
+# ------------------------------------------------------------------------------------------------
+def embedding(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    T, (V, D) = ids.numel(), table.shape
+    out = torch.empty((T, D), dtype=table.dtype, device=table.device)
+    ids = ids.to(device=table.device, dtype=torch.long).contiguous()
+    check(lib().mi_embedding(dev_ptr(out), dev_ptr(table), dev_ptr(ids, torch.long), T, D, V, stream_ptr(table.device)),
+          "mi_embedding")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    o = torch.empty_like(x2) if out is None else out
+    check(lib().mi_rmsnorm(dev_ptr(o), dev_ptr(x2), dev_ptr(w), x2.shape[0], x2.shape[1], float(eps),
+                           stream_ptr(x.device)), "mi_rmsnorm")
+    return o.view(x.shape)
+
+
+def linear(x: torch.Tensor, weights: Sequence[torch.Tensor], epilogue: int = EPI_STORE,
+           residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None, eps: float = 0.0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(x @ cat(weights)^T); SWIGLU: weights = (W1, W3)."""
+    assert 1 <= len(weights) <= 3 and x.dim() == 2
+    M, K = x.shape
+    n_rows = [w.shape[0] for w in weights]
+    for w in weights:
+        assert w.shape[1] == K and w.is_contiguous()
+    N = n_rows[0] if epilogue == EPI_SWIGLU else sum(n_rows)
+    odt = torch.float32 if epilogue == EPI_LOGITS else torch.bfloat16
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=x.device)
+    wp = (_vp * 3)(*[dev_ptr(w) for w in weights], *([None] * (3 - len(weights))))
+    nr = (C.c_int * 3)(*n_rows, *([0] * (3 - len(weights))))
+    check(lib().mi_linear(dev_ptr(out, odt), out.stride(0), dev_ptr(x), x.stride(0), M, K, wp, nr, epilogue,
+                          dev_ptr(residual), dev_ptr(norm_w), float(eps), stream_ptr(x.device)), "mi_linear")
+    return out
+
+
+def rope_inplace(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int, rope_cs: torch.Tensor,
+                 tok_pos: torch.Tensor) -> None:
+    assert rope_cs.dtype == torch.float32 and rope_cs.is_contiguous() and tok_pos.dtype == torch.int32
+    check(lib().mi_rope_inplace(dev_ptr(qkv), qkv.stride(0), qkv.shape[0], n_heads, n_kv_heads, head_dim,
+                                dev_ptr(rope_cs, torch.float32), rope_cs.shape[0], dev_ptr(tok_pos, torch.int32),
+                                stream_ptr(qkv.device)), "mi_rope_inplace")
+
+
+def kv_write(cache_k: torch.Tensor, cache_v: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tok_seq: torch.Tensor,
+             tok_pos: torch.Tensor, q_start: torch.Tensor) -> None:
+    W = cache_k.shape[1]
+    kv_dim = cache_k.shape[2] * cache_k.shape[3]
+    assert cache_k.is_contiguous() and cache_v.is_contiguous() and k.stride(0) == v.stride(0)
+    check(lib().mi_kv_write(dev_ptr(cache_k), dev_ptr(cache_v), W, dev_ptr(k), dev_ptr(v), k.stride(0), k.shape[0], kv_dim,
+                            dev_ptr(tok_seq, torch.int32), dev_ptr(tok_pos, torch.int32), dev_ptr(q_start, torch.int32),
+                            stream_ptr(k.device)), "mi_kv_write")
+
+
+_decode_scratch = {}
+
+
+def attn_decode(q: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, n_heads: int, tok_pos: torch.Tensor
+                ) -> torch.Tensor:
+    B = q.shape[0]
+    _, W, Hkv, Dh = cache_k.shape
+    need = lib().mi_attn_decode_scratch_bytes(B, n_heads, Hkv, Dh, W)
+    key = (q.device, need)
+    if key not in _decode_scratch:
+        _decode_scratch[key] = torch.zeros(need, dtype=torch.uint8, device=q.device)
+    out = torch.empty((B, n_heads * Dh), dtype=q.dtype, device=q.device)
+    check(lib().mi_attn_decode(dev_ptr(out), dev_ptr(q), q.stride(0), dev_ptr(cache_k), dev_ptr(cache_v), W, B, n_heads, Hkv,
+                               Dh, dev_ptr(tok_pos, torch.int32), dev_ptr(_decode_scratch[key], torch.uint8),
+                               stream_ptr(q.device)), "mi_attn_decode")
+    return out
+
+
+def attn_prefill(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int, cache_k: Optional[torch.Tensor],
+                 cache_v: Optional[torch.Tensor], W: int, q_start: Optional[torch.Tensor],
+                 kv_before: Optional[torch.Tensor], B: int, max_q_len: int, causal: bool = True) -> torch.Tensor:
+    T = qkv.shape[0]
+    out = torch.empty((T, n_heads * head_dim), dtype=qkv.dtype, device=qkv.device)
+    check(lib().mi_attn_prefill(dev_ptr(out), dev_ptr(qkv), qkv.stride(0), dev_ptr(cache_k), dev_ptr(cache_v), W, B,
+                                max_q_len, n_heads, n_kv_heads, head_dim, dev_ptr(q_start, torch.int32),
+                                dev_ptr(kv_before, torch.int32), 1 if causal else 0, stream_ptr(qkv.device)),
+          "mi_attn_prefill")
+    return out
+
+
+def moe_router(x: torch.Tensor, gate: torch.Tensor, top_k: int, norm_w: Optional[torch.Tensor] = None, eps: float = 0.0):
+    T, D = x.shape
+    E = gate.shape[0]
+    idx = torch.empty((T, top_k), dtype=torch.int32, device=x.device)
+    w = torch.empty((T, top_k), dtype=torch.float32, device=x.device)
+    check(lib().mi_moe_router(dev_ptr(idx, torch.int32), dev_ptr(w, torch.float32), dev_ptr(x), x.stride(0), T, D,
+                              dev_ptr(gate), E, top_k, dev_ptr(norm_w), float(eps), stream_ptr(x.device)), "mi_moe_router")
+    return idx, w
+
+
+def ptr_array(ptrs: List[Optional[int]]):
+    return (_vp * len(ptrs))(*ptrs)

@@ -1,0 +1,148 @@
+"""`generate()` with the reference's contract (generate.py:43-170), minus its host round trips.
+
+Same arguments, same return value: `(tokens, logprobs)` where logprobs hold prompt tokens 1..n-1 then the
+generated tokens, `tokens == []` when nothing was generated, sequences keep generating until ALL have hit
+`eos_id`, top-p is fixed at 0.8 at the call site (generate.py:126).
+
+What changes is where the bookkeeping runs.  The reference reads one logprob per token with `.item()`
+(one device sync per prompt token, generate.py:107,111, and per generated token, :134-136), allocates the
+K/V buffers on the host before moving them (:69-78) and rebuilds mask metadata per layer per step.  Here
+the cache is allocated in HBM once per call, logprobs are gathered on the device and copied back once at
+the end, and a decode step is a single native call with no host metadata; the only per-token sync left
+is the EOS test, and only when `eos_id` is given.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+
+from .cache import BufferCache
+from .transformer import Transformer
+
+
+@torch.inference_mode()
+def generate(
+    encoded_prompts: List[List[int]],
+    model: Transformer,
+    images: List[List] = [],
+    *,
+    max_tokens: int,
+    temperature: float,
+    chunk_size: Optional[int] = None,
+    eos_id: Optional[int] = None,
+) -> Tuple[List[List[int]], List[List[float]]]:
+    if images and any(len(i) for i in images):
+        raise NotImplementedError("images: the Pixtral vision tower is outside the forward_partial hot path")
+    model = model.eval()
+    B, V = len(encoded_prompts), model.args.vocab_size
+    seqlens = [len(x) for x in encoded_prompts]
+    dev = model.device
+
+    # K/V rings, straight in device memory (reference generate.py:67-78)
+    cache_window = max(seqlens) + max_tokens
+    cache = BufferCache(model.n_local_layers, model.args.max_batch_size, cache_window, model.args.n_kv_heads,
+                        model.args.head_dim, model.args.sliding_window, device=dev, dtype=model.dtype)
+    cache.reset()
+
+    # logprob pieces stay on the device; (sequence, tensor) in emission order
+    lp_chunks: List[Tuple[int, torch.Tensor]] = []
+    last_token_prelogits: Optional[torch.Tensor] = None
+
+    max_prompt_len = max(seqlens)
+    if chunk_size is None:
+        chunk_size = max_prompt_len
+
+    # ---- prompt, by chunks (reference generate.py:91-118)
+    for s in range(0, max_prompt_len, chunk_size):
+        prompt_chunks = [p[s: s + chunk_size] for p in encoded_prompts]
+        assert all(len(p) > 0 for p in prompt_chunks)
+        flat = torch.tensor(sum(prompt_chunks, []), device=dev, dtype=torch.long)
+        prelogits = model.forward(flat, seqlens=[len(p) for p in prompt_chunks], cache=cache)
+        logits = torch.log_softmax(prelogits, dim=-1)
+
+        if last_token_prelogits is not None:
+            # first token of this chunk is scored by the previous chunk's last position
+            prev = torch.log_softmax(last_token_prelogits, dim=-1)
+            firsts = torch.tensor([p[0] for p in prompt_chunks], device=dev, dtype=torch.long)
+            picked = prev.gather(1, firsts[:, None])[:, 0]
+            for b in range(B):
+                lp_chunks.append((b, picked[b: b + 1]))
+
+        # token i+1 of each chunk is scored by position i: one gather for the whole chunk
+        rows, cols, owners = [], [], []
+        offset = 0
+        for b, seq in enumerate(prompt_chunks):
+            n = len(seq) - 1
+            rows += list(range(offset, offset + n))
+            cols += seq[1:]
+            owners.append((b, n))
+            offset += len(seq)
+        if rows:
+            idx = torch.tensor([rows, cols], device=dev, dtype=torch.long)
+            picked = logits[idx[0], idx[1]]
+            o = 0
+            for b, n in owners:
+                if n:
+                    lp_chunks.append((b, picked[o: o + n]))
+                o += n
+
+        ends = torch.tensor([len(p) for p in prompt_chunks], device=dev).cumsum(dim=0) - 1
+        last_token_prelogits = prelogits.index_select(0, ends)
+        assert last_token_prelogits.shape == (B, V)
+
+    # ---- decode (reference generate.py:120-140)
+    generated: List[torch.Tensor] = []
+    gen_lp: List[torch.Tensor] = []
+    is_finished = torch.zeros(B, dtype=torch.bool, device=dev)
+    assert last_token_prelogits is not None
+    for _ in range(max_tokens):
+        next_token = sample(last_token_prelogits, temperature=temperature, top_p=0.8)
+        if eos_id is not None:
+            is_finished = is_finished | (next_token == eos_id)
+            if bool(is_finished.all()):  # the one remaining per-token sync, only with an eos_id
+                break
+        lsm = torch.log_softmax(last_token_prelogits, dim=-1)
+        gen_lp.append(lsm.gather(1, next_token[:, None])[:, 0])
+        generated.append(next_token)
+        last_token_prelogits = model.forward(next_token, seqlens=[1] * B, cache=cache)
+        assert last_token_prelogits.shape == (B, V)
+
+    # ---- one copy back
+    logprobs: List[List[float]] = [[] for _ in range(B)]
+    if lp_chunks:
+        flat_lp = torch.cat([t for _, t in lp_chunks]).tolist()
+        o = 0
+        for b, t in lp_chunks:
+            n = t.numel()
+            logprobs[b].extend(flat_lp[o: o + n])
+            o += n
+    generated_tokens: List[List[int]]
+    if generated:
+        generated_tokens = torch.stack(generated, 1).tolist()
+        lp = torch.stack(gen_lp, 1).tolist()
+        for b in range(B):
+            logprobs[b].extend(lp[b])
+    else:
+        generated_tokens = []
+    return generated_tokens, logprobs
+
+
+def sample(logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
+    """Greedy for temperature 0, else nucleus sampling (reference generate.py:151-159)."""
+    if temperature > 0:
+        probs = torch.softmax(logits / temperature, dim=-1)
+        next_token = sample_top_p(probs, top_p)
+    else:
+        next_token = torch.argmax(logits, dim=-1).unsqueeze(0)
+    return next_token.reshape(-1)
+
+
+def sample_top_p(probs: torch.Tensor, p: float) -> torch.Tensor:
+    """Reference generate.py:162-170: keep the smallest prefix of the sorted distribution whose mass
+    before the token is <= p, renormalise, draw one."""
+    assert 0 <= p <= 1
+    sorted_probs, order = torch.sort(probs, dim=-1, descending=True)
+    mass_before = torch.cumsum(sorted_probs, dim=-1) - sorted_probs
+    sorted_probs = sorted_probs.masked_fill(mass_before > p, 0.0)
+    sorted_probs = sorted_probs / sorted_probs.sum(dim=-1, keepdim=True)
+    pick = torch.multinomial(sorted_probs, num_samples=1)
+    return torch.gather(order, -1, pick)

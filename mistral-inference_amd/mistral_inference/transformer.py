@@ -1,0 +1,342 @@
+"""`Transformer` with the reference's API (transformer.py:33-338) over the native layer-stack runner.
+
+Drop-in surfaces kept: constructor arguments, `from_folder`, `forward`, `forward_partial`,
+`load_state_dict` (rank filtering + "Unexpected key"), the `dtype/device/freqs_cis` properties,
+`args`, `n_local_layers`, `layers` (ModuleDict keyed by GLOBAL layer id), `pipeline_rank`,
+`num_pipeline_ranks`.  Checkpoint tensor names and layouts are the reference's; weights are used
+exactly as loaded (the fused q|k|v and w1|w3 kernels take the separate matrices, nothing is re-packed).
+
+One `forward_partial` = ONE call into libmistral_hip (`mi_forward`): embedding or received activations ->
+all local layers -> final norm / LM head, enqueued on the current stream without host synchronisation.
+Pipeline parallelism keeps the reference's contract (contiguous layer ranges, transformer.py:94-98;
+activations to the next rank, logits broadcast from the last rank) through torch.distributed, whose
+"nccl" backend is RCCL over xGMI on ROCm.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import logging
+import math
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, List, Mapping, Optional, Union
+
+import safetensors.torch
+import torch
+from torch import nn
+
+from . import _hip
+from .args import TransformerArgs
+from .cache import BatchMetadata, BufferCache
+from .model import ModelBase
+from .rope import precompute_freqs_cis
+from .transformer_layers import RMSNorm, TransformerBlock
+
+ROPE_TABLE_LEN = 128_000  # reference transformer.py:116
+
+
+@dataclass
+class SimpleInputMetadata:
+    """Positions for the cache=None call (reference transformer.py:21-30)."""
+
+    positions: torch.Tensor
+
+    @staticmethod
+    def from_seqlens(seqlens: List[int], device: torch.device) -> "SimpleInputMetadata":
+        return SimpleInputMetadata(
+            positions=torch.cat([torch.arange(0, s) for s in seqlens]).to(device=device, dtype=torch.long))
+
+
+class HipStackBackend:
+    """Runs the local layer stack through `mi_forward`.  The only backend shipped: the product has no
+    CPU or eager path (tests may inject a different object to exercise host-side pipeline logic)."""
+
+    def __init__(self) -> None:
+        self._plan = None
+        self._workspace: Optional[torch.Tensor] = None
+
+    # -- one-time: pointer tables of the weights -------------------------------------------------
+    def _build_plan(self, model: "Transformer"):
+        a = model.args
+        dev = model.device
+        if dev.type != "cuda":
+            raise RuntimeError(f"mistral_inference needs a HIP device (model is on {dev}); there is no CPU fallback")
+        if model.dtype != torch.bfloat16:
+            raise RuntimeError(f"the gfx950 kernels are bf16-storage only; model dtype is {model.dtype} "
+                               "(pass dtype=torch.bfloat16 to from_folder)")
+        keep = []  # python objects that own memory referenced by raw pointers
+        p = _hip.dev_ptr
+        E = a.moe.num_experts if a.moe is not None else 0
+        layers = (_hip.MiLayer * max(1, model.n_local_layers))()
+        for j, blk in enumerate(model.layers.values()):
+            L = layers[j]
+            at = blk.attention
+            L.attention_norm, L.ffn_norm = p(blk.attention_norm.weight), p(blk.ffn_norm.weight)
+            L.wq, L.wk, L.wv, L.wo = p(at.wq.weight), p(at.wk.weight), p(at.wv.weight), p(at.wo.weight)
+            if E:
+                ff = blk.feed_forward
+                L.gate = p(ff.gate.weight)
+                ptrs = []
+                for ex in ff.experts:
+                    ptrs += [p(ex.w1.weight), p(ex.w2.weight), p(ex.w3.weight)]
+                host = _hip.ptr_array(ptrs)
+                devtab = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+                keep += [host, devtab]
+                L.expert_w_host = C.cast(host, C.c_void_p)
+                L.expert_w_dev = devtab.data_ptr()
+            else:
+                ff = blk.feed_forward
+                L.w1, L.w2, L.w3 = p(ff.w1.weight), p(ff.w2.weight), p(ff.w3.weight)
+        rope = torch.view_as_real(model.freqs_cis).contiguous()
+        keep += [layers, rope]
+        m = _hip.MiModel()
+        m.dim, m.n_heads, m.n_kv_heads, m.head_dim = a.dim, a.n_heads, a.n_kv_heads, a.head_dim
+        m.hidden_dim, m.vocab_size, m.n_layers = a.hidden_dim, a.vocab_size, model.n_local_layers
+        m.num_experts, m.top_k = E, (a.moe.num_experts_per_tok if E else 0)
+        m.norm_eps = a.norm_eps
+        m.tok_embeddings = p(model.tok_embeddings.weight) if model.tok_embeddings is not None else None
+        m.final_norm = p(model.norm.weight) if model.norm is not None else None
+        m.output = p(model.output.weight) if model.output is not None else None
+        m.rope_cs, m.rope_len = p(rope, torch.float32), rope.shape[0]
+        m.layers = C.cast(layers, C.POINTER(_hip.MiLayer))
+        return m, keep
+
+    def plan(self, model: "Transformer"):
+        if self._plan is None:
+            self._plan = self._build_plan(model)
+        return self._plan[0]
+
+    def invalidate(self) -> None:
+        self._plan = None
+        self._workspace = None
+
+    def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
+        need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
+        ws = self._workspace
+        if ws is None or ws.numel() < need or ws.device != model.device:
+            # grow geometrically; zero-filled because the first 4 KiB are split-KV arrival counters
+            ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=model.device)
+            self._workspace = ws
+        return ws
+
+    # -- per forward -------------------------------------------------------------------------------
+    def run_stack(self, model: "Transformer", h: torch.Tensor, input_ids: Optional[torch.Tensor],
+                  meta: BatchMetadata, cache: Optional[BufferCache], logits: Optional[torch.Tensor]) -> None:
+        m = self.plan(model)
+        T, B = h.shape[0], len(meta.seqlens)
+        bt = _hip.MiBatch()
+        bt.T, bt.B, bt.branch, bt.max_q_len = T, B, meta.branch, meta.max_q_len
+        bt.input_ids = _hip.dev_ptr(input_ids, torch.long) if model.tok_embeddings is not None else None
+        i32 = torch.int32
+        bt.q_start, bt.kv_before = _hip.dev_ptr(meta.q_start, i32), _hip.dev_ptr(meta.kv_before, i32)
+        bt.tok_seq, bt.tok_pos = _hip.dev_ptr(meta.tok_seq, i32), _hip.dev_ptr(meta.tok_pos, i32)
+        max_w = 1
+        if cache is not None:
+            ks, vs, ws = cache.pointer_tables()
+            bt.cache_k, bt.cache_v = C.cast(ks, C.POINTER(C.c_void_p)), C.cast(vs, C.POINTER(C.c_void_p))
+            bt.cache_sizes = C.cast(ws, C.POINTER(C.c_int32))
+            bt.kv_seqlens = _hip.dev_ptr(cache.kv_seqlens, torch.long)
+            max_w = max(cache.cache_sizes)
+        bt.h = _hip.dev_ptr(h)
+        bt.logits = _hip.dev_ptr(logits, torch.float32)
+        wsb = self._get_workspace(model, m, T, B, max_w)
+        bt.workspace, bt.workspace_bytes = wsb.data_ptr(), wsb.numel()
+        _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
+
+
+class Transformer(ModelBase):
+    def __init__(self, args: TransformerArgs, pipeline_rank: int = 0, num_pipeline_ranks: int = 1,
+                 softmax_fp32: bool = True, backend: Optional[Any] = None):
+        super().__init__()
+        self.args = args
+        self.vocab_size = args.vocab_size
+        self.n_layers = args.n_layers
+        self._precomputed_freqs_cis: Optional[torch.Tensor] = None
+        assert self.vocab_size > 0
+        assert pipeline_rank < num_pipeline_ranks, (pipeline_rank, num_pipeline_ranks)
+        self.pipeline_rank = pipeline_rank
+        self.num_pipeline_ranks = num_pipeline_ranks
+        self.softmax_fp32 = softmax_fp32
+        if args.vision_encoder is not None:
+            raise NotImplementedError("the Pixtral vision tower is outside the forward_partial hot path (SURVEY.md 2a)")
+        if args.lora is not None:
+            raise NotImplementedError("un-merged LoRA is outside the hot path; merge the adapter into the weights")
+
+        # Rank-specific modules (reference transformer.py:52-79)
+        self.tok_embeddings: Optional[nn.Embedding] = None
+        self.norm: Optional[RMSNorm] = None
+        self.output: Optional[nn.Linear] = None
+        self.vision_encoder = None
+        if pipeline_rank == 0:
+            self.tok_embeddings = nn.Embedding(args.vocab_size, args.dim)
+        if pipeline_rank == num_pipeline_ranks - 1:
+            self.norm = RMSNorm(args.dim, eps=args.norm_eps)
+            self.output = nn.Linear(args.dim, args.vocab_size, bias=False)
+        # Only this rank's contiguous layer range is ever constructed (the reference builds all n_layers
+        # blocks and throws the rest away, transformer.py:80-98); keys stay GLOBAL layer ids.
+        per_rank = math.ceil(self.n_layers / self.num_pipeline_ranks)
+        first = self.pipeline_rank * per_rank
+        last = min(self.n_layers, first + per_rank)
+        self.layers = nn.ModuleDict({
+            str(i): TransformerBlock(dim=args.dim, hidden_dim=args.hidden_dim, n_heads=args.n_heads,
+                                     n_kv_heads=args.n_kv_heads, head_dim=args.head_dim, norm_eps=args.norm_eps,
+                                     lora=args.lora, moe=args.moe)
+            for i in range(first, last)})
+        self.n_local_layers = len(self.layers)
+        self._backend = backend if backend is not None else HipStackBackend()
+
+    # ---- properties ----------------------------------------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def freqs_cis(self) -> torch.Tensor:
+        """complex64 [128000, head_dim/2] as in the reference (transformer.py:107-120); the kernels read its
+        real view."""
+        if self._precomputed_freqs_cis is None:
+            theta = self.args.rope_theta or 1000000.0
+            self._precomputed_freqs_cis = precompute_freqs_cis(self.args.head_dim, ROPE_TABLE_LEN, theta)
+        if self._precomputed_freqs_cis.device != self.device:
+            self._precomputed_freqs_cis = self._precomputed_freqs_cis.to(device=self.device)
+        return self._precomputed_freqs_cis
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / dtype casts move the weights: rebuild pointer tables
+        out = super()._apply(fn, *a, **k)
+        if hasattr(self._backend, "invalidate"):
+            self._backend.invalidate()
+        return out
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _nocache_metadata(self, seqlens: List[int]) -> BatchMetadata:
+        T = sum(seqlens)
+        pos = [i for s in seqlens for i in range(s)]
+        blob = torch.tensor([0, T] + [0] + [0] * T + pos, dtype=torch.int32).to(self.device)
+        return BatchMetadata(_hip.BRANCH_NOCACHE, [T], T, blob[:2], blob[2:3], blob[3:3 + T], blob[3 + T:])
+
+    def _run(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
+             want_logits: bool):
+        assert len(seqlens) <= self.args.max_batch_size, (
+            f"Max batch size is {self.args.max_batch_size}, got batch size of {len(seqlens)}")
+        (num_toks,) = input_ids.shape
+        assert sum(seqlens) == num_toks, (sum(seqlens), num_toks)
+        meta = cache.batch_metadata(seqlens) if cache is not None else self._nocache_metadata(seqlens)
+        dev = self.device
+        h = torch.empty((num_toks, self.args.dim), device=dev, dtype=self.dtype)
+        if self.pipeline_rank > 0:
+            torch.distributed.recv(h, src=self.pipeline_rank - 1)
+        last = self.pipeline_rank == self.num_pipeline_ranks - 1
+        logits = None
+        if want_logits and last:
+            logits = torch.empty((num_toks, self.vocab_size), device=dev, dtype=torch.float32)
+        ids = input_ids.to(device=dev, dtype=torch.long) if self.pipeline_rank == 0 else None
+        self._backend.run_stack(self, h, ids, meta, cache, logits)
+        if cache is not None:
+            if meta.branch == _hip.BRANCH_DECODE:
+                cache.advance_host(seqlens)   # device kv_seqlens already advanced by the decode-prep kernel
+            else:
+                cache.update_seqlens(seqlens)
+        if not last:
+            torch.distributed.send(h, dst=self.pipeline_rank + 1)
+        return h, logits
+
+    def forward_partial(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache] = None,
+                        images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        """Local forward pass (reference transformer.py:163-219): the activations of this stage's last layer,
+        RMS-normalised on the last stage."""
+        if images:
+            raise NotImplementedError("images: the vision tower is outside the hot path")
+        h, _ = self._run(input_ids, seqlens, cache, want_logits=False)
+        return h
+
+    def forward(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache] = None,
+                images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        """Logits [T, vocab] (reference transformer.py:221-242): fp32 unless softmax_fp32=False."""
+        if images:
+            raise NotImplementedError("images: the vision tower is outside the hot path")
+        h, logits = self._run(input_ids, seqlens, cache, want_logits=True)
+        if self.num_pipeline_ranks > 1:
+            # every rank receives the logits in the model dtype, as the reference does (transformer.py:229-237);
+            # the kernel's fp32 logits are bf16-representable, so the narrowing is exact
+            outs = logits.to(self.dtype) if logits is not None else torch.empty(
+                h.shape[0], self.vocab_size, device=h.device, dtype=h.dtype)
+            torch.distributed.broadcast(outs, src=self.num_pipeline_ranks - 1)
+            return outs.float() if self.softmax_fp32 else outs
+        assert logits is not None
+        return logits if self.softmax_fp32 else logits.to(self.dtype)
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True, assign: bool = False) -> None:
+        """Keep only this rank's tensors (reference transformer.py:244-295): embeddings on rank 0, norm/output
+        on the last rank, layers by global id; any other key raises ValueError("Unexpected key ...")."""
+        mine, skipped = {}, set()
+        last = self.pipeline_rank == self.num_pipeline_ranks - 1
+        for k, v in state_dict.items():
+            if k.startswith("tok_embeddings"):
+                keep = self.pipeline_rank == 0
+            elif k.startswith("norm") or k.startswith("output"):
+                keep = last
+            elif k.startswith("layers"):
+                keep = k.split(".")[1] in self.layers
+            elif any(k.startswith(p) for p in ("vision_encoder", "vision_language_adapter", "patch_merger",
+                                               "pre_mm_projector_norm")):
+                raise NotImplementedError(f"vision weights ({k}) are outside the hot path")
+            else:
+                raise ValueError(f"Unexpected key {k}")
+            if keep:
+                mine[k] = v
+            else:
+                logging.debug("Skipping parameter %s at pipeline rank %d", k, self.pipeline_rank)
+                skipped.add(k)
+        assert set(state_dict.keys()) == skipped.union(set(mine.keys()))
+        super().load_state_dict(mine, strict=strict, assign=assign)
+        if hasattr(self._backend, "invalidate"):
+            self._backend.invalidate()
+
+    @staticmethod
+    def from_folder(folder: Union[Path, str], max_batch_size: int = 1, num_pipeline_ranks: int = 1,
+                    device: Union[torch.device, str] = "cuda", dtype: Optional[torch.dtype] = None,
+                    softmax_fp32: bool = True, backend: Optional[Any] = None) -> "Transformer":
+        """params.json + exactly one of consolidated.00.pth / consolidated.safetensors (reference
+        transformer.py:297-338).  With safetensors only this rank's tensors are read, straight to `device`
+        (the reference loads the whole file to the host on every rank)."""
+        folder = Path(folder)
+        with open(folder / "params.json", "r") as f:
+            model_args = TransformerArgs.from_dict(json.load(f))
+        model_args.max_batch_size = max_batch_size
+        pipeline_rank = torch.distributed.get_rank() if num_pipeline_ranks > 1 else 0
+        with torch.device("meta"):
+            model = Transformer(model_args, pipeline_rank=pipeline_rank, num_pipeline_ranks=num_pipeline_ranks,
+                                softmax_fp32=softmax_fp32, backend=backend)
+        pt_file = folder / "consolidated.00.pth"
+        st_file = folder / "consolidated.safetensors"
+        assert pt_file.exists() or st_file.exists(), f"Make sure either {pt_file} or {st_file} exists"
+        assert not (pt_file.exists() and st_file.exists()), f"Both {pt_file} and {st_file} cannot exist"
+        if pt_file.exists():
+            loaded = torch.load(str(pt_file), mmap=True)
+            model.load_state_dict(loaded, assign=True, strict=True)
+            return model.to(device=device, dtype=dtype)
+        wanted = set(model.state_dict().keys())
+        loaded = {}
+        with safetensors.safe_open(str(st_file), framework="pt", device=str(device)) as f:
+            for k in f.keys():
+                if k in wanted:
+                    loaded[k] = f.get_tensor(k)
+                else:
+                    model._check_foreign_key(k)
+        missing = wanted - set(loaded)
+        assert not missing, f"checkpoint is missing {sorted(missing)[:4]}..."
+        nn.Module.load_state_dict(model, loaded, strict=True, assign=True)
+        model._backend.invalidate() if hasattr(model._backend, "invalidate") else None
+        return model.to(device=device, dtype=dtype)
+
+    def _check_foreign_key(self, k: str) -> None:
+        """A key this rank does not own must still be a known kind (reference raises on anything else)."""
+        known = ("tok_embeddings", "norm", "output", "layers")
+        if not any(k.startswith(p) for p in known):
+            raise ValueError(f"Unexpected key {k}")

@@ -1,0 +1,46 @@
+"""TEST-ONLY stack backend: lets the host-side logic of `Transformer` (pipeline partitioning, rank-filtered
+weight loading, send/recv/broadcast order, cache bookkeeping, generate()) run on CPU under gloo by
+delegating the layer stack to the oracle.  Lives under tests/ on purpose: the product ships only
+HipStackBackend and has no CPU path."""
+import torch
+import torch.nn.functional as F
+
+import mistral_oracle as mo
+
+
+class OracleStackBackend:
+    def invalidate(self):
+        pass
+
+    def run_stack(self, model, h, input_ids, meta, cache, logits):
+        a = model.args
+        oargs = mo.OracleArgs(dim=a.dim, n_layers=a.n_layers, head_dim=a.head_dim, hidden_dim=a.hidden_dim,
+                              n_heads=a.n_heads, n_kv_heads=a.n_kv_heads, norm_eps=a.norm_eps, vocab_size=a.vocab_size,
+                              rope_theta=a.rope_theta, num_experts=a.moe.num_experts if a.moe else 0,
+                              num_experts_per_tok=a.moe.num_experts_per_tok if a.moe else 0,
+                              sliding_window=a.sliding_window)
+        om = mo.OracleModel(oargs, dict(model.state_dict()), model.pipeline_rank, model.num_pipeline_ranks)
+        ocache = None
+        if cache is not None:
+            ocache = getattr(cache, "_oracle", None)
+            if ocache is None or cache._seen is None or all(p == 0 for p in cache._seen):
+                ocache = mo.OracleCache(model.n_local_layers, cache.max_batch_size, cache.max_seq_len, cache.n_kv_heads,
+                                        cache.head_dim, a.sliding_window, dtype=model.dtype)
+                cache._oracle = ocache
+            ocache.seen = list(cache._seen)
+        seqlens = meta.seqlens if cache is not None else None
+        if cache is None:
+            # NOCACHE: meta.seqlens is [T]; positions restart per original sequence -> recover from tok_pos
+            pos = meta.tok_pos.tolist()
+            seqlens, run = [], 0
+            for i, p in enumerate(pos):
+                if p == 0 and i:
+                    seqlens.append(run)
+                    run = 0
+                run += 1
+            seqlens.append(run)
+        ids = input_ids if input_ids is not None else torch.zeros(h.shape[0], dtype=torch.long)
+        out = om.forward_partial(ids, seqlens, ocache, h_in=h.clone())
+        if logits is not None:
+            logits.copy_(F.linear(out, om.w["output.weight"]).float())
+        h.copy_(out)

@@ -1,0 +1,44 @@
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/mistral_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mistral_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from mistral_inference import _hip
+    handle = ctypes.CDLL(_hip.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in mistral_hip.h but not exported"
+    assert set(names) == set(_hip.EXPORTED_SYMBOLS), set(names) ^ set(_hip.EXPORTED_SYMBOLS)
+
+
+def test_abi_version_and_error_strings():
+    from mistral_inference import _hip
+    L = _hip.lib()
+    assert L.mi_abi_version() == _hip.MI_ABI_VERSION
+    assert L.mi_error_string(0) == b"ok"
+    assert b"shape" in L.mi_error_string(-2)
+    # argument checks run before any device work, so they are testable on a box without a GPU
+    assert L.mi_rmsnorm(None, None, None, 1, 8, 1e-5, None) == -1
+    assert b"mi_rmsnorm" in L.mi_last_error_detail()
+    assert L.mi_workspace_bytes(None, 1, 1, 1) == 0
+
+
+def test_no_oracle_import_in_product():
+    """The shipped package must never reach into oracle/ (it has no CPU path to fall back to)."""
+    pkg = os.path.join(ROOT, "mistral-inference_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "mistral_oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,246 @@
+"""Per-operator parity: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mistral_oracle as mo
+from hip_util import bf16_ulp_close
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _hip():
+    from mistral_inference import _hip
+    return _hip
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("T,D", [(1, 4096), (3, 256), (40, 5120), (7, 14336)])
+def test_rmsnorm(T, D):
+    h = _hip()
+    x, w = rnd(T, D, seed=1, scale=3.0), (1 + 0.1 * torch.randn(D, generator=torch.Generator().manual_seed(2))).to(BF)
+    ref = mo.rms_norm(x, w, 1e-5)
+    got = h.rmsnorm(x.cuda(), w.cuda(), 1e-5).cpu()
+    mism = (got.view(torch.int16) != ref.view(torch.int16)).float().mean().item()
+    ok, err = bf16_ulp_close(got, ref, ulps=1.0)
+    assert ok and mism < 2e-3, (mism, err)  # reduction order may flip a rounding on a handful of elements
+
+
+def test_embedding():
+    h = _hip()
+    tab = rnd(1000, 512, seed=3)
+    ids = torch.tensor([0, 999, 5, 5, 123], dtype=torch.long)
+    assert torch.equal(h.embedding(tab.cuda(), ids.cuda()).cpu(), tab[ids])
+
+
+def test_rope_bit_exact():
+    h = _hip()
+    T, H, Hkv, Dh = 37, 4, 2, 128
+    qkv = rnd(T, (H + 2 * Hkv) * Dh, seed=4)
+    cs = mo.rope_angles(Dh, 5000, 1e6)
+    pos = torch.randint(0, 5000, (T,), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+    q = mo.apply_rope(qkv[:, : H * Dh].reshape(T, H, Dh), cs[pos.long()]).reshape(T, -1)
+    k = mo.apply_rope(qkv[:, H * Dh: (H + Hkv) * Dh].reshape(T, Hkv, Dh), cs[pos.long()]).reshape(T, -1)
+    dev = qkv.cuda()
+    h.rope_inplace(dev, H, Hkv, Dh, cs.cuda(), pos.cuda())
+    got = dev.cpu()
+    assert torch.equal(got[:, : H * Dh], q)
+    assert torch.equal(got[:, H * Dh: (H + Hkv) * Dh], k)
+    assert torch.equal(got[:, (H + Hkv) * Dh:], qkv[:, (H + Hkv) * Dh:])  # v untouched
+
+
+def _lin_ref(x, ws):
+    return torch.cat([F.linear(x.float(), w.float()) for w in ws], dim=1)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 9, 64, 200])
+@pytest.mark.parametrize("K,N", [(256, 512), (4096, 1024), (1024, 4096)])
+def test_linear_store(M, K, N):
+    h = _hip()
+    x, w = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=1 / math.sqrt(K))
+    ref = _lin_ref(x, [w])
+    got = h.linear(x.cuda(), (w.cuda(),), h.EPI_STORE).cpu()
+    ok, err = bf16_ulp_close(got, ref.to(BF), ulps=1.0)
+    assert ok, err
+
+
+@pytest.mark.parametrize("M", [1, 4, 150])
+def test_linear_three_segments_and_transpose_detection(M):
+    """q|k|v style row blocks, asymmetric weights (a transposed or permuted C write cannot pass)."""
+    h = _hip()
+    K = 512
+    x = rnd(M, K, seed=8)
+    ws = [rnd(512, K, seed=9, scale=0.05), rnd(256, K, seed=10, scale=0.05), rnd(256, K, seed=11, scale=0.05)]
+    ws[0][3, :] += 0.5  # make rows distinguishable
+    ref = _lin_ref(x, ws).to(BF)
+    got = h.linear(x.cuda(), tuple(w.cuda() for w in ws), h.EPI_STORE).cpu()
+    ok, err = bf16_ulp_close(got, ref, ulps=1.0)
+    assert ok, err
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 130])
+def test_linear_residual_swiglu_logits(M):
+    h = _hip()
+    K, N = 512, 1024
+    x = rnd(M, K, seed=12)
+    w1, w3 = rnd(N, K, seed=13, scale=0.06), rnd(N, K, seed=14, scale=0.06)
+    res = rnd(M, N, seed=15)
+    # residual
+    ref = (res + F.linear(x, w1)).float()
+    got = h.linear(x.cuda(), (w1.cuda(),), h.EPI_RESIDUAL, residual=res.cuda()).cpu()
+    assert bf16_ulp_close(got, ref, ulps=1.5)[0]
+    # swiglu with the reference's rounding chain
+    ref = (F.silu(F.linear(x, w1)) * F.linear(x, w3)).float()
+    got = h.linear(x.cuda(), (w1.cuda(), w3.cuda()), h.EPI_SWIGLU).cpu()
+    ok, err = bf16_ulp_close(got, ref, ulps=2.0, floor=2e-2)
+    assert ok, err
+    # logits: fp32 tensor of bf16-rounded values
+    got = h.linear(x.cuda(), (w1.cuda(),), h.EPI_LOGITS).cpu()
+    assert got.dtype == torch.float32 and torch.equal(got, got.to(BF).float())
+    assert bf16_ulp_close(got, F.linear(x, w1).float(), ulps=1.0)[0]
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_linear_fused_norm(M):
+    h = _hip()
+    K, N = 1024, 512
+    x, w = rnd(M, K, seed=16, scale=2.0), rnd(N, K, seed=17, scale=0.03)
+    nw = (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(18))).to(BF)
+    ref = F.linear(mo.rms_norm(x, nw, 1e-5), w).float()
+    got = h.linear(x.cuda(), (w.cuda(),), h.EPI_STORE, norm_w=nw.cuda(), eps=1e-5).cpu()
+    assert bf16_ulp_close(got, ref, ulps=1.5)[0]
+
+
+def _ring_case(B, W, Hkv, Dh, lens, seed):
+    """Fill rings as a model would: token p of sequence b sits at slot p % W."""
+    g = torch.Generator().manual_seed(seed)
+    ck = torch.zeros(B, W, Hkv, Dh, dtype=BF)
+    cv = torch.zeros(B, W, Hkv, Dh, dtype=BF)
+    hist_k, hist_v = [], []
+    for b, n in enumerate(lens):
+        k = torch.randn(n, Hkv, Dh, generator=g).to(BF)
+        v = torch.randn(n, Hkv, Dh, generator=g).to(BF)
+        for p in range(n):
+            ck[b, p % W], cv[b, p % W] = k[p], v[p]
+        hist_k.append(k)
+        hist_v.append(v)
+    return ck, cv, hist_k, hist_v
+
+
+@pytest.mark.parametrize("H,Hkv", [(4, 2), (32, 8), (8, 8), (12, 2)])
+@pytest.mark.parametrize("W,lens", [(16, [5, 16, 40]), (300, [1, 299, 300]), (4096, [4096, 17, 5000])])
+def test_attn_decode(H, Hkv, W, lens):
+    """lens[b] = tokens seen INCLUDING the new one (already in the ring)."""
+    h = _hip()
+    Dh, B = 128, len(lens)
+    ck, cv, hk, hv = _ring_case(B, W, Hkv, Dh, lens, seed=20)
+    q = rnd(B, H * Dh, seed=21)
+    pos = torch.tensor([n - 1 for n in lens], dtype=torch.int32)
+    got = h.attn_decode(q.cuda(), ck.cuda(), cv.cuda(), H, pos.cuda()).cpu()
+    for b, n in enumerate(lens):
+        lo = max(0, n - W)
+        kp = torch.arange(lo, n)
+        ref = mo._attend(q[b].view(1, H, Dh), hk[b][lo:n], hv[b][lo:n], torch.tensor([n - 1]), kp, W, causal=True)
+        ok, err = bf16_ulp_close(got[b], ref[0], ulps=2.0, floor=1e-2)
+        assert ok, (b, err)
+    # the arrival counters must be left at zero: a second call gives the same answer
+    again = h.attn_decode(q.cuda(), ck.cuda(), cv.cuda(), H, pos.cuda()).cpu()
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("H,Hkv", [(4, 2), (32, 8)])
+@pytest.mark.parametrize("W,seen,new", [
+    (4096, [0, 0, 0], [7, 150, 33]),      # first prefill, ragged
+    (8, [0, 0], [13, 5]),                 # window shorter than the prompt
+    (8, [4, 8, 21], [4, 4, 2]),           # later chunk: ring + new keys, wrap
+    (64, [100], [200]),                   # chunk longer than the window over a wrapped ring
+    (512, [0], [700]),                    # several key tiles, window cuts early tiles
+])
+def test_attn_prefill(H, Hkv, W, seen, new):
+    h = _hip()
+    Dh, B = 128, len(new)
+    T = sum(new)
+    ck, cv, hk, hv = _ring_case(B, W, Hkv, Dh, seen, seed=22)
+    qkv = rnd(T, (H + 2 * Hkv) * Dh, seed=23)
+    q_start = torch.tensor([0] + list(torch.tensor(new).cumsum(0)), dtype=torch.int32)
+    kv_before = torch.tensor(seen, dtype=torch.int32)
+    got = h.attn_prefill(qkv.cuda(), H, Hkv, Dh, ck.cuda(), cv.cuda(), W, q_start.cuda(), kv_before.cuda(), B, max(new)).cpu()
+    nq, nkv = H * Dh, Hkv * Dh
+    o = 0
+    for b, s in enumerate(new):
+        p = seen[b]
+        rows = qkv[o:o + s]
+        n_old = min(p, W)
+        keys = torch.cat([hk[b][p - n_old:p], rows[:, nq:nq + nkv].reshape(s, Hkv, Dh)])
+        vals = torch.cat([hv[b][p - n_old:p], rows[:, nq + nkv:].reshape(s, Hkv, Dh)])
+        kpos = torch.arange(p - n_old, p + s)
+        ref = mo._attend(rows[:, :nq].reshape(s, H, Dh), keys, vals, torch.arange(p, p + s), kpos, W, causal=True)
+        ok, err = bf16_ulp_close(got[o:o + s], ref, ulps=3.0, floor=2e-2)
+        assert ok, (b, err)
+        o += s
+
+
+def test_attn_prefill_nocache_unmasked():
+    h = _hip()
+    H, Hkv, Dh, T = 4, 2, 128, 150
+    qkv = rnd(T, (H + 2 * Hkv) * Dh, seed=24)
+    got = h.attn_prefill(qkv.cuda(), H, Hkv, Dh, None, None, T, None, None, 1, T, causal=False).cpu()
+    nq, nkv = H * Dh, Hkv * Dh
+    pos = torch.arange(T)
+    ref = mo._attend(qkv[:, :nq].reshape(T, H, Dh), qkv[:, nq:nq + nkv].reshape(T, Hkv, Dh),
+                     qkv[:, nq + nkv:].reshape(T, Hkv, Dh), pos, pos, None, causal=False)
+    ok, err = bf16_ulp_close(got, ref, ulps=3.0, floor=2e-2)
+    assert ok, err
+
+
+def test_kv_write_keeps_last_window():
+    h = _hip()
+    B, W, Hkv, Dh = 2, 4, 2, 128
+    new, seen = [6, 3], [5, 2]
+    T = sum(new)
+    k, v = rnd(T, Hkv * Dh, seed=25), rnd(T, Hkv * Dh, seed=26)
+    ck = torch.full((B, W, Hkv, Dh), 7.0, dtype=BF)
+    cv = torch.full((B, W, Hkv, Dh), 9.0, dtype=BF)
+    tok_seq = torch.tensor([0] * 6 + [1] * 3, dtype=torch.int32)
+    tok_pos = torch.tensor([5 + i for i in range(6)] + [2 + i for i in range(3)], dtype=torch.int32)
+    q_start = torch.tensor([0, 6, 9], dtype=torch.int32)
+    dk, dv = ck.cuda(), cv.cuda()
+    h.kv_write(dk, dv, k.cuda(), v.cuda(), tok_seq.cuda(), tok_pos.cuda(), q_start.cuda())
+    ek, ev = ck.clone(), cv.clone()
+    for t in range(T):
+        b = int(tok_seq[t])
+        i = t - int(q_start[b])
+        if i >= new[b] - W:
+            ek[b, int(tok_pos[t]) % W] = k[t].view(Hkv, Dh)
+            ev[b, int(tok_pos[t]) % W] = v[t].view(Hkv, Dh)
+    assert torch.equal(dk.cpu(), ek) and torch.equal(dv.cpu(), ev)
+
+
+@pytest.mark.parametrize("T", [1, 5, 40])
+def test_moe_router(T):
+    h = _hip()
+    D, E, k = 512, 8, 2
+    x, gate = rnd(T, D, seed=27), rnd(E, D, seed=28, scale=0.05)
+    logits = F.linear(x, gate)
+    tw, ti = torch.topk(logits, k)
+    tw = torch.softmax(tw, dim=1, dtype=torch.float).to(BF).float()
+    idx, w = h.moe_router(x.cuda(), gate.cuda(), k)
+    idx, w = idx.cpu().long(), w.cpu()
+    for t in range(T):
+        srt = torch.sort(logits[t].float(), descending=True).values
+        if srt[k - 1] == srt[k] or (k > 1 and srt[0] == srt[1]):
+            continue  # tie on bf16 logits: torch.topk's order is unspecified (hard parts)
+        got_logits = logits[t][idx[t]].float()
+        ref_logits = logits[t][ti[t]].float()
+        if not torch.equal(idx[t], ti[t]):
+            # accumulation-order noise may flip a bf16 rounding of a logit; require the same VALUES picked
+            assert torch.allclose(got_logits, ref_logits, atol=2e-2), (t, idx[t], ti[t])
+        assert torch.allclose(w[t], tw[t], atol=8e-3), (t, w[t], tw[t])

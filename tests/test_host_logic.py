@@ -1,0 +1,112 @@
+"""Host-side logic that needs no GPU: params.json decoding, ring sizing / metadata, rank-filtered loading."""
+import pytest
+import torch
+
+import mistral_oracle as mo
+from golden_util import Case
+from oracle_backend import OracleStackBackend
+
+
+def test_args_from_dict_aliases_and_unknown_keys():
+    from mistral_inference.args import TransformerArgs
+    p = dict(dim=8, n_layers=2, head_dim=128, hidden_dim=16, n_heads=2, n_kv_heads=1, norm_eps=1e-5, vocab_size=10,
+             _sliding_window=7, moe=dict(num_experts=8, num_experts_per_tok=2), bogus_key=1)
+    a = TransformerArgs.from_dict(p)
+    assert a.sliding_window == 7 and a.moe.num_experts == 8 and a.rope_theta is None and a.max_batch_size == 0
+    with pytest.raises(AssertionError):
+        TransformerArgs.from_dict(dict(p, sliding_window=3))  # both spellings given (reference args.py:56)
+    with pytest.raises(AssertionError):
+        TransformerArgs.from_dict(dict(p, model_type="mamba"))
+
+
+def test_cache_sizes():
+    from mistral_inference.cache import RotatingBufferCache, BufferCache, get_cache_sizes
+    assert RotatingBufferCache is BufferCache
+    assert get_cache_sizes(4, 100, None) == [100] * 4
+    assert get_cache_sizes(4, 100, 4096) == [4096] * 4          # an int window larger than the run still allocates W
+    assert get_cache_sizes(4, 100, [8, None]) == [8, 100, 8, 100]
+    with pytest.raises(AssertionError):
+        get_cache_sizes(3, 100, [8, None])
+
+
+def test_metadata_worked_example():
+    """W=3, seqlens=[5,7,2], kv_seqlens=[1,1,3]."""
+    from mistral_inference.cache import BufferCache
+    from mistral_inference import _hip
+    c = BufferCache(1, 3, 16, 2, 128, sliding_window=3)
+    c.init_kvseqlens(3)
+    c.update_seqlens([1, 1, 3])
+    (md,) = c.get_input_metadata([5, 7, 2])
+    assert md.to_cache_mask.int().tolist() == [0, 0, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 1]
+    assert md.positions.tolist() == [1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 6, 7, 3, 4]
+    assert md.cache_positions.tolist() == [0, 1, 2, 5, 3, 4, 6, 7]
+    assert md.cached_elements.tolist() == [3, 3, 2]
+    assert md.prefill and md.batch.branch == _hip.BRANCH_PREFILL
+    assert md.batch.q_start.tolist() == [0, 5, 12, 14] and md.batch.kv_before.tolist() == [1, 1, 3]
+    assert md.batch.tok_seq.tolist() == [0] * 5 + [1] * 7 + [2] * 2
+    c.update_seqlens([5, 7, 2])
+    assert c.kv_seqlens.tolist() == [6, 8, 5]
+    b = c.batch_metadata([1, 1, 1])
+    assert b.branch == _hip.BRANCH_DECODE
+    with pytest.raises(AssertionError, match="did you forget to reset cache"):
+        c.batch_metadata([1, 1])
+    c.reset()
+    assert c.batch_metadata([1, 1]).branch == _hip.BRANCH_PREFILL  # first call after reset is a (first) prefill
+
+
+def _model(case, rank, world):
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.transformer import Transformer
+    a = TransformerArgs.from_dict(case.params)
+    a.max_batch_size = case.max_batch_size
+    return Transformer(a, pipeline_rank=rank, num_pipeline_ranks=world, backend=OracleStackBackend())
+
+
+def test_rank_filtered_load_and_unexpected_key():
+    case = Case("dense_fp32")
+    w = case.weights()
+    m0, m1 = _model(case, 0, 2), _model(case, 1, 2)
+    assert list(m0.layers.keys()) == ["0"] and list(m1.layers.keys()) == ["1"]   # global ids (transformer.py:97)
+    assert m0.tok_embeddings is not None and m0.norm is None and m0.output is None
+    assert m1.tok_embeddings is None and m1.norm is not None and m1.output is not None
+    m0.load_state_dict(w, assign=True)
+    m1.load_state_dict(w, assign=True)
+    assert torch.equal(m1.layers["1"].attention.wq.weight, w["layers.1.attention.wq.weight"])
+    with pytest.raises(ValueError, match="Unexpected key"):
+        m0.load_state_dict(dict(w, stray=torch.zeros(1)))
+    three = _model(Case("swa_list_fp32"), 1, 3)  # ceil(2/3) = 1 layer per rank, rank 2 gets none
+    assert list(three.layers.keys()) == ["1"]
+
+
+@pytest.mark.parametrize("name", ["dense_fp32", "swa_chunk_fp32", "moe_fp32"])
+def test_generate_host_loop_matches_reference(name):
+    """generate() bookkeeping (chunking, logprob order, return shapes) with the oracle standing in for the
+    kernels, against the unmodified reference's outputs."""
+    from mistral_inference.generate import generate
+    case = Case(name)
+    m = _model(case, 0, 1)
+    m.load_state_dict(case.weights(), assign=True)
+    toks, lps = generate(case.prompts, m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size)
+    assert toks == case.tokens()
+    for a, b in zip(lps, case.logprobs()):
+        assert len(a) == len(b) and max(abs(x - y) for x, y in zip(a, b)) < 2e-5
+    gen, lps0 = generate(case.prompts, m, max_tokens=0, temperature=0.0, chunk_size=case.chunk_size)
+    assert gen == [] and [len(x) for x in lps0] == [len(p) - 1 for p in case.prompts]
+
+
+def test_generate_eos_and_sampling():
+    from mistral_inference.generate import generate, sample_top_p
+    case = Case("dense_fp32")
+    m = _model(case, 0, 1)
+    m.load_state_dict(case.weights(), assign=True)
+    ref = case.tokens()
+    eos = ref[0][2]
+    toks, _ = generate(case.prompts[:1], m, max_tokens=6, temperature=0.0, eos_id=eos)
+    assert toks == [ref[0][:2]]  # stops when every sequence has produced eos; eos itself is not emitted
+    torch.manual_seed(0)
+    probs = torch.tensor([[0.5, 0.25, 0.2, 0.05]])
+    picks = {int(sample_top_p(probs, 0.8)) for _ in range(200)}
+    assert picks == {0, 1, 2}  # mass before token 3 is 0.95 > 0.8 -> never drawn; token 2 (0.75 before) is kept
+    torch.manual_seed(1)
+    toks, lps = generate(case.prompts, m, max_tokens=3, temperature=0.7)
+    assert all(len(t) == 3 for t in toks) and all(x <= 0 for l in lps for x in l)
