@@ -11,6 +11,8 @@
 // with DPP row rotations; online softmax is kept per 16-lane group (no cross-lane sync in the loop)
 // and merged once at the end: lanes -> waves (LDS) -> splits (global fp32 partials; the last block to
 // arrive for a (sequence, kv head) combines them - agent-scope release/acquire, guide section 6 G16).
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -83,45 +85,56 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   const bf16_t* kbase = a.cache_k + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
   const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
 
-  int s = s_begin + wid * 4 + g;
-  u32x4 kc = {0u, 0u, 0u, 0u}, vc = {0u, 0u, 0u, 0u};
-  if (s < s_end) {
-    kc = ld16_nt(kbase + (size_t)s * row_stride);
-    vc = ld16_nt(vbase + (size_t)s * row_stride);
-  }
-  for (int s0 = s_begin; s0 < s_end; s0 += 16) {
-    const bool valid = s < s_end;
-    const int sn = s + 16;
-    u32x4 kn = {0u, 0u, 0u, 0u}, vn = {0u, 0u, 0u, 0u};
-    if (sn < s_end) {
-      kn = ld16_nt(kbase + (size_t)sn * row_stride);
-      vn = ld16_nt(vbase + (size_t)sn * row_stride);
+  // Each lane group walks slots s_begin + wid*4 + g + 16*j.  UK slots (K and V rows) are loaded per step and
+  // the next UK are already in flight while the current ones are reduced: 4*UK 16-byte loads per lane
+  // outstanding, i.e. 16 KiB per wave - the kernel is pure HBM latency/bandwidth, so depth is what matters.
+  constexpr int UK = 4;
+  const int s_first = s_begin + wid * 4 + g;
+  u32x4 kc[UK], vc[UK];
+  auto load_slots = [&](int s0, u32x4 (&kk)[UK], u32x4 (&vv)[UK]) {
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int sl = s0 + 16 * u;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      kk[u] = (sl < s_end) ? ld16_nt(kbase + (size_t)sl * row_stride) : z;
+      vv[u] = (sl < s_end) ? ld16_nt(vbase + (size_t)sl * row_stride) : z;
     }
-    float kf[8], vf[8];
+  };
+  load_slots(s_first, kc, vc);
+  for (int s0 = s_first; s0 - (wid * 4 + g) < s_end; s0 += 16 * UK) {
+    u32x4 kn[UK], vn[UK];
+    load_slots(s0 + 16 * UK, kn, vn);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      kf[2 * i] = bf_lo(kc[i]);
-      kf[2 * i + 1] = bf_hi(kc[i]);
-      vf[2 * i] = bf_lo(vc[i]);
-      vf[2 * i + 1] = bf_hi(vc[i]);
+    for (int u = 0; u < UK; ++u) {
+      const bool valid = (s0 + 16 * u) < s_end;
+      float kf[8], vf[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kf[2 * i] = bf_lo(kc[u][i]);
+        kf[2 * i + 1] = bf_hi(kc[u][i]);
+        vf[2 * i] = bf_lo(vc[u][i]);
+        vf[2 * i + 1] = bf_hi(vc[u][i]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(qf[r][i], kf[i], d);
+        d = row16_sum(d);
+        const float mn = valid ? fmaxf(st.m[r], d) : st.m[r];
+        const float alpha = exp2f(st.m[r] - mn);
+        const float p = valid ? exp2f(d - mn) : 0.f;
+        st.m[r] = mn;
+        st.l[r] = st.l[r] * alpha + p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i] * alpha);
+      }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float d = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) d = fmaf(qf[r][i], kf[i], d);
-      d = row16_sum(d);
-      const float mn = valid ? fmaxf(st.m[r], d) : st.m[r];
-      const float alpha = exp2f(st.m[r] - mn);
-      const float p = valid ? exp2f(d - mn) : 0.f;
-      st.m[r] = mn;
-      st.l[r] = st.l[r] * alpha + p;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i] * alpha);
+    for (int u = 0; u < UK; ++u) {
+      kc[u] = kn[u];
+      vc[u] = vn[u];
     }
-    kc = kn;
-    vc = vn;
-    s = sn;
   }
 
   // 4 lane groups -> wave
@@ -195,7 +208,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 }  // namespace
 
 int attn_decode_splits(int W) {
-  int n = (W + 127) / 128;
+  static int slots = 0;  // ring slots per block; MI_ATTN_SPLIT_SLOTS overrides (tuning)
+  if (slots == 0) {
+    const char* e = getenv("MI_ATTN_SPLIT_SLOTS");
+    slots = e ? atoi(e) : 128;
+    if (slots < 16) slots = 128;
+  }
+  int n = (W + slots - 1) / slots;
   if (n < 1) n = 1;
   if (n > 64) n = 64;
   return n;

@@ -5,16 +5,21 @@
 // (rope.py:13-23), the ring write (cache.py:83-92), the residual adds (:166,:168) and silu*mul.
 //
 // Structure (cdna_hip_programming.md "GEMV / M<=16 decode weights"): weights go straight HBM -> VGPR
-// with 16-byte non-temporal loads, two rows per wave in flight, U chunks deep, double buffered; the
-// (optionally RMS-normalised) activation vector lives in LDS; the first weight batch is issued before
-// the prologue so the x staging hides under HBM latency.  A wave owns "units" (a pair of weight rows)
+// with 16-byte non-temporal loads in batches of 8 per lane; a wave always has two batches (16 KiB) in
+// flight, across the prologue and across unit boundaries (the load cursor runs over the flattened
+// (unit, batch) sequence, two batches ahead of the FMAs).  The (optionally RMS-normalised) activation
+// vector lives in LDS; its loads are issued before the first weight batch so the prologue finishes under
+// the HBM latency of the weights.  A wave owns "units" (a pair of weight rows, or one row for small N)
 // strided over the whole grid, so at any instant the chip streams one contiguous weight region.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
 namespace {
 
-constexpr int U = 4;  // 16-byte chunks in flight per row per buffer
+constexpr int BATCH = 8;  // 16-byte loads per lane per batch (ROWS rows x BATCH/ROWS chunks); two batches in flight
+constexpr int XP = 4;     // x pieces (16 B) a thread can hold while the weight batches are issued (K * T <= 8192)
 
 template <int TT>
 struct Acc {
@@ -26,93 +31,125 @@ struct RowPair {
   const bf16_t* b;  // nullptr when the unit has one row
 };
 
-__device__ __forceinline__ void load_batch(const RowPair& r, int c0, int K, int lane, u32x4 (&ca)[U], u32x4 (&cb)[U]) {
+// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows.
+template <int ROWS>
+__device__ __forceinline__ void load_batch(const RowPair& r, int c0, int K, int lane, u32x4 (&buf)[BATCH]) {
+  constexpr int U = BATCH / ROWS;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = ((c0 + u) * 64 + lane) * 8;
     const bool ok = e < K;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    ca[u] = ok ? ld16_nt(r.a + e) : z;
-    cb[u] = (ok && r.b) ? ld16_nt(r.b + e) : z;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    buf[u] = ok ? ld16_nt(r.a + e) : z;
+    if (ROWS == 2) buf[U + u] = (ok && r.b) ? ld16_nt(r.b + e) : z;
   }
 }
 
-template <int TT>
-__device__ __forceinline__ void fma_chunk(const u32x4& wa, const u32x4& wb, const bf16_t* xs, int K, int e,
+template <int TT, int ROWS>
+__device__ __forceinline__ void fma_batch(const u32x4 (&buf)[BATCH], int c0, const bf16_t* xs, int K, int lane,
                                           Acc<TT>& acc) {
-  float a[8], b[8];
+  constexpr int U = BATCH / ROWS;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a[2 * i] = bf_lo(wa[i]);
-    a[2 * i + 1] = bf_hi(wa[i]);
-    b[2 * i] = bf_lo(wb[i]);
-    b[2 * i + 1] = bf_hi(wb[i]);
-  }
+  for (int u = 0; u < U; ++u) {
+    const int e = ((c0 + u) * 64 + lane) * 8;
+    if (e < K) {
+      float a[8], b[8];
 #pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + e);
+      for (int i = 0; i < 4; ++i) {
+        a[2 * i] = bf_lo(buf[u][i]);
+        a[2 * i + 1] = bf_hi(buf[u][i]);
+        if (ROWS == 2) {
+          b[2 * i] = bf_lo(buf[U + u][i]);
+          b[2 * i + 1] = bf_hi(buf[U + u][i]);
+        }
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float x0 = bf_lo(xv[i]), x1 = bf_hi(xv[i]);
-      acc.v[0][t] = fmaf(a[2 * i], x0, acc.v[0][t]);
-      acc.v[0][t] = fmaf(a[2 * i + 1], x1, acc.v[0][t]);
-      acc.v[1][t] = fmaf(b[2 * i], x0, acc.v[1][t]);
-      acc.v[1][t] = fmaf(b[2 * i + 1], x1, acc.v[1][t]);
-    }
-  }
-}
-
-// Finish the dot products of one unit whose first batch (ca, cb) is already in flight.
-template <int TT>
-__device__ __forceinline__ void dot_unit(const RowPair& r, const bf16_t* xs, int K, int lane, u32x4 (&ca)[U],
-                                         u32x4 (&cb)[U], Acc<TT>& acc) {
-  const int nch = (K + 511) >> 9;
+      for (int t = 0; t < TT; ++t) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + e);
 #pragma unroll
-  for (int t = 0; t < TT; ++t) acc.v[0][t] = acc.v[1][t] = 0.f;
-  for (int c0 = 0; c0 < nch; c0 += U) {
-    u32x4 na[U], nb[U];
-    if (c0 + U < nch) load_batch(r, c0 + U, K, lane, na, nb);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = ((c0 + u) * 64 + lane) * 8;
-      if (e < K) fma_chunk<TT>(ca[u], cb[u], xs, K, e, acc);
-    }
-    if (c0 + U < nch) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ca[u] = na[u];
-        cb[u] = nb[u];
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = bf_lo(xv[i]), x1 = bf_hi(xv[i]);
+          acc.v[0][t] = fmaf(a[2 * i], x0, acc.v[0][t]);
+          acc.v[0][t] = fmaf(a[2 * i + 1], x1, acc.v[0][t]);
+          if (ROWS == 2) {
+            acc.v[1][t] = fmaf(b[2 * i], x0, acc.v[1][t]);
+            acc.v[1][t] = fmaf(b[2 * i + 1], x1, acc.v[1][t]);
+          }
+        }
       }
     }
   }
-#pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    acc.v[0][t] = wave_sum(acc.v[0][t]);
-    acc.v[1][t] = wave_sum(acc.v[1][t]);
-  }
 }
 
-// Stage x[T, K] (rows x + t*ldx; rows t >= T are zero) into LDS, optionally RMS-normalised:
-// bf16( bf16(x * rsqrt(mean(x^2) + eps)) * w )   (transformer_layers.py:115-120)
+// ---- activation staging.  x[T, K] (rows t >= T are zero) goes to LDS, optionally RMS-normalised:
+// bf16( bf16(x * rsqrt(mean(x^2) + eps)) * w )   (transformer_layers.py:115-120).
+// Split in two so that the x (and norm weight) loads are the FIRST loads the wave issues - they are L2 hits and
+// return long before the HBM weight batches issued right after them, so the whole prologue runs under the
+// weight latency instead of in front of it.
+struct XRegs {
+  u32x4 x[XP];
+  u32x4 w[XP];
+};
+
 template <int TT>
-__device__ __forceinline__ void stage_x(bf16_t* xs, float* red, const bf16_t* x, int ldx, int T, int K,
-                                        const bf16_t* norm_w, float eps) {
+__device__ __forceinline__ bool x_issue(XRegs& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w) {
+  const int npieces = K >> 3;
+  const int total = TT * npieces;
+  if (total > XP * 256) return false;  // too big for registers: staged by the slow path in x_finish
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int q = threadIdx.x + i * 256;
+    xr.x[i] = u32x4{0u, 0u, 0u, 0u};
+    xr.w[i] = u32x4{0u, 0u, 0u, 0u};
+    if (q < total) {
+      const int t = q / npieces, p = q - t * npieces;
+      if (t < T) xr.x[i] = ld16(x + (size_t)t * ldx + p * 8);
+      if (norm_w) xr.w[i] = ld16(norm_w + p * 8);
+    }
+  }
+  return true;
+}
+
+template <int TT>
+__device__ __forceinline__ void x_finish(bool in_regs, XRegs& xr, bf16_t* xs, float* red, const bf16_t* x, int ldx,
+                                         int T, int K, const bf16_t* norm_w, float eps) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int npieces = K >> 3;
   float ss[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) ss[t] = 0.f;
-  for (int p = tid; p < npieces; p += 256) {
+  if (in_regs) {
+    const int total = TT * npieces;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t < T) v = ld16(x + (size_t)t * ldx + p * 8);
-      st16(xs + (size_t)t * K + p * 8, v);
+    for (int i = 0; i < XP; ++i) {
+      const int q = tid + i * 256;
+      if (q < total) {
+        const int t = q / npieces;
+        float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a = bf_lo(v[i]), b = bf_hi(v[i]);
-        ss[t] = fmaf(a, a, ss[t]);
-        ss[t] = fmaf(b, b, ss[t]);
+        for (int c = 0; c < 4; ++c) {
+          const float a = bf_lo(xr.x[i][c]), b = bf_hi(xr.x[i][c]);
+          s = fmaf(a, a, s);
+          s = fmaf(b, b, s);
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) ss[tt] += (tt == t) ? s : 0.f;
+        if (!norm_w) st16(xs + (size_t)q * 8, xr.x[i]);  // [t][K] row-major == q * 8
+      }
+    }
+  } else {
+    for (int p = tid; p < npieces; p += 256) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < T) v = ld16(x + (size_t)t * ldx + p * 8);
+        st16(xs + (size_t)t * K + p * 8, v);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = bf_lo(v[c]), b = bf_hi(v[c]);
+          ss[t] = fmaf(a, a, ss[t]);
+          ss[t] = fmaf(b, b, ss[t]);
+        }
       }
     }
   }
@@ -132,19 +169,36 @@ __device__ __forceinline__ void stage_x(bf16_t* xs, float* red, const bf16_t* x,
     const float s = red[t] + red[TT + t] + red[2 * TT + t] + red[3 * TT + t];
     inv[t] = 1.0f / sqrtf(s / (float)K + eps);
   }
-  for (int p = tid; p < npieces; p += 256) {
-    const u32x4 wv = ld16(norm_w + p * 8);
+  if (in_regs) {
+    const int total = TT * npieces;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + p * 8);
-      u32x4 o;
+    for (int i = 0; i < XP; ++i) {
+      const int q = tid + i * 256;
+      if (q < total) {
+        const int t = q / npieces;
+        float iv = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float y0 = bf_round(bf_lo(v[i]) * inv[t]) * bf_lo(wv[i]);
-        const float y1 = bf_round(bf_hi(v[i]) * inv[t]) * bf_hi(wv[i]);
-        o[i] = pack_bf2(y0, y1);
+        for (int tt = 0; tt < TT; ++tt) iv = (tt == t) ? inv[tt] : iv;
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          o[c] = pack_bf2(bf_round(bf_lo(xr.x[i][c]) * iv) * bf_lo(xr.w[i][c]),
+                          bf_round(bf_hi(xr.x[i][c]) * iv) * bf_hi(xr.w[i][c]));
+        st16(xs + (size_t)q * 8, o);
       }
-      st16(xs + (size_t)t * K + p * 8, o);
+    }
+  } else {
+    for (int p = tid; p < npieces; p += 256) {
+      const u32x4 wv = ld16(norm_w + p * 8);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + p * 8);
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          o[c] = pack_bf2(bf_round(bf_lo(v[c]) * inv[t]) * bf_lo(wv[c]), bf_round(bf_hi(v[c]) * inv[t]) * bf_hi(wv[c]));
+        st16(xs + (size_t)t * K + p * 8, o);
+      }
     }
   }
   __syncthreads();
@@ -156,7 +210,7 @@ __device__ __forceinline__ const bf16_t* seg_row(const GemvArgs& a, int r) {
   return a.w2 + (size_t)(r - a.n1) * a.K;
 }
 
-template <int MODE>
+template <int MODE, int ROWS>
 __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf16_t* e1, const bf16_t* e3) {
   RowPair r;
   if (MODE == GEMV_SWIGLU) {
@@ -165,6 +219,9 @@ __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf1
   } else if (MODE == GEMV_MOE_W13) {
     r.a = e1 + (size_t)u * a.K;
     r.b = e3 + (size_t)u * a.K;
+  } else if (ROWS == 1) {
+    r.a = seg_row(a, u);
+    r.b = nullptr;
   } else {
     r.a = seg_row(a, 2 * u);
     r.b = (2 * u + 1 < a.N) ? seg_row(a, 2 * u + 1) : nullptr;
@@ -172,14 +229,20 @@ __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf1
   return r;
 }
 
-template <int TT, int MODE>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+// ROWS = rows per unit (2 everywhere except the plain/residual/logits modes on small N, where single-row units
+// double the number of waves so that a 4096-row matrix still fills 256 CUs x 16 waves).
+template <int TT, int MODE, int ROWS>
+__global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)TT * a.K * 2);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nwaves = gridDim.x * 4;
-  const int units = (MODE == GEMV_SWIGLU || MODE == GEMV_MOE_W13) ? a.N : (a.N + 1) >> 1;
+  constexpr bool kPairOut = !(MODE == GEMV_SWIGLU || MODE == GEMV_MOE_W13);
+  const int units = kPairOut ? (ROWS == 2 ? (a.N + 1) >> 1 : a.N) : a.N;
+  constexpr int U = BATCH / ROWS;
+  const int nch = (a.K + 511) >> 9;
+  const int nb = (nch + U - 1) / U;  // batches per unit
 
   // MoE: blockIdx.y is the problem (token, slot); pick this problem's expert and input row
   const bf16_t* x = a.x;
@@ -193,23 +256,46 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     x = a.x + (size_t)(prob / a.top_k) * a.ldx;
     outp += (size_t)prob * a.ldo * 2;
   }
+  const int T = (MODE == GEMV_MOE_W13) ? 1 : a.T;
 
+  // 1. activation (and norm weight) loads first, 2. two weight batches, 3. finish the prologue under them
+  XRegs xr;
+  const bool in_regs = x_issue<TT>(xr, x, a.ldx, T, a.K, a.norm_w);
+
+  // load cursor over the flattened (unit, batch) sequence of this wave: always two batches ahead of the math
   int u = blockIdx.x * 4 + wid;
-  u32x4 ca[U], cb[U];
-  RowPair rp = {nullptr, nullptr};
-  if (u < units) {
-    rp = unit_rows<MODE>(a, u, e1, e3);
-    load_batch(rp, 0, a.K, lane, ca, cb);
-  }
-  stage_x<TT>(xs, red, x, a.ldx, (MODE == GEMV_MOE_W13) ? 1 : a.T, a.K, a.norm_w, a.eps);
+  int ul = u, jl = 0;
+  RowPair rpl = {nullptr, nullptr};
+  if (ul < units) rpl = unit_rows<MODE, ROWS>(a, ul, e1, e3);
+  u32x4 cur[BATCH], nxt[BATCH];
+  auto issue = [&](u32x4 (&buf)[BATCH]) {
+    if (ul < units) {
+      load_batch<ROWS>(rpl, jl * U, a.K, lane, buf);
+      if (++jl == nb) {
+        jl = 0;
+        ul += nwaves;
+        if (ul < units) rpl = unit_rows<MODE, ROWS>(a, ul, e1, e3);
+      }
+    }
+  };
+  issue(cur);
+  issue(nxt);
+  x_finish<TT>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
 
   while (u < units) {
     Acc<TT> acc;
-    dot_unit<TT>(rp, xs, a.K, lane, ca, cb, acc);
-    const int un = u + nwaves;
-    if (un < units) {
-      rp = unit_rows<MODE>(a, un, e1, e3);
-      load_batch(rp, 0, a.K, lane, ca, cb);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc.v[0][t] = acc.v[1][t] = 0.f;
+    for (int j = 0; j < nb; ++j) {
+      fma_batch<TT, ROWS>(cur, j * U, xs, a.K, lane, acc);
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) cur[i] = nxt[i];
+      issue(nxt);
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      acc.v[0][t] = wave_sum(acc.v[0][t]);
+      if (ROWS == 2) acc.v[1][t] = wave_sum(acc.v[1][t]);
     }
     // ---- epilogue: lane t finishes token t
     float v0 = 0.f, v1 = 0.f;
@@ -220,14 +306,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         v1 = acc.v[1][t];
       }
     }
-    const int T = (MODE == GEMV_MOE_W13) ? 1 : a.T;
     if (lane < T) {
       const int t = lane;
       if (MODE == GEMV_SWIGLU || MODE == GEMV_MOE_W13) {
         reinterpret_cast<bf16_t*>(outp)[(size_t)t * a.ldo + u] = f_to_bf(swiglu_bf(v0, v1));
       } else {
-        const int r0 = 2 * u;
-        const bool two = (r0 + 1 < a.N);
+        const int r0 = (ROWS == 2) ? 2 * u : u;
+        const bool two = (ROWS == 2) && (r0 + 1 < a.N);
         if (MODE == GEMV_LOGITS) {
           float* o = reinterpret_cast<float*>(outp) + (size_t)t * a.ldo + r0;
           o[0] = bf_round(v0);
@@ -267,7 +352,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         }
       }
     }
-    u = un;
+    u += nwaves;
   }
 }
 
@@ -282,6 +367,9 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   const int t = blockIdx.y;
   const int nwaves = gridDim.x * 4;
   const int units = (a.N + 1) >> 1;
+  constexpr int U = BATCH / 2;
+  const int nch = (a.K + 511) >> 9;
+  const int nb = (nch + U - 1) / U;
 
   int eid[TOPK];
   float ew[TOPK];
@@ -310,23 +398,37 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
     w2[k] = reinterpret_cast<const bf16_t*>(a.expert_tab[eid[k] * 3 + 1]);
   }
 
+  // flattened load cursor over (unit, expert, batch)
   int u = blockIdx.x * 4 + wid;
-  u32x4 ca[U], cb[U];
-  RowPair rp = {nullptr, nullptr};
-  auto rows = [&](int k, int uu) {
-    RowPair r;
-    r.a = w2[k] + (size_t)(2 * uu) * a.K;
-    r.b = (2 * uu + 1 < a.N) ? w2[k] + (size_t)(2 * uu + 1) * a.K : nullptr;
-    return r;
+  int ul = u, kl = 0, jl = 0;
+  u32x4 cur[BATCH], nxt[BATCH];
+  auto issue = [&](u32x4 (&buf)[BATCH]) {
+    if (ul < units) {
+      RowPair r;
+      const bf16_t* base = w2[0];
+#pragma unroll
+      for (int k = 1; k < TOPK; ++k) base = (kl == k) ? w2[k] : base;
+      r.a = base + (size_t)(2 * ul) * a.K;
+      r.b = (2 * ul + 1 < a.N) ? base + (size_t)(2 * ul + 1) * a.K : nullptr;
+      load_batch<2>(r, jl * U, a.K, lane, buf);
+      if (++jl == nb) {
+        jl = 0;
+        if (++kl == TOPK) {
+          kl = 0;
+          ul += nwaves;
+        }
+      }
+    }
   };
-  if (u < units) {
-    rp = rows(0, u);
-    load_batch(rp, 0, a.K, lane, ca, cb);
-  }
+  issue(cur);
+  issue(nxt);
   // stage the TOPK hidden rows of this token (rows of a.x are [T*TOPK, K], slot-major per token)
   for (int p = tid; p < (a.K >> 3) * TOPK; p += 256) {
     const int k = p / (a.K >> 3), pp = p % (a.K >> 3);
-    st16(xs + (size_t)k * a.K + pp * 8, ld16(a.x + ((size_t)t * TOPK + slot_of[k]) * a.ldx + pp * 8));
+    int so = slot_of[0];
+#pragma unroll
+    for (int kk = 1; kk < TOPK; ++kk) so = (k == kk) ? slot_of[kk] : so;
+    st16(xs + (size_t)k * a.K + pp * 8, ld16(a.x + ((size_t)t * TOPK + so) * a.ldx + pp * 8));
   }
   __syncthreads();
 
@@ -335,16 +437,16 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
 #pragma unroll
     for (int k = 0; k < TOPK; ++k) {
       Acc<1> acc;
-      dot_unit<1>(rp, xs + (size_t)k * a.K, a.K, lane, ca, cb, acc);
-      // next rows: next expert of this unit, or first expert of the next unit
-      const int nk = (k + 1 < TOPK) ? k + 1 : 0;
-      const int nu = (k + 1 < TOPK) ? u : u + nwaves;
-      if (nu < units) {
-        rp = rows(nk, nu);
-        load_batch(rp, 0, a.K, lane, ca, cb);
+      acc.v[0][0] = acc.v[1][0] = 0.f;
+      for (int j = 0; j < nb; ++j) {
+        fma_batch<1, 2>(cur, j * U, xs + (size_t)k * a.K, a.K, lane, acc);
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) cur[i] = nxt[i];
+        issue(nxt);
       }
-      r0 = bf_round(r0 + bf_round(ew[k] * bf_round(acc.v[0][0])));
-      r1 = bf_round(r1 + bf_round(ew[k] * bf_round(acc.v[1][0])));
+      const float y0 = wave_sum(acc.v[0][0]), y1 = wave_sum(acc.v[1][0]);
+      r0 = bf_round(r0 + bf_round(ew[k] * bf_round(y0)));
+      r1 = bf_round(r1 + bf_round(ew[k] * bf_round(y1)));
     }
     if (lane == 0) {
       const int n = 2 * u;
@@ -357,15 +459,15 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   }
 }
 
-template <int MODE>
+template <int MODE, int ROWS>
 hipError_t launch_mode(const GemvArgs& a, int TT, dim3 grid, size_t lds, hipStream_t s) {
   switch (TT) {
-    case 1: hipLaunchKernelGGL((gemv_kernel<1, MODE>), grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((gemv_kernel<2, MODE>), grid, dim3(256), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((gemv_kernel<3, MODE>), grid, dim3(256), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((gemv_kernel<4, MODE>), grid, dim3(256), lds, s, a); break;
-    case 6: hipLaunchKernelGGL((gemv_kernel<6, MODE>), grid, dim3(256), lds, s, a); break;
-    default: hipLaunchKernelGGL((gemv_kernel<8, MODE>), grid, dim3(256), lds, s, a); break;
+    case 1: hipLaunchKernelGGL((gemv_kernel<1, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((gemv_kernel<2, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((gemv_kernel<3, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((gemv_kernel<4, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
+    case 6: hipLaunchKernelGGL((gemv_kernel<6, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL((gemv_kernel<8, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
   }
   return hipGetLastError();
 }
@@ -383,11 +485,13 @@ int gemv_max_tokens(int K) {
 hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   if (g_gemv_max_blocks == 0) {
     const char* e = getenv("MI_GEMV_MAX_BLOCKS");
-    g_gemv_max_blocks = e ? atoi(e) : 2048;
-    if (g_gemv_max_blocks <= 0) g_gemv_max_blocks = 2048;
+    g_gemv_max_blocks = e ? atoi(e) : 4096;
+    if (g_gemv_max_blocks <= 0) g_gemv_max_blocks = 4096;
   }
   const bool pair_mode = !(a.mode == GEMV_SWIGLU || a.mode == GEMV_MOE_W13);
-  const int units = pair_mode ? (a.N + 1) / 2 : a.N;
+  // single-row units when row pairs would leave CUs without a full set of waves (256 CUs x 4 blocks x 4 waves)
+  const bool single = pair_mode && a.mode != GEMV_QKV_ROPE && a.mode != GEMV_MOE_W2 && (a.N + 1) / 2 < 4096;
+  const int units = pair_mode ? (single ? a.N : (a.N + 1) / 2) : a.N;
   int blocks = (units + 3) / 4;
   if (blocks > g_gemv_max_blocks) blocks = g_gemv_max_blocks;
   if (a.mode == GEMV_MOE_W2) {
@@ -408,12 +512,15 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)TT * a.K * 2 + 4 * TT * sizeof(float);
   dim3 grid(blocks, a.mode == GEMV_MOE_W13 ? a.T * a.top_k : 1);
   switch (a.mode) {
-    case GEMV_STORE: return launch_mode<GEMV_STORE>(a, TT, grid, lds, s);
-    case GEMV_RESIDUAL: return launch_mode<GEMV_RESIDUAL>(a, TT, grid, lds, s);
-    case GEMV_SWIGLU: return launch_mode<GEMV_SWIGLU>(a, TT, grid, lds, s);
-    case GEMV_LOGITS: return launch_mode<GEMV_LOGITS>(a, TT, grid, lds, s);
-    case GEMV_QKV_ROPE: return launch_mode<GEMV_QKV_ROPE>(a, TT, grid, lds, s);
-    case GEMV_MOE_W13: return launch_mode<GEMV_MOE_W13>(a, 1, grid, lds, s);
+    case GEMV_STORE:
+      return single ? launch_mode<GEMV_STORE, 1>(a, TT, grid, lds, s) : launch_mode<GEMV_STORE, 2>(a, TT, grid, lds, s);
+    case GEMV_RESIDUAL:
+      return single ? launch_mode<GEMV_RESIDUAL, 1>(a, TT, grid, lds, s) : launch_mode<GEMV_RESIDUAL, 2>(a, TT, grid, lds, s);
+    case GEMV_LOGITS:
+      return single ? launch_mode<GEMV_LOGITS, 1>(a, TT, grid, lds, s) : launch_mode<GEMV_LOGITS, 2>(a, TT, grid, lds, s);
+    case GEMV_SWIGLU: return launch_mode<GEMV_SWIGLU, 2>(a, TT, grid, lds, s);
+    case GEMV_QKV_ROPE: return launch_mode<GEMV_QKV_ROPE, 2>(a, TT, grid, lds, s);
+    case GEMV_MOE_W13: return launch_mode<GEMV_MOE_W13, 2>(a, 1, grid, lds, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -32,6 +32,11 @@ import torch.nn.functional as F
 
 ROPE_TABLE_LEN = 128_000  # transformer.py:116
 
+# Tests may set this to a list to record every router call's bf16 logits [T, E] (as fp32), in call order.
+# Used to tell a genuine mismatch from a top-k near-tie (torch.topk's tie order is unspecified and a 1-ulp
+# difference in a bf16 logit can swap the k-th and (k+1)-th expert; SURVEY.md section 7 "hard parts").
+ROUTER_TRACE: Optional[list] = None
+
 
 @dataclass
 class OracleArgs:
@@ -109,6 +114,8 @@ def moe_ffn(x: torch.Tensor, gate: torch.Tensor, experts: Sequence[Tuple[torch.T
     logits rounded to x.dtype, then experts visited in ascending id, each adding
     round(w * y_e) into a zero-initialised x.dtype accumulator."""
     logits = F.linear(x, gate)
+    if ROUTER_TRACE is not None:
+        ROUTER_TRACE.append(logits.float().clone())
     top_w, top_i = torch.topk(logits, top_k)
     top_w = torch.softmax(top_w, dim=1, dtype=torch.float).to(x.dtype)
     out = torch.zeros_like(x)

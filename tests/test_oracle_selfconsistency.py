@@ -1,0 +1,51 @@
+"""The reference's two self-consistency tests (tests/test_generate.py:36-69 and :199-230), restated on the
+oracle: greedy-decode then re-score prompt+generation in one prefill (and in chunks of 5) -- the decode
+branch, the first-prefill branch and the chunked branch must agree to 5e-4 in fp32."""
+import torch
+
+import mistral_oracle as mo
+
+ARGS = mo.OracleArgs(dim=512, n_layers=1, head_dim=128, hidden_dim=2048, n_heads=4, n_kv_heads=2, norm_eps=1e-5,
+                     vocab_size=32000)
+
+
+def _model(**over):
+    a = mo.OracleArgs(**{**ARGS.__dict__, **over})
+    return mo.OracleModel(a, mo.synth_weights(a, seed=42, dtype=torch.float32))
+
+
+def test_generation_decode_equals_prefill():
+    m = _model()
+    enc = [[0, 1, 2, 3, 4, 5, 6, 7], [0, 0, 1, 2], [0, 12, 13, 14], [0, 2, 4, 34]]
+    toks, lp_old = mo.generate(enc, m, max_tokens=7)
+    enc2 = [e + t for e, t in zip(enc, toks)]
+    gen, lp_new = mo.generate(enc2, m, max_tokens=0)
+    assert gen == [] and len(toks[0]) == 7
+    for a, b in zip(lp_old, lp_new):
+        assert all(abs(x - y) < 5e-4 for x, y in zip(a, b))
+
+
+def test_chunks_equal_one_shot():
+    m = _model()
+    enc = [[0] + list(range(7)), [0] + list(range(9, 0, -1))]
+    toks, lp_old = mo.generate(enc, m, max_tokens=8, max_batch_size=3)
+    enc2 = [e + t for e, t in zip(enc, toks)]
+    gen, lp_new = mo.generate(enc2, m, max_tokens=0, chunk_size=5, max_batch_size=3)
+    assert gen == []
+    for a, b in zip(lp_old, lp_new):
+        assert all(abs(x - y) < 5e-4 for x, y in zip(a, b))
+
+
+def test_sliding_window_and_moe_selfconsistency():
+    """Cases the reference's tests never reach (coverage gaps)."""
+    for over in (dict(sliding_window=4), dict(sliding_window=[4, None], n_layers=2),
+                 dict(num_experts=8, num_experts_per_tok=2, hidden_dim=512)):
+        m = _model(**over)
+        enc = [[0, 1, 2, 3, 4, 5, 6, 7, 8], [0, 5, 1]]
+        toks, lp_old = mo.generate(enc, m, max_tokens=6)
+        enc2 = [e + t for e, t in zip(enc, toks)]
+        for chunk in (None, 8):  # every prompt needs a token in every chunk (generate.py:94)
+            gen, lp_new = mo.generate(enc2, m, max_tokens=0, chunk_size=chunk)
+            assert gen == []
+            for a, b in zip(lp_old, lp_new):
+                assert all(abs(x - y) < 5e-4 for x, y in zip(a, b)), (over, chunk)
