@@ -202,7 +202,11 @@ def main() -> None:
         torch.cuda.synchronize()
 
     with torch.inference_mode():
-        # ---- prefill (timed once; includes the [T, V] fp32 LM head the API contract requires)
+        # ---- prefill: one untimed pass (allocates the workspace / logits buffers), then the timed pass on a
+        # reset cache; includes the [T, V] fp32 LM head the API contract requires
+        logits = model.forward(prompt, [T0], cache)
+        del logits
+        cache.reset()
         sync()
         t0 = time.perf_counter()
         logits = model.forward(prompt, [T0], cache)
@@ -244,7 +248,7 @@ def main() -> None:
                               "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
         "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),
                     "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
-                    "note": "first call: includes one-time workspace allocation"},
+                    "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
     }
     if world == 1:
         out["roofline"] = dominant_kernel_roofline(model, iters=4)

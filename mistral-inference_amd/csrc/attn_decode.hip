@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   __shared__ float sm_acc[4][R][DH];
   __shared__ int sm_last;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar control flow
   const int g = lane >> 4, dl = lane & 15;
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
   const int pos = a.tok_pos[b];
@@ -85,35 +86,44 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   const bf16_t* kbase = a.cache_k + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
   const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
 
-  // Each lane group walks slots s_begin + wid*4 + g + 16*j.  UK slots (K and V rows) are loaded per step and
-  // the next UK are already in flight while the current ones are reduced: 4*UK 16-byte loads per lane
-  // outstanding, i.e. 16 KiB per wave - the kernel is pure HBM latency/bandwidth, so depth is what matters.
+  // Each lane group walks slots s_begin + wid*4 + g + 16*j, UK slots (K and V rows = 2*UK loads) per step, two
+  // steps in flight (ping-pong register sets A/B, 16 KiB per wave outstanding): the kernel is pure HBM
+  // latency/bandwidth, so depth is what matters.  The loads are inline asm that hipcc does not count, waited for by
+  // hand with vmcnt(2*UK) = "the other set may stay in flight" (common.cuh; guide section 5.7): hipcc's own
+  // bookkeeping drains vmcnt to 0 every iteration.  Every step issues exactly 2*UK loads: out-of-range slots are
+  // clamped to a valid one and masked through `valid`; steps past the block's range load one dummy line.
   constexpr int UK = 4;
+  static_assert(2 * UK == 8, "vm_wait8");
   const int s_first = s_begin + wid * 4 + g;
-  u32x4 kc[UK], vc[UK];
-  auto load_slots = [&](int s0, u32x4 (&kk)[UK], u32x4 (&vv)[UK]) {
+  const int s_clamp = max(kv_len - 1, 0);
+  const int n_steps = (s_end > s_begin) ? (s_end - s_begin + 16 * UK - 1) / (16 * UK) : 0;  // block-uniform
+  u32x4 setA[2 * UK], setB[2 * UK];  // [0, UK): K rows, [UK, 2UK): V rows
+  auto load_step = [&](int it, u32x4 (&kv)[2 * UK]) {
+    if (it < n_steps) {
+      const int s0 = s_first + it * 16 * UK;
 #pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      const int sl = s0 + 16 * u;
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      kk[u] = (sl < s_end) ? ld16_nt(kbase + (size_t)sl * row_stride) : z;
-      vv[u] = (sl < s_end) ? ld16_nt(vbase + (size_t)sl * row_stride) : z;
+      for (int u = 0; u < UK; ++u) {
+        const int sl = min(s0 + 16 * u, s_clamp);
+        ld16_asm_nt(kv[u], kbase + (size_t)sl * row_stride);
+        ld16_asm_nt(kv[UK + u], vbase + (size_t)sl * row_stride);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2 * UK; ++u) ld16_asm(kv[u], a.q);
     }
   };
-  load_slots(s_first, kc, vc);
-  for (int s0 = s_first; s0 - (wid * 4 + g) < s_end; s0 += 16 * UK) {
-    u32x4 kn[UK], vn[UK];
-    load_slots(s0 + 16 * UK, kn, vn);
+  auto reduce_step = [&](int it, const u32x4 (&kv)[2 * UK]) {
+    const int s0 = s_first + it * 16 * UK;
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
       const bool valid = (s0 + 16 * u) < s_end;
       float kf[8], vf[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        kf[2 * i] = bf_lo(kc[u][i]);
-        kf[2 * i + 1] = bf_hi(kc[u][i]);
-        vf[2 * i] = bf_lo(vc[u][i]);
-        vf[2 * i + 1] = bf_hi(vc[u][i]);
+        kf[2 * i] = bf_lo(kv[u][i]);
+        kf[2 * i + 1] = bf_hi(kv[u][i]);
+        vf[2 * i] = bf_lo(kv[UK + u][i]);
+        vf[2 * i + 1] = bf_hi(kv[UK + u][i]);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -130,10 +140,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i] * alpha);
       }
     }
-#pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      kc[u] = kn[u];
-      vc[u] = vn[u];
+  };
+  load_step(0, setA);
+  load_step(1, setB);
+  for (int it = 0; it < n_steps; it += 2) {
+    vm_wait8<2 * UK>(setA);
+    reduce_step(it, setA);
+    load_step(it + 2, setA);
+    if (it + 1 < n_steps) {
+      vm_wait8<2 * UK>(setB);
+      reduce_step(it + 1, setB);
+      load_step(it + 3, setB);
     }
   }
 
@@ -188,16 +205,38 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   __syncthreads();
   if (!sm_last) return;
 
+  // Combine the splits.  (m, l) of every split go through LDS (one coalesced read) so that the accumulator loads
+  // below are independent of each other and can all be in flight together.
   const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH;
   const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2;
+  float* sm_ms = &sm_acc[0][0][0];      // [n_splits * R]   (sm_acc is free again: two barriers since its last read)
+  float* sm_ls = sm_ms + 64 * R;        // n_splits <= 64
+  for (int i = tid; i < a.n_splits * R; i += 256) {
+    const float2 ml = *reinterpret_cast<const float2*>(all_ml + 2 * i);
+    sm_ms[i] = ml.x;
+    sm_ls[i] = ml.y;
+  }
+  __syncthreads();
   for (int idx = tid; idx < R * DH; idx += 256) {
     const int r = idx / DH, d = idx % DH;
     float M = -1e30f;
-    for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, all_ml[(sp * R + r) * 2]);
+    for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, sm_ms[sp * R + r]);
     float L = 0.f, A = 0.f;
-    for (int sp = 0; sp < a.n_splits; ++sp) {
-      const float e = exp2f(all_ml[(sp * R + r) * 2] - M);
-      L += all_ml[(sp * R + r) * 2 + 1] * e;
+    int sp = 0;
+    for (; sp + 8 <= a.n_splits; sp += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = all_acc[(size_t)(sp + j) * R * DH + idx];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = exp2f(sm_ms[(sp + j) * R + r] - M);
+        L += sm_ls[(sp + j) * R + r] * e;
+        A += v[j] * e;
+      }
+    }
+    for (; sp < a.n_splits; ++sp) {
+      const float e = exp2f(sm_ms[sp * R + r] - M);
+      L += sm_ls[sp * R + r] * e;
       A += all_acc[(size_t)sp * R * DH + idx] * e;
     }
     reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)(kvh * R + r) * DH + d] = f_to_bf(A / L);

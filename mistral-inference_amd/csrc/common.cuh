@@ -35,6 +35,31 @@ __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
 }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// ---- loads hipcc does not count (cdna_hip_programming.md section 5.7).
+// hipcc's s_waitcnt insertion tracks only its most recent batch across a loop back-edge and drains vmcnt to 0
+// every iteration, which collapses a two-batch-deep weight stream to one batch in flight.  These asm loads are
+// invisible to that bookkeeping; the kernel waits for them itself with vm_wait<N>(regs...) - `N` = loads issued
+// AFTER the ones being waited for (loads retire in order), and the "+v" operands pin every consumer of those
+// registers behind the wait (form (ii) of the guide).  Compiler-issued loads elsewhere in the kernel only ever
+// over-wait because of the extra outstanding loads, never under-wait.
+__device__ __forceinline__ void ld16_asm_nt(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld16_asm(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait8(u32x4 (&r)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+               : "n"(N)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait4(u32x4 (&r)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+
 // Sum over the 64 lanes of a wave; every lane gets the total.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int BATCH = 8;  // 16-byte loads per lane per batch (ROWS rows x BATCH/ROWS chunks); two batches in flight
-constexpr int XP = 4;     // x pieces (16 B) a thread can hold while the weight batches are issued (K * T <= 8192)
 
 template <int TT>
 struct Acc {
@@ -31,17 +30,19 @@ struct RowPair {
   const bf16_t* b;  // nullptr when the unit has one row
 };
 
-// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows.
+// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows: ALWAYS exactly BATCH asm loads, so the
+// hand-written vmcnt counts are static.  Chunk offsets past K are clamped to the row's last 16 bytes (fma_batch
+// skips them), a missing second row aliases the first (the epilogue drops it), and past the wave's last unit the
+// caller passes a dummy row (one L2-resident line).  Never a `cond ? load : 0`: that makes hipcc branch around each
+// load and wait vmcnt(0) after it (cdna_hip_programming.md, ".s-level traps" (c)).
 template <int ROWS>
 __device__ __forceinline__ void load_batch(const RowPair& r, int c0, int K, int lane, u32x4 (&buf)[BATCH]) {
   constexpr int U = BATCH / ROWS;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int e = ((c0 + u) * 64 + lane) * 8;
-    const bool ok = e < K;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    buf[u] = ok ? ld16_nt(r.a + e) : z;
-    if (ROWS == 2) buf[U + u] = (ok && r.b) ? ld16_nt(r.b + e) : z;
+    const int e = min(((c0 + u) * 64 + lane) * 8, K - 8);
+    ld16_asm_nt(buf[u], r.a + e);
+    if (ROWS == 2) ld16_asm_nt(buf[U + u], r.b + e);
   }
 }
 
@@ -86,45 +87,52 @@ __device__ __forceinline__ void fma_batch(const u32x4 (&buf)[BATCH], int c0, con
 // Split in two so that the x (and norm weight) loads are the FIRST loads the wave issues - they are L2 hits and
 // return long before the HBM weight batches issued right after them, so the whole prologue runs under the
 // weight latency instead of in front of it.
+// Activation pieces (16 B) a thread holds in registers while the weight batches are issued.  Modes that fuse the
+// RMSNorm (K = model dim <= 8192 for one token) hold NX = 4 x pieces + NW = 4 norm-weight pieces; the plain modes
+// (Wo, W2: K up to 16384) hold NX = 8 x pieces and no norm weights.  Anything larger takes the in-loop path.
+template <int NX, int NW>
 struct XRegs {
-  u32x4 x[XP];
-  u32x4 w[XP];
+  u32x4 x[NX];
+  u32x4 w[NW > 0 ? NW : 1];
 };
 
-template <int TT>
-__device__ __forceinline__ bool x_issue(XRegs& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w) {
+// Issues exactly NX + NW asm loads (clamped / dummy where there is nothing to load).
+template <int TT, int NX, int NW>
+__device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w) {
   const int npieces = K >> 3;
   const int total = TT * npieces;
-  if (total > XP * 256) return false;  // too big for registers: staged by the slow path in x_finish
+  const bool fits = total <= NX * 256 && (norm_w == nullptr || total <= NW * 256);
+  const bf16_t* wsrc = norm_w ? norm_w : x;
 #pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    const int q = threadIdx.x + i * 256;
-    xr.x[i] = u32x4{0u, 0u, 0u, 0u};
-    xr.w[i] = u32x4{0u, 0u, 0u, 0u};
-    if (q < total) {
-      const int t = q / npieces, p = q - t * npieces;
-      if (t < T) xr.x[i] = ld16(x + (size_t)t * ldx + p * 8);
-      if (norm_w) xr.w[i] = ld16(norm_w + p * 8);
-    }
+  for (int i = 0; i < NX; ++i) {
+    const int q = min((int)threadIdx.x + i * 256, total - 1);
+    const int t = q / npieces, p = q - t * npieces;
+    ld16_asm(xr.x[i], x + (size_t)min(t, T - 1) * ldx + p * 8);
+    if (i < NW) ld16_asm(xr.w[i], wsrc + p * 8);
   }
-  return true;
+  return fits;
 }
 
-template <int TT>
-__device__ __forceinline__ void x_finish(bool in_regs, XRegs& xr, bf16_t* xs, float* red, const bf16_t* x, int ldx,
+template <int TT, int NX, int NW>
+__device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red, const bf16_t* x, int ldx,
                                          int T, int K, const bf16_t* norm_w, float eps) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int npieces = K >> 3;
   float ss[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) ss[t] = 0.f;
+  // the NX + NW activation loads were issued before the two weight batches (2 * BATCH loads)
+  if constexpr (NX == 8) vm_wait8<2 * BATCH>(xr.x);
+  if constexpr (NX == 4) vm_wait4<2 * BATCH>(xr.x);
+  if constexpr (NW == 4) vm_wait4<2 * BATCH>(xr.w);
   if (in_regs) {
     const int total = TT * npieces;
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int q = tid + i * 256;
       if (q < total) {
         const int t = q / npieces;
+        if (t >= T) xr.x[i] = u32x4{0u, 0u, 0u, 0u};
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -141,8 +149,9 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs& xr, bf16_t* xs, fl
     for (int p = tid; p < npieces; p += 256) {
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (t < T) v = ld16(x + (size_t)t * ldx + p * 8);
+        const u32x4 ld = ld16(x + (size_t)min(t, T - 1) * ldx + p * 8);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const u32x4 v = (t < T) ? ld : z;
         st16(xs + (size_t)t * K + p * 8, v);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -170,21 +179,23 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs& xr, bf16_t* xs, fl
     inv[t] = 1.0f / sqrtf(s / (float)K + eps);
   }
   if (in_regs) {
-    const int total = TT * npieces;
+    if constexpr (NW > 0) {
+      const int total = TT * npieces;
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      const int q = tid + i * 256;
-      if (q < total) {
-        const int t = q / npieces;
-        float iv = 0.f;
+      for (int i = 0; i < NX; ++i) {
+        const int q = tid + i * 256;
+        if (q < total) {
+          const int t = q / npieces;
+          float iv = 0.f;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) iv = (tt == t) ? inv[tt] : iv;
-        u32x4 o;
+          for (int tt = 0; tt < TT; ++tt) iv = (tt == t) ? inv[tt] : iv;
+          u32x4 o;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          o[c] = pack_bf2(bf_round(bf_lo(xr.x[i][c]) * iv) * bf_lo(xr.w[i][c]),
-                          bf_round(bf_hi(xr.x[i][c]) * iv) * bf_hi(xr.w[i][c]));
-        st16(xs + (size_t)q * 8, o);
+          for (int c = 0; c < 4; ++c)
+            o[c] = pack_bf2(bf_round(bf_lo(xr.x[i][c]) * iv) * bf_lo(xr.w[i < NW ? i : 0][c]),
+                            bf_round(bf_hi(xr.x[i][c]) * iv) * bf_hi(xr.w[i < NW ? i : 0][c]));
+          st16(xs + (size_t)q * 8, o);
+        }
       }
     }
   } else {
@@ -221,10 +232,10 @@ __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf1
     r.b = e3 + (size_t)u * a.K;
   } else if (ROWS == 1) {
     r.a = seg_row(a, u);
-    r.b = nullptr;
+    r.b = r.a;
   } else {
     r.a = seg_row(a, 2 * u);
-    r.b = (2 * u + 1 < a.N) ? seg_row(a, 2 * u + 1) : nullptr;
+    r.b = (2 * u + 1 < a.N) ? seg_row(a, 2 * u + 1) : r.a;  // odd N: alias, result dropped in the epilogue
   }
   return r;
 }
@@ -236,7 +247,8 @@ __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_k
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)TT * a.K * 2);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: unit loops become scalar
   const int nwaves = gridDim.x * 4;
   constexpr bool kPairOut = !(MODE == GEMV_SWIGLU || MODE == GEMV_MOE_W13);
   const int units = kPairOut ? (ROWS == 2 ? (a.N + 1) >> 1 : a.N) : a.N;
@@ -259,15 +271,17 @@ __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_k
   const int T = (MODE == GEMV_MOE_W13) ? 1 : a.T;
 
   // 1. activation (and norm weight) loads first, 2. two weight batches, 3. finish the prologue under them
-  XRegs xr;
-  const bool in_regs = x_issue<TT>(xr, x, a.ldx, T, a.K, a.norm_w);
+  constexpr bool kNormMode = MODE == GEMV_QKV_ROPE || MODE == GEMV_SWIGLU || MODE == GEMV_LOGITS || MODE == GEMV_MOE_W13;
+  constexpr int NX = kNormMode ? 4 : 8, NW = kNormMode ? 4 : 0;
+  XRegs<NX, NW> xr;
+  const bool in_regs = x_issue<TT, NX, NW>(xr, x, a.ldx, T, a.K, a.norm_w);
 
   // load cursor over the flattened (unit, batch) sequence of this wave: always two batches ahead of the math
   int u = blockIdx.x * 4 + wid;
   int ul = u, jl = 0;
-  RowPair rpl = {nullptr, nullptr};
-  if (ul < units) rpl = unit_rows<MODE, ROWS>(a, ul, e1, e3);
-  u32x4 cur[BATCH], nxt[BATCH];
+  RowPair rpl = unit_rows<MODE, ROWS>(a, min(ul, units - 1), e1, e3);
+  u32x4 bufA[BATCH], bufB[BATCH];
+  const RowPair dummy = {x, x};  // past the last unit: BATCH loads of one L2-resident line keep the counts static
   auto issue = [&](u32x4 (&buf)[BATCH]) {
     if (ul < units) {
       load_batch<ROWS>(rpl, jl * U, a.K, lane, buf);
@@ -276,22 +290,20 @@ __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_k
         ul += nwaves;
         if (ul < units) rpl = unit_rows<MODE, ROWS>(a, ul, e1, e3);
       }
+    } else {
+      load_batch<ROWS>(dummy, 0, 8, 0, buf);
     }
   };
-  issue(cur);
-  issue(nxt);
-  x_finish<TT>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
+  issue(bufA);
+  issue(bufB);
+  x_finish<TT, NX, NW>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
 
-  while (u < units) {
-    Acc<TT> acc;
+  Acc<TT> acc;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) acc.v[0][t] = acc.v[1][t] = 0.f;
-    for (int j = 0; j < nb; ++j) {
-      fma_batch<TT, ROWS>(cur, j * U, xs, a.K, lane, acc);
-#pragma unroll
-      for (int i = 0; i < BATCH; ++i) cur[i] = nxt[i];
-      issue(nxt);
-    }
+  for (int t = 0; t < TT; ++t) acc.v[0][t] = acc.v[1][t] = 0.f;
+  int jc = 0;
+
+  auto finish_unit = [&]() {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       acc.v[0][t] = wave_sum(acc.v[0][t]);
@@ -352,7 +364,25 @@ __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_k
         }
       }
     }
-    u += nwaves;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc.v[0][t] = acc.v[1][t] = 0.f;
+  };
+
+  // One step = consume the oldest batch, refill the same registers with the batch two ahead (ping-pong between
+  // bufA and bufB: no register copies, so the compiler's wait for bufA leaves bufB's eight loads in flight).
+  auto step = [&](u32x4 (&buf)[BATCH]) {
+    vm_wait8<BATCH>(buf);  // the other buffer's BATCH loads were issued after this one's and may stay in flight
+    fma_batch<TT, ROWS>(buf, jc * U, xs, a.K, lane, acc);
+    issue(buf);
+    if (++jc == nb) {
+      jc = 0;
+      finish_unit();
+      u += nwaves;
+    }
+  };
+  while (u < units) {
+    step(bufA);
+    if (u < units) step(bufB);
   }
 }
 
@@ -363,7 +393,8 @@ template <int TOPK>
 __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [TOPK][K]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = blockIdx.y;
   const int nwaves = gridDim.x * 4;
   const int units = (a.N + 1) >> 1;
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   // flattened load cursor over (unit, expert, batch)
   int u = blockIdx.x * 4 + wid;
   int ul = u, kl = 0, jl = 0;
-  u32x4 cur[BATCH], nxt[BATCH];
+  u32x4 bufA[BATCH], bufB[BATCH];
   auto issue = [&](u32x4 (&buf)[BATCH]) {
     if (ul < units) {
       RowPair r;
@@ -409,7 +440,7 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
 #pragma unroll
       for (int k = 1; k < TOPK; ++k) base = (kl == k) ? w2[k] : base;
       r.a = base + (size_t)(2 * ul) * a.K;
-      r.b = (2 * ul + 1 < a.N) ? base + (size_t)(2 * ul + 1) * a.K : nullptr;
+      r.b = (2 * ul + 1 < a.N) ? base + (size_t)(2 * ul + 1) * a.K : r.a;
       load_batch<2>(r, jl * U, a.K, lane, buf);
       if (++jl == nb) {
         jl = 0;
@@ -418,10 +449,13 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
           ul += nwaves;
         }
       }
+    } else {
+      const RowPair dummy = {a.x, a.x};
+      load_batch<2>(dummy, 0, 8, 0, buf);
     }
   };
-  issue(cur);
-  issue(nxt);
+  issue(bufA);
+  issue(bufB);
   // stage the TOPK hidden rows of this token (rows of a.x are [T*TOPK, K], slot-major per token)
   for (int p = tid; p < (a.K >> 3) * TOPK; p += 256) {
     const int k = p / (a.K >> 3), pp = p % (a.K >> 3);
@@ -432,30 +466,40 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   }
   __syncthreads();
 
-  while (u < units) {
-    float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < TOPK; ++k) {
-      Acc<1> acc;
-      acc.v[0][0] = acc.v[1][0] = 0.f;
-      for (int j = 0; j < nb; ++j) {
-        fma_batch<1, 2>(cur, j * U, xs + (size_t)k * a.K, a.K, lane, acc);
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) cur[i] = nxt[i];
-        issue(nxt);
-      }
+  Acc<1> acc;
+  acc.v[0][0] = acc.v[1][0] = 0.f;
+  int jc = 0, kc = 0;
+  float r0 = 0.f, r1 = 0.f;
+  auto step = [&](u32x4 (&buf)[BATCH]) {
+    vm_wait8<BATCH>(buf);
+    fma_batch<1, 2>(buf, jc * U, xs + (size_t)kc * a.K, a.K, lane, acc);
+    issue(buf);
+    if (++jc == nb) {
+      jc = 0;
       const float y0 = wave_sum(acc.v[0][0]), y1 = wave_sum(acc.v[1][0]);
-      r0 = bf_round(r0 + bf_round(ew[k] * bf_round(y0)));
-      r1 = bf_round(r1 + bf_round(ew[k] * bf_round(y1)));
+      acc.v[0][0] = acc.v[1][0] = 0.f;
+      float w = ew[0];
+#pragma unroll
+      for (int k = 1; k < TOPK; ++k) w = (kc == k) ? ew[k] : w;
+      r0 = bf_round(r0 + bf_round(w * bf_round(y0)));
+      r1 = bf_round(r1 + bf_round(w * bf_round(y1)));
+      if (++kc == TOPK) {
+        kc = 0;
+        if (lane == 0) {
+          const int n = 2 * u;
+          const bf16_t* rs = a.residual + (size_t)t * a.ldo + n;
+          bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)t * a.ldo + n;
+          o[0] = f_to_bf(bf_to_f(rs[0]) + r0);
+          if (n + 1 < a.N) o[1] = f_to_bf(bf_to_f(rs[1]) + r1);
+        }
+        r0 = r1 = 0.f;
+        u += nwaves;
+      }
     }
-    if (lane == 0) {
-      const int n = 2 * u;
-      const bf16_t* rs = a.residual + (size_t)t * a.ldo + n;
-      bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)t * a.ldo + n;
-      o[0] = f_to_bf(bf_to_f(rs[0]) + r0);
-      if (n + 1 < a.N) o[1] = f_to_bf(bf_to_f(rs[1]) + r1);
-    }
-    u += nwaves;
+  };
+  while (u < units) {
+    step(bufA);
+    if (u < units) step(bufB);
   }
 }
 
