@@ -44,7 +44,7 @@ __device__ __forceinline__ void merge_from(State<R>& s, int off) {
   }
 }
 
-template <int R>
+template <int R, bool TWO_PASS>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   __shared__ float sm_m[4][R];
   __shared__ float sm_l[4][R];
@@ -90,26 +90,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   // steps in flight (ping-pong register sets A/B, 16 KiB per wave outstanding): the kernel is pure HBM
   // latency/bandwidth, so depth is what matters.  The loads are inline asm that hipcc does not count, waited for by
   // hand with vmcnt(2*UK) = "the other set may stay in flight" (common.cuh; guide section 5.7): hipcc's own
-  // bookkeeping drains vmcnt to 0 every iteration.  Every step issues exactly 2*UK loads: out-of-range slots are
-  // clamped to a valid one and masked through `valid`; steps past the block's range load one dummy line.
+  // bookkeeping drains vmcnt to 0 every iteration.  Out-of-range slots are clamped to a valid one and masked
+  // through `valid`.
   constexpr int UK = 4;
   static_assert(2 * UK == 8, "vm_wait8");
   const int s_first = s_begin + wid * 4 + g;
   const int s_clamp = max(kv_len - 1, 0);
   const int n_steps = (s_end > s_begin) ? (s_end - s_begin + 16 * UK - 1) / (16 * UK) : 0;  // block-uniform
   u32x4 setA[2 * UK], setB[2 * UK];  // [0, UK): K rows, [UK, 2UK): V rows
-  auto load_step = [&](int it, u32x4 (&kv)[2 * UK]) {
-    if (it < n_steps) {
-      const int s0 = s_first + it * 16 * UK;
+  auto load_step = [&](int it, u32x4 (&kv)[2 * UK]) {   // callers guarantee it < n_steps (block-uniform)
+    const int s0 = s_first + it * 16 * UK;
 #pragma unroll
-      for (int u = 0; u < UK; ++u) {
-        const int sl = min(s0 + 16 * u, s_clamp);
-        ld16_asm_nt(kv[u], kbase + (size_t)sl * row_stride);
-        ld16_asm_nt(kv[UK + u], vbase + (size_t)sl * row_stride);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 2 * UK; ++u) ld16_asm(kv[u], a.q);
+    for (int u = 0; u < UK; ++u) {
+      const int sl = min(s0 + 16 * u, s_clamp);
+      ld16_asm_nt(kv[u], kbase + (size_t)sl * row_stride);
+      ld16_asm_nt(kv[UK + u], vbase + (size_t)sl * row_stride);
     }
   };
   auto reduce_step = [&](int it, const u32x4 (&kv)[2 * UK]) {
@@ -141,16 +136,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
       }
     }
   };
-  load_step(0, setA);
-  load_step(1, setB);
+  // Every asm load is waited for before its registers can be reused: the wait for step `it` allows the 2*UK loads
+  // of step it+1 to stay in flight when that step exists, and is a full drain when it does not.
+  if (n_steps > 0) load_step(0, setA);
+  if (n_steps > 1) load_step(1, setB);
   for (int it = 0; it < n_steps; it += 2) {
-    vm_wait8<2 * UK>(setA);
+    if (it + 1 < n_steps) vm_wait8<2 * UK>(setA); else vm_wait8<0>(setA);
     reduce_step(it, setA);
-    load_step(it + 2, setA);
+    if (it + 2 < n_steps) load_step(it + 2, setA);
     if (it + 1 < n_steps) {
-      vm_wait8<2 * UK>(setB);
+      if (it + 2 < n_steps) vm_wait8<2 * UK>(setB); else vm_wait8<0>(setB);
       reduce_step(it + 1, setB);
-      load_step(it + 3, setB);
+      if (it + 3 < n_steps) load_step(it + 3, setB);
     }
   }
 
@@ -190,6 +187,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
       p_ml[r * 2 + 1] = L;
     }
   }
+
+  if (TWO_PASS) return;  // the combine runs as its own launch (the kernel boundary provides the visibility)
 
   // arrival ticket; the last block of this (sequence, kv head) combines all splits
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -244,6 +243,58 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   if (tid == 0) __hip_atomic_store(&a.tickets[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Second launch of the two-pass form: one block per (sequence, kv head) folds the per-split partials.
+template <int R>
+__global__ __launch_bounds__(256) void attn_decode_combine_kernel(AttnDecodeArgs a) {
+  __shared__ float sm_ms[64 * R];
+  __shared__ float sm_ls[64 * R];
+  const int tid = threadIdx.x, kvh = blockIdx.x, b = blockIdx.y;
+  const int bh = b * a.Hkv + kvh;
+  const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH;
+  const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2;
+  for (int i = tid; i < a.n_splits * R; i += 256) {
+    const float2 ml = *reinterpret_cast<const float2*>(all_ml + 2 * i);
+    sm_ms[i] = ml.x;
+    sm_ls[i] = ml.y;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < R * DH; idx += 256) {
+    const int r = idx / DH, d = idx % DH;
+    float M = -1e30f;
+    for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, sm_ms[sp * R + r]);
+    float L = 0.f, A = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= a.n_splits; sp += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = all_acc[(size_t)(sp + j) * R * DH + idx];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = exp2f(sm_ms[(sp + j) * R + r] - M);
+        L += sm_ls[(sp + j) * R + r] * e;
+        A += v[j] * e;
+      }
+    }
+    for (; sp < a.n_splits; ++sp) {
+      const float e = exp2f(sm_ms[sp * R + r] - M);
+      L += sm_ls[sp * R + r] * e;
+      A += all_acc[(size_t)sp * R * DH + idx] * e;
+    }
+    reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)(kvh * R + r) * DH + d] = f_to_bf(A / L);
+  }
+}
+
+template <int R>
+void launch_r(const AttnDecodeArgs& a, bool two_pass, hipStream_t s) {
+  dim3 grid(a.n_splits, a.Hkv, a.B), block(256);
+  if (two_pass) {
+    hipLaunchKernelGGL((attn_decode_kernel<R, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<R>), dim3(a.Hkv, a.B), block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_decode_kernel<R, false>), grid, block, 0, s, a);
+  }
+}
+
 }  // namespace
 
 int attn_decode_splits(int W) {
@@ -267,13 +318,17 @@ size_t attn_decode_partial_floats(int B, int H, int Hkv, int Dh, int W) {
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
   if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
   const int R = a.H / a.Hkv;
-  dim3 grid(a.n_splits, a.Hkv, a.B), block(256);
+  static int two_pass = -1;  // MI_ATTN_TWO_PASS=1: partials + separate combine launch instead of the in-kernel ticket
+  if (two_pass < 0) {
+    const char* e = getenv("MI_ATTN_TWO_PASS");
+    two_pass = e ? atoi(e) : 0;
+  }
   switch (R) {
-    case 1: hipLaunchKernelGGL((attn_decode_kernel<1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((attn_decode_kernel<2>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((attn_decode_kernel<4>), grid, block, 0, s, a); break;
-    case 6: hipLaunchKernelGGL((attn_decode_kernel<6>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((attn_decode_kernel<8>), grid, block, 0, s, a); break;
+    case 1: launch_r<1>(a, two_pass, s); break;
+    case 2: launch_r<2>(a, two_pass, s); break;
+    case 4: launch_r<4>(a, two_pass, s); break;
+    case 6: launch_r<6>(a, two_pass, s); break;
+    case 8: launch_r<8>(a, two_pass, s); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

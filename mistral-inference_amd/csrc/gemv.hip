@@ -30,11 +30,10 @@ struct RowPair {
   const bf16_t* b;  // nullptr when the unit has one row
 };
 
-// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows: ALWAYS exactly BATCH asm loads, so the
+// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows: always exactly BATCH asm loads, so the
 // hand-written vmcnt counts are static.  Chunk offsets past K are clamped to the row's last 16 bytes (fma_batch
-// skips them), a missing second row aliases the first (the epilogue drops it), and past the wave's last unit the
-// caller passes a dummy row (one L2-resident line).  Never a `cond ? load : 0`: that makes hipcc branch around each
-// load and wait vmcnt(0) after it (cdna_hip_programming.md, ".s-level traps" (c)).
+// skips them) and a missing second row aliases the first (the epilogue drops it).  Never a `cond ? load : 0`: that
+// makes hipcc branch around each load and wait vmcnt(0) after it (cdna_hip_programming.md, ".s-level traps" (c)).
 template <int ROWS>
 __device__ __forceinline__ void load_batch(const RowPair& r, int c0, int K, int lane, u32x4 (&buf)[BATCH]) {
   constexpr int U = BATCH / ROWS;
@@ -113,18 +112,23 @@ __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int 
   return fits;
 }
 
+template <int NX, int NW, int AFTER>
+__device__ __forceinline__ void x_wait(XRegs<NX, NW>& xr) {
+  if constexpr (NX == 8) vm_wait8<AFTER>(xr.x);
+  if constexpr (NX == 4) vm_wait4<AFTER>(xr.x);
+  if constexpr (NW == 4) vm_wait4<AFTER>(xr.w);
+}
+
+// Exactly two weight batches (2 * BATCH loads) are issued between x_issue and x_finish.
 template <int TT, int NX, int NW>
-__device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red, const bf16_t* x, int ldx,
-                                         int T, int K, const bf16_t* norm_w, float eps) {
+__device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red,
+                                         const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w, float eps) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int npieces = K >> 3;
   float ss[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) ss[t] = 0.f;
-  // the NX + NW activation loads were issued before the two weight batches (2 * BATCH loads)
-  if constexpr (NX == 8) vm_wait8<2 * BATCH>(xr.x);
-  if constexpr (NX == 4) vm_wait4<2 * BATCH>(xr.x);
-  if constexpr (NW == 4) vm_wait4<2 * BATCH>(xr.w);
+  x_wait<NX, NW, 2 * BATCH>(xr);  // both weight batches stay in flight under the prologue
   if (in_regs) {
     const int total = TT * npieces;
 #pragma unroll
@@ -281,7 +285,11 @@ __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_k
   int ul = u, jl = 0;
   RowPair rpl = unit_rows<MODE, ROWS>(a, min(ul, units - 1), e1, e3);
   u32x4 bufA[BATCH], bufB[BATCH];
-  const RowPair dummy = {x, x};  // past the last unit: BATCH loads of one L2-resident line keep the counts static
+  // Past the wave's last unit `issue` loads BATCH times one L2-resident line instead, so that every wait below can
+  // use the static count "the other buffer's BATCH loads may stay in flight" (branching between counted and draining
+  // waits makes hipcc spill the buffers).  Those trailing loads are never consumed; that is safe because bufA/bufB
+  // are loop-carried (their registers are not reused inside the loop) and nothing executes after the loop.
+  const RowPair dummy = {x, x};
   auto issue = [&](u32x4 (&buf)[BATCH]) {
     if (ul < units) {
       load_batch<ROWS>(rpl, jl * U, a.K, lane, buf);
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
         }
       }
     } else {
-      const RowPair dummy = {a.x, a.x};
+      const RowPair dummy = {a.x, a.x};  // see gemv_kernel: keeps the wait counts static
       load_batch<2>(dummy, 0, 8, 0, buf);
     }
   };
@@ -534,7 +542,12 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   }
   const bool pair_mode = !(a.mode == GEMV_SWIGLU || a.mode == GEMV_MOE_W13);
   // single-row units when row pairs would leave CUs without a full set of waves (256 CUs x 4 blocks x 4 waves)
-  const bool single = pair_mode && a.mode != GEMV_QKV_ROPE && a.mode != GEMV_MOE_W2 && (a.N + 1) / 2 < 4096;
+  static int single_below = -1;  // MI_GEMV_SINGLE_BELOW: row-pair count under which units become single rows
+  if (single_below < 0) {
+    const char* e = getenv("MI_GEMV_SINGLE_BELOW");
+    single_below = e ? atoi(e) : 4096;
+  }
+  const bool single = pair_mode && a.mode != GEMV_QKV_ROPE && a.mode != GEMV_MOE_W2 && (a.N + 1) / 2 < single_below;
   const int units = pair_mode ? (single ? a.N : (a.N + 1) / 2) : a.N;
   int blocks = (units + 3) / 4;
   if (blocks > g_gemv_max_blocks) blocks = g_gemv_max_blocks;
