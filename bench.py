@@ -13,6 +13,7 @@ with the ring full (4096 keys per layer).  Inputs (weights, K/V rings, token ids
 Prints ONE JSON line on rank 0 (see README/DESIGN.md section 6 for the roofline / cpu_baseline definitions).
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -171,6 +172,7 @@ def main() -> None:
     ap.add_argument("--prefill", type=int, default=4096, help="prompt tokens (BASELINE configs[1]: 4096)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers => NOT the named config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue decode steps launch by launch (no hipGraph replay)")
     opt = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,7 +193,7 @@ def main() -> None:
     from mistral_inference.cache import BufferCache
     a = model.args
     T0, K, Wm = opt.prefill, opt.steps, opt.warmup
-    cache = BufferCache(model.n_local_layers, 1, T0 + K + Wm + 8, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
+    cache = BufferCache(model.n_local_layers, 1, T0 + K + max(Wm, 2) + 8, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
                         dtype=torch.bfloat16)
     cache.reset()
     prompt = torch.randint(0, a.vocab_size, (T0,), generator=torch.Generator().manual_seed(0)).to(dev)
@@ -214,15 +216,18 @@ def main() -> None:
         prefill_s = time.perf_counter() - t0
         nxt = torch.argmax(logits[-1:], dim=-1)
         del logits
-        # ---- decode
-        for _ in range(Wm):
-            nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
-        sync()
-        dt = time.perf_counter() - t0
+        # ---- decode: the generate() loop body - forward(next_token, [1], cache) under the decode hipGraph context
+        # (capture happens inside the warm-up steps; W >= 2 keeps it out of the timed region)
+        ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
+        with ctx:
+            for _ in range(max(Wm, 2)):
+                nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+            sync()
+            dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt, prefill_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -232,8 +237,8 @@ def main() -> None:
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    ctx = T0 + Wm + K // 2
-    step_bytes = decode_bytes_per_token(params, ctx)
+    ctx_len = T0 + Wm + K // 2
+    step_bytes = decode_bytes_per_token(params, ctx_len)
     ms = dt / K * 1e3
     step_gbs = step_bytes / (dt / K) / 1e9
     out = {
@@ -242,7 +247,8 @@ def main() -> None:
         "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Mistral-7B-v0.3 dims, {params['n_layers']} layers, random-init bf16, "
                                f"{T0}-token prefill then batch-1 greedy decode, sliding_window=4096",
-                   "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx,
+                   "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
+                   "decode_launch": "eager" if opt.no_graph else "hipGraph replay",
                    "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
         "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                               "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},

@@ -318,10 +318,12 @@ size_t attn_decode_partial_floats(int B, int H, int Hkv, int Dh, int W) {
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
   if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
   const int R = a.H / a.Hkv;
-  static int two_pass = -1;  // MI_ATTN_TWO_PASS=1: partials + separate combine launch instead of the in-kernel ticket
+  // Default: partials + a separate combine launch (measured faster than the in-kernel arrival ticket, whose
+  // release -> atomic -> acquire chain costs more than one kernel boundary); MI_ATTN_TWO_PASS=0 selects the ticket.
+  static int two_pass = -1;
   if (two_pass < 0) {
     const char* e = getenv("MI_ATTN_TWO_PASS");
-    two_pass = e ? atoi(e) : 0;
+    two_pass = e ? atoi(e) : 1;
   }
   switch (R) {
     case 1: launch_r<1>(a, two_pass, s); break;

@@ -545,7 +545,7 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   static int single_below = -1;  // MI_GEMV_SINGLE_BELOW: row-pair count under which units become single rows
   if (single_below < 0) {
     const char* e = getenv("MI_GEMV_SINGLE_BELOW");
-    single_below = e ? atoi(e) : 4096;
+    single_below = e ? atoi(e) : 0;  // measured: row pairs are at least as fast on MI355X
   }
   const bool single = pair_mode && a.mode != GEMV_QKV_ROPE && a.mode != GEMV_MOE_W2 && (a.N + 1) / 2 < single_below;
   const int units = pair_mode ? (single ? a.N : (a.N + 1) / 2) : a.N;

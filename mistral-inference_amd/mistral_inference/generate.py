@@ -11,6 +11,7 @@ the cache is allocated in HBM once per call, logprobs are gathered on the device
 the end, and a decode step is a single native call with no host metadata; the only per-token sync left
 is the EOS test, and only when `eos_id` is given.
 """
+import contextlib
 from typing import List, Optional, Tuple
 
 import torch
@@ -94,17 +95,21 @@ def generate(
     gen_lp: List[torch.Tensor] = []
     is_finished = torch.zeros(B, dtype=torch.bool, device=dev)
     assert last_token_prelogits is not None
-    for _ in range(max_tokens):
-        next_token = sample(last_token_prelogits, temperature=temperature, top_p=0.8)
-        if eos_id is not None:
-            is_finished = is_finished | (next_token == eos_id)
-            if bool(is_finished.all()):  # the one remaining per-token sync, only with an eos_id
-                break
-        lsm = torch.log_softmax(last_token_prelogits, dim=-1)
-        gen_lp.append(lsm.gather(1, next_token[:, None])[:, 0])
-        generated.append(next_token)
-        last_token_prelogits = model.forward(next_token, seqlens=[1] * B, cache=cache)
-        assert last_token_prelogits.shape == (B, V)
+    graphed = model.graphed_decode(cache) if hasattr(model, "graphed_decode") else contextlib.nullcontext()
+    with graphed:  # decode steps replay a captured hipGraph (single rank; no-op otherwise)
+        for _ in range(max_tokens):
+            next_token = sample(last_token_prelogits, temperature=temperature, top_p=0.8)
+            if eos_id is not None:
+                is_finished = is_finished | (next_token == eos_id)
+                if bool(is_finished.all()):  # the one remaining per-token sync, only with an eos_id
+                    break
+            lsm = torch.log_softmax(last_token_prelogits, dim=-1)
+            gen_lp.append(lsm.gather(1, next_token[:, None])[:, 0])
+            generated.append(next_token)
+            # under the graph the returned tensor is the graph's output buffer (overwritten by the next step);
+            # everything derived from it (next token, logprob) is computed before that happens
+            last_token_prelogits = model.forward(next_token, seqlens=[1] * B, cache=cache)
+            assert last_token_prelogits.shape == (B, V)
 
     # ---- one copy back
     logprobs: List[List[float]] = [[] for _ in range(B)]

@@ -14,6 +14,7 @@ activations to the next rank, logits broadcast from the last rank) through torch
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import json
 import logging
@@ -185,6 +186,7 @@ class Transformer(ModelBase):
             for i in range(first, last)})
         self.n_local_layers = len(self.layers)
         self._backend = backend if backend is not None else HipStackBackend()
+        self._graphed: Optional[dict] = None  # state of an active graphed_decode() context
 
     # ---- properties ----------------------------------------------------------------------------
     @property
@@ -254,11 +256,58 @@ class Transformer(ModelBase):
         h, _ = self._run(input_ids, seqlens, cache, want_logits=False)
         return h
 
+    # ---- decode step as a hipGraph ----------------------------------------------------------------
+    @contextlib.contextmanager
+    def graphed_decode(self, cache: BufferCache):
+        """Inside this context, decode-branch `forward()` calls on `cache` (every sequence adds exactly one token)
+        are replayed from a captured hipGraph instead of being enqueued launch by launch.
+
+        A decode step is ~165 dependent kernel launches and needs nothing from the host (positions and ring slots
+        are derived on the device from `cache.kv_seqlens`), so the whole step is captured once - on the second
+        decode call, after one eager warm-up step - and replayed afterwards; only the token ids are copied into the
+        graph's input buffer.  The returned logits tensor is the graph's output buffer: it is overwritten by the
+        next call, which is how `generate()` uses it (it reduces the logits to a token and a logprob immediately).
+        Single-rank only; with pipeline ranks the context is a no-op.
+        """
+        usable = (self.num_pipeline_ranks == 1 and self.device.type == "cuda" and isinstance(self._backend, HipStackBackend))
+        self._graphed = {"cache": cache, "graph": None, "warm": 0} if usable else None
+        try:
+            yield self
+        finally:
+            self._graphed = None
+
+    def _graphed_step(self, input_ids: torch.Tensor, seqlens: List[int], cache: BufferCache, st: dict) -> torch.Tensor:
+        if st["graph"] is None:
+            if st["warm"] < 1:  # eager step: sizes the workspace and the cache's device metadata before capture
+                st["warm"] += 1
+                _, logits = self._run(input_ids, seqlens, cache, want_logits=True)
+                return logits if self.softmax_fp32 else logits.to(self.dtype)
+            st["ids"] = input_ids.to(device=self.device, dtype=torch.long).clone()
+            st["B"] = len(seqlens)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            seen = list(cache._seen)
+            with torch.cuda.graph(graph):
+                _, logits = self._run(st["ids"], seqlens, cache, want_logits=True)
+                st["out"] = logits if self.softmax_fp32 else logits.to(self.dtype)
+            cache._seen = seen  # capture enqueues nothing: the step itself is the first replay below
+            st["graph"] = graph
+        else:
+            st["ids"].copy_(input_ids)
+        st["graph"].replay()
+        cache.advance_host(seqlens)
+        return st["out"]
+
     def forward(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache] = None,
                 images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """Logits [T, vocab] (reference transformer.py:221-242): fp32 unless softmax_fp32=False."""
         if images:
             raise NotImplementedError("images: the vision tower is outside the hot path")
+        st = self._graphed
+        if (st is not None and cache is st["cache"] and cache._seen is not None and cache._seen[0] > 0
+                and all(s == 1 for s in seqlens) and len(seqlens) == len(cache._seen)
+                and (st["graph"] is None or len(seqlens) == st["B"])):
+            return self._graphed_step(input_ids, seqlens, cache, st)
         h, logits = self._run(input_ids, seqlens, cache, want_logits=True)
         if self.num_pipeline_ranks > 1:
             # every rank receives the logits in the model dtype, as the reference does (transformer.py:229-237);
