@@ -243,45 +243,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   if (tid == 0) __hip_atomic_store(&a.tickets[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Second launch of the two-pass form: one block per (sequence, kv head) folds the per-split partials.
-template <int R>
-__global__ __launch_bounds__(256) void attn_decode_combine_kernel(AttnDecodeArgs a) {
-  __shared__ float sm_ms[64 * R];
-  __shared__ float sm_ls[64 * R];
-  const int tid = threadIdx.x, kvh = blockIdx.x, b = blockIdx.y;
+// Second launch of the two-pass form: one block per (sequence, q head), one thread per output element.  All of a
+// thread's loads (the head's (m, l) pairs - same address across the block, so one transaction each - and its own
+// accumulator column) are independent and issued together: one memory round trip instead of a chain.
+template <int NS>  // upper bound on n_splits held in registers
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs a) {
+  const int d = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const int R = a.H / a.Hkv, kvh = h / R, r = h % R;
   const int bh = b * a.Hkv + kvh;
-  const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH;
-  const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2;
-  for (int i = tid; i < a.n_splits * R; i += 256) {
-    const float2 ml = *reinterpret_cast<const float2*>(all_ml + 2 * i);
-    sm_ms[i] = ml.x;
-    sm_ls[i] = ml.y;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < R * DH; idx += 256) {
-    const int r = idx / DH, d = idx % DH;
-    float M = -1e30f;
-    for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, sm_ms[sp * R + r]);
-    float L = 0.f, A = 0.f;
-    int sp = 0;
-    for (; sp + 8 <= a.n_splits; sp += 8) {
-      float v[8];
+  const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH + (size_t)r * DH + d;
+  const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2 + r * 2;
+  float m[NS], l[NS], v[NS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = all_acc[(size_t)(sp + j) * R * DH + idx];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float e = exp2f(sm_ms[(sp + j) * R + r] - M);
-        L += sm_ls[(sp + j) * R + r] * e;
-        A += v[j] * e;
-      }
-    }
-    for (; sp < a.n_splits; ++sp) {
-      const float e = exp2f(sm_ms[sp * R + r] - M);
-      L += sm_ls[sp * R + r] * e;
-      A += all_acc[(size_t)sp * R * DH + idx] * e;
-    }
-    reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)(kvh * R + r) * DH + d] = f_to_bf(A / L);
+  for (int sp = 0; sp < NS; ++sp) {
+    const int s2 = min(sp, a.n_splits - 1);  // clamped, never a conditional load
+    const float2 ml = *reinterpret_cast<const float2*>(all_ml + (size_t)s2 * R * 2);
+    m[sp] = (sp < a.n_splits) ? ml.x : -1e30f;
+    l[sp] = (sp < a.n_splits) ? ml.y : 0.f;
+    v[sp] = all_acc[(size_t)s2 * R * DH];
   }
+  float M = -1e30f;
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) M = fmaxf(M, m[sp]);
+  float L = 0.f, A = 0.f;
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) {
+    const float e = exp2f(m[sp] - M);
+    L += l[sp] * e;
+    A += ((sp < a.n_splits) ? v[sp] : 0.f) * e;
+  }
+  reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)h * DH + d] = f_to_bf(A / L);
 }
 
 template <int R>
@@ -289,7 +280,9 @@ void launch_r(const AttnDecodeArgs& a, bool two_pass, hipStream_t s) {
   dim3 grid(a.n_splits, a.Hkv, a.B), block(256);
   if (two_pass) {
     hipLaunchKernelGGL((attn_decode_kernel<R, true>), grid, block, 0, s, a);
-    hipLaunchKernelGGL((attn_decode_combine_kernel<R>), dim3(a.Hkv, a.B), block, 0, s, a);
+    if (a.n_splits <= 16) hipLaunchKernelGGL((attn_decode_combine_kernel<16>), dim3(a.H, a.B), dim3(128), 0, s, a);
+    else if (a.n_splits <= 32) hipLaunchKernelGGL((attn_decode_combine_kernel<32>), dim3(a.H, a.B), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(a.H, a.B), dim3(128), 0, s, a);
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<R, false>), grid, block, 0, s, a);
   }

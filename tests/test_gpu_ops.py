@@ -94,9 +94,12 @@ def test_linear_residual_swiglu_logits(M):
     w1, w3 = rnd(N, K, seed=13, scale=0.06), rnd(N, K, seed=14, scale=0.06)
     res = rnd(M, N, seed=15)
     # residual
-    ref = (res + F.linear(x, w1)).float()
+    y = F.linear(x, w1)
+    ref = (res + y).float()
     got = h.linear(x.cuda(), (w1.cuda(),), h.EPI_RESIDUAL, residual=res.cuda()).cpu()
-    assert bf16_ulp_close(got, ref, ulps=1.5)[0]
+    # bf16(W x) may be 1 ulp off (fp32 summation order); after the add that ulp is relative to |W x|, not to the sum
+    scale = torch.maximum(torch.maximum(res.float().abs(), y.float().abs()), ref.abs())
+    assert bool(((got.float() - ref).abs() <= 1.5 * scale * 2.0 ** -7 + 1e-6).all())
     # swiglu with the reference's rounding chain
     ref = (F.silu(F.linear(x, w1)) * F.linear(x, w3)).float()
     got = h.linear(x.cuda(), (w1.cuda(), w3.cuda()), h.EPI_SWIGLU).cpu()
