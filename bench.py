@@ -107,9 +107,19 @@ def dominant_kernel_roofline(model, iters: int) -> dict:
     us = e0.elapsed_time(e1) * 1e3 / n
     bytes_per_launch = 2 * a.hidden_dim * a.dim * 2 + 2 * a.dim * 2 + a.hidden_dim * 2
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
+    # HBM bytes per launch from the PMC counters: collected in a separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
+    # WRITE_SIZE` pass (scripts/gpu_round.sh), corrected as MI355X_MICROARCH.md prescribes for gfx950
+    # (2 x FETCH_SIZE), committed under profiles/.  Only valid for the named model dimensions.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+    if os.path.exists(pmc) and (a.dim, a.hidden_dim) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"]):
+        with open(pmc) as f:
+            rec = json.load(f)
+        traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
     return {"bound": "hbm", "kernel": "gemv_kernel<1,SWIGLU> (RMSNorm + W1|W3 GEMV + SiLU*mul)", "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2), "launches_timed": n}
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
+            "launches_timed": n}
 
 
 def cpu_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
