@@ -29,6 +29,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 MISTRAL_7B = dict(dim=4096, n_layers=32, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
                   vocab_size=32768, rope_theta=1e6, sliding_window=4096)
+# The other BASELINE.json configs.  They are parity / evidence runs, not the headline line:
+# `python bench.py --model nemo-12b --prefill 8192`, `--model mixtral-8x7b` (93 GB of random-init weights, fits one GPU).
+PRESETS = {
+    "mistral-7b": (MISTRAL_7B, "Mistral-7B-v0.3"),
+    "nemo-12b": (dict(dim=5120, n_layers=40, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                      vocab_size=131072, rope_theta=1e6), "Mistral-Nemo-12B"),
+    "mixtral-8x7b": (dict(dim=4096, n_layers=32, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                          vocab_size=32000, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2)),
+                     "Mixtral-8x7B"),
+}
 
 
 def init_weights_(model, seed: int) -> None:
@@ -64,7 +74,9 @@ def build_model(params: dict, rank: int, world: int, device: str):
 def decode_bytes_per_token(p: dict, ctx: int) -> int:
     """weights read once + K/V window read once (bf16)."""
     D, L, H, Hkv, Dh, F, V = p["dim"], p["n_layers"], p["n_heads"], p["n_kv_heads"], p["head_dim"], p["hidden_dim"], p["vocab_size"]
-    per_layer = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + 2 * D + 3 * D * F
+    moe = p.get("moe")
+    ffn = (moe["num_experts_per_tok"] * 3 * D * F + moe["num_experts"] * D) if moe else 3 * D * F
+    per_layer = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + 2 * D + ffn
     w = 2 * (L * per_layer + V * D + D)
     W = p.get("sliding_window") or ctx
     kv = L * 2 * min(ctx, W) * Hkv * Dh * 2
@@ -73,7 +85,8 @@ def decode_bytes_per_token(p: dict, ctx: int) -> int:
 
 def prefill_flops(p: dict, T: int) -> float:
     D, L, H, Hkv, Dh, F, V = p["dim"], p["n_layers"], p["n_heads"], p["n_kv_heads"], p["head_dim"], p["hidden_dim"], p["vocab_size"]
-    lin = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + 3 * D * F
+    moe = p.get("moe")
+    lin = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + (moe["num_experts_per_tok"] if moe else 1) * 3 * D * F
     W = p.get("sliding_window") or T
     pairs = sum(min(i + 1, W) for i in range(T))
     return 2.0 * T * (L * lin + V * D) + L * 4.0 * H * Dh * pairs
@@ -181,6 +194,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prefill", type=int, default=4096, help="prompt tokens (BASELINE configs[1]: 4096)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers => NOT the named config")
+    ap.add_argument("--model", default="mistral-7b", choices=sorted(PRESETS), help="default = BASELINE configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue decode steps launch by launch (no hipGraph replay)")
     opt = ap.parse_args()
@@ -195,7 +209,8 @@ def main() -> None:
     if world > 1:
         torch.distributed.init_process_group("nccl")  # RCCL
 
-    params = dict(MISTRAL_7B)
+    params, model_name = PRESETS[opt.model]
+    params = dict(params)
     if opt.layers:
         params["n_layers"] = opt.layers
     model = build_model(params, rank, world, dev)
@@ -255,8 +270,8 @@ def main() -> None:
         "metric": "decode tokens/sec/GPU (batch=1, seq=1)", "value": round(K / dt, 2), "unit": "tokens/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Mistral-7B-v0.3 dims, {params['n_layers']} layers, random-init bf16, "
-                               f"{T0}-token prefill then batch-1 greedy decode, sliding_window=4096",
+        "config": {"workload": f"{model_name} dims, {params['n_layers']} layers, random-init bf16, "
+                               f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
                    "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
                    "decode_launch": "eager" if opt.no_graph else "hipGraph replay",
                    "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
@@ -266,7 +281,7 @@ def main() -> None:
                     "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
                     "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
     }
-    if world == 1:
+    if world == 1 and not params.get("moe"):
         out["roofline"] = dominant_kernel_roofline(model, iters=4)
         if not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, T0)

@@ -88,22 +88,30 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
   const int k_slot = tid & 15, k_key0 = tid >> 4;   // K: keys k_key0 + 16 j, 16-byte slot k_slot
   const int v_kq = tid & 15, v_ds = tid >> 4;       // V: keys 4 v_kq + j, d slice v_ds*8..+8
   u32x4 rk[4], rv[4];
+  // Source row of key position kp: ring slot (kp % W) for keys older than this forward, activation row otherwise.
+  // Both candidate addresses are formed and SELECTED (v_cndmask), and the load itself is unconditional from a
+  // clamped position: a `cond ? load : 0` makes hipcc branch around every load and wait vmcnt(0) after each one
+  // (cdna_hip_programming.md ".s-level traps" (c)), which serialised this staging to one load in flight.
+  // Keys past kp_hi are masked in the softmax (their P is exactly 0), so the clamped duplicates are harmless.
+  const bf16_t* ring_k0 = a.cache_k ? a.cache_k + ((size_t)b * W) * kv_dim + (size_t)kvh * DH : a.qkv;
+  const bf16_t* ring_v0 = a.cache_v ? a.cache_v + ((size_t)b * W) * kv_dim + (size_t)kvh * DH : a.qkv;
+  const bf16_t* act_k0 = a.qkv + nq_cols + (size_t)kvh * DH;
+  const bf16_t* act_v0 = act_k0 + kv_dim;
   auto key_ptr = [&](int kp, bool is_v) -> const bf16_t* {
-    if (kp < p_b) {
-      const bf16_t* ring = is_v ? a.cache_v : a.cache_k;
-      return ring + ((size_t)b * W + (kp % W)) * kv_dim + (size_t)kvh * DH;
-    }
-    return a.qkv + (size_t)(row0 + kp - p_b) * a.ld + nq_cols + (is_v ? kv_dim : 0) + (size_t)kvh * DH;
+    const int slot = (kp < p_b) ? (kp % W) : 0;                  // only cached keys live in the ring
+    const int arow = (kp < p_b) ? 0 : (row0 + kp - p_b);
+    const bf16_t* r = (is_v ? ring_v0 : ring_k0) + (size_t)slot * kv_dim;
+    const bf16_t* x = (is_v ? act_v0 : act_k0) + (size_t)arow * a.ld;
+    return (kp < p_b) ? r : x;
   };
   auto gload = [&](int it) {
     const int t_lo = kp_lo + it * KT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      const int kpk = t_lo + k_key0 + 16 * j;
-      rk[j] = (kpk <= kp_hi) ? ld16(key_ptr(kpk, false) + k_slot * 8) : z;
-      const int kpv = t_lo + v_kq * 4 + j;
-      rv[j] = (kpv <= kp_hi) ? ld16(key_ptr(kpv, true) + v_ds * 8) : z;
+      const int kpk = min(t_lo + k_key0 + 16 * j, kp_hi);
+      rk[j] = ld16(key_ptr(kpk, false) + k_slot * 8);
+      const int kpv = min(t_lo + v_kq * 4 + j, kp_hi);
+      rv[j] = ld16(key_ptr(kpv, true) + v_ds * 8);
     }
   };
   auto lstore = [&]() {
