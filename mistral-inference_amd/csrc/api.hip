@@ -51,13 +51,14 @@ struct Workspace {
   bf16_t* attn;     // [T, H Dh]
   bf16_t* hid;      // [T * max(1, top_k), F]
   float* partial;   // decode attention partials
-  int32_t* sel_idx; // MoE
+  int32_t* sel_idx; // MoE: router picks [T, top_k]
   float* sel_w;
-  int32_t* counts;
-  int32_t* offsets;
-  int32_t* tok_of;
-  float* w_of;
-  bf16_t* moe_res;  // [T, D]
+  int32_t* tok_of;   // token of compact row r            [T * top_k]
+  int32_t* row_of;   // compact row of (token, slot)      [T * top_k]
+  int32_t* tile_tab; // grouped-GEMM m-tile table         [max_tiles][4]
+  int32_t* n_tiles;
+  bf16_t* moe_y;     // expert outputs, compact rows      [T * top_k, D]
+  int max_tiles;
   size_t total;
 };
 
@@ -79,11 +80,12 @@ Workspace carve(const mi_model_t* m, int T, int B, int maxW, char* base) {
   w.partial = (float*)take(attn_decode_partial_floats(B, m->n_heads, m->n_kv_heads, m->head_dim, maxW) * sizeof(float));
   w.sel_idx = (int32_t*)take((size_t)T * slots * 4);
   w.sel_w = (float*)take((size_t)T * slots * 4);
-  w.counts = (int32_t*)take(64 * 4);
-  w.offsets = (int32_t*)take(64 * 4);
+  w.max_tiles = (T * slots + 127) / 128 + (m->num_experts > 0 ? m->num_experts : 0);
   w.tok_of = (int32_t*)take((size_t)T * slots * 4);
-  w.w_of = (float*)take((size_t)T * slots * 4);
-  w.moe_res = (bf16_t*)take(m->num_experts > 0 ? (size_t)T * m->dim * 2 : 0);
+  w.row_of = (int32_t*)take((size_t)T * slots * 4);
+  w.tile_tab = (int32_t*)take((size_t)w.max_tiles * 16);
+  w.n_tiles = (int32_t*)take(256);
+  w.moe_y = (bf16_t*)take(m->num_experts > 0 ? (size_t)T * slots * m->dim * 2 : 0);
   w.total = off;
   return w;
 }
@@ -376,23 +378,22 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       } else {
         MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
         MI_TRY(hip_rc(launch_moe_router(ws.sel_idx, ws.sel_w, ws.xn, D, T, D, L.gate, E, k, nullptr, 0.f, s), "moe_router"));
-        MI_TRY(hip_rc(launch_moe_lists(ws.sel_idx, ws.sel_w, T, E, k, ws.counts, ws.offsets, ws.tok_of, ws.w_of, s), "moe_lists"));
-        MI_TRY(hip_rc(hipMemsetAsync(ws.moe_res, 0, (size_t)T * D * 2, s), "moe memset"));
-        for (int e = 0; e < E; ++e) {  // ascending expert id = the reference's accumulation order (moe.py:29)
-          GemmArgs g;
-          memset(&g, 0, sizeof(g));
-          g.epi = GEMM_SWIGLU; g.M = T; g.N = F; g.K = D; g.a = ws.xn; g.lda = D;
-          g.w0 = (const bf16_t*)L.expert_w_host[e * 3 + 0]; g.w1 = (const bf16_t*)L.expert_w_host[e * 3 + 2];
-          g.n0 = g.n1 = F; g.out = ws.hid; g.ldo = F;
-          g.m_count = ws.counts + e; g.row_base = ws.offsets + e; g.a_gather = ws.tok_of;
-          MI_TRY(hip_rc(launch_gemm(g, s), "moe w13 gemm"));
-          memset(&g, 0, sizeof(g));
-          g.epi = GEMM_MOE_ACCUM; g.M = T; g.N = D; g.K = F; g.a = ws.hid; g.lda = F;
-          g.w0 = (const bf16_t*)L.expert_w_host[e * 3 + 1]; g.n0 = g.n1 = D; g.out = ws.moe_res; g.ldo = D;
-          g.m_count = ws.counts + e; g.row_base = ws.offsets + e; g.out_scatter = ws.tok_of; g.row_scale = ws.w_of;
-          MI_TRY(hip_rc(launch_gemm(g, s), "moe w2 gemm"));
-        }
-        MI_TRY(hip_rc(launch_add_rows(h, h, ws.moe_res, (size_t)T * D, s), "moe residual"));
+        MI_TRY(hip_rc(launch_moe_lists(ws.sel_idx, T, E, k, ws.tok_of, ws.row_of, ws.tile_tab, ws.n_tiles, s), "moe_lists"));
+        // one token-grouped launch per projection covers all experts (tile table built on the device: no host sync)
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.epi = GEMM_SWIGLU; g.M = T * k; g.N = F; g.K = D; g.a = ws.xn; g.lda = D; g.n0 = g.n1 = F;
+        g.out = ws.hid; g.ldo = F;
+        g.tile_tab = ws.tile_tab; g.n_tiles_ptr = ws.n_tiles; g.max_m_tiles = ws.max_tiles;
+        g.expert_tab = L.expert_w_dev; g.w_sel0 = 0; g.w_sel1 = 2; g.a_gather = ws.tok_of;
+        MI_TRY(hip_rc(launch_gemm(g, s), "moe w13 grouped gemm"));
+        memset(&g, 0, sizeof(g));
+        g.epi = GEMM_STORE; g.M = T * k; g.N = D; g.K = F; g.a = ws.hid; g.lda = F; g.n0 = g.n1 = D;
+        g.out = ws.moe_y; g.ldo = D;
+        g.tile_tab = ws.tile_tab; g.n_tiles_ptr = ws.n_tiles; g.max_m_tiles = ws.max_tiles;
+        g.expert_tab = L.expert_w_dev; g.w_sel0 = 1; g.w_sel1 = -1;
+        MI_TRY(hip_rc(launch_gemm(g, s), "moe w2 grouped gemm"));
+        MI_TRY(hip_rc(launch_moe_combine(h, h, ws.moe_y, ws.sel_idx, ws.sel_w, ws.row_of, T, D, k, s), "moe combine"));
       }
     }
   }

@@ -213,40 +213,80 @@ __global__ __launch_bounds__(64) void moe_router_kernel(int32_t* sel_idx, float*
   }
 }
 
-// Per-expert token lists for grouped prefill GEMMs: entries are ordered by token within an expert,
-// so every launch is deterministic.  Single block; T*top_k is at most a few tens of thousands.
-__global__ __launch_bounds__(256) void moe_lists_kernel(const int32_t* sel_idx, const float* sel_w, int T, int E,
-                                                        int top_k, int32_t* counts, int32_t* offsets, int32_t* tok_of,
-                                                        float* w_of) {
+// Sort the T*top_k (token, slot) pairs by expert for the token-grouped prefill GEMMs (moe.py:29-31 `torch.where` per
+// expert, which costs the reference one host sync per expert per layer).  Single block: LDS histogram, exclusive
+// scan, LDS-cursor scatter.  Row order inside an expert is arbitrary (it only decides which MFMA tile a row lands
+// in, never its value); the bf16 accumulation ORDER of moe.py is reproduced later by moe_combine_kernel.
+__global__ __launch_bounds__(1024) void moe_lists_kernel(const int32_t* sel_idx, int T, int E, int top_k, int32_t* tok_of,
+                                                         int32_t* row_of, int32_t* tile_tab, int32_t* n_tiles) {
   __shared__ int cnt[MOE_MAX_E];
   __shared__ int off[MOE_MAX_E + 1];
-  const int tid = threadIdx.x;
-  // one wave per expert group would be faster; one thread per expert walking the tokens keeps order trivially
-  if (tid < E) {
-    int c = 0;
-    for (int i = 0; i < T * top_k; ++i) c += (sel_idx[i] == tid);
-    cnt[tid] = c;
-  }
+  __shared__ int cur[MOE_MAX_E];
+  const int tid = threadIdx.x, n = T * top_k;
+  if (tid < MOE_MAX_E) cnt[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&cnt[sel_idx[i]], 1);
   __syncthreads();
   if (tid == 0) {
-    int o = 0;
+    int o = 0, nt = 0;
     for (int e = 0; e < E; ++e) {
       off[e] = o;
+      cur[e] = o;
+      for (int r = 0; r < cnt[e]; r += 128) {  // m-tiles of this expert
+        tile_tab[nt * 4 + 0] = e;
+        tile_tab[nt * 4 + 1] = o + r;
+        tile_tab[nt * 4 + 2] = min(128, cnt[e] - r);
+        tile_tab[nt * 4 + 3] = 0;
+        ++nt;
+      }
       o += cnt[e];
     }
     off[E] = o;
+    *n_tiles = nt;
   }
   __syncthreads();
-  if (tid < E) {
-    counts[tid] = cnt[tid];
-    offsets[tid] = off[tid];
-    int o = off[tid];
-    for (int i = 0; i < T * top_k; ++i)
-      if (sel_idx[i] == tid) {
-        tok_of[o] = i / top_k;
-        w_of[o] = sel_w[i];
-        ++o;
+  for (int i = tid; i < n; i += 1024) {
+    const int r = atomicAdd(&cur[sel_idx[i]], 1);
+    tok_of[r] = i / top_k;
+    row_of[i] = r;
+  }
+}
+
+// moe.py:28-32 accumulation + transformer_layers.py:168: per token, experts in ascending id, bf16 running sum from 0.
+__global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* out, const bf16_t* h, const bf16_t* y, const int32_t* sel_idx,
+                                                          const float* sel_w, const int32_t* row_of, int D, int top_k) {
+  const int t = blockIdx.x;
+  int eid[4], row[4];
+  float w[4];
+  for (int k = 0; k < top_k; ++k) {
+    eid[k] = sel_idx[t * top_k + k];
+    row[k] = row_of[t * top_k + k];
+    w[k] = sel_w[t * top_k + k];
+  }
+  for (int i = 0; i < top_k; ++i)
+    for (int j = i + 1; j < top_k; ++j)
+      if (eid[j] < eid[i]) {
+        int te = eid[i]; eid[i] = eid[j]; eid[j] = te;
+        te = row[i]; row[i] = row[j]; row[j] = te;
+        const float tw = w[i]; w[i] = w[j]; w[j] = tw;
       }
+  for (int p = threadIdx.x; p < (D >> 3); p += 256) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = 0.f;
+    for (int k = 0; k < top_k; ++k) {
+      const u32x4 v = ld16(y + (size_t)row[k] * D + p * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        r[2 * i] = bf_round(r[2 * i] + bf_round(w[k] * bf_lo(v[i])));
+        r[2 * i + 1] = bf_round(r[2 * i + 1] + bf_round(w[k] * bf_hi(v[i])));
+      }
+    }
+    const u32x4 hv = ld16(h + (size_t)t * D + p * 8);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf2(bf_lo(hv[i]) + r[2 * i], bf_hi(hv[i]) + r[2 * i + 1]);
+    st16(out + (size_t)t * D + p * 8, o);
   }
 }
 
@@ -296,9 +336,14 @@ hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int 
                      (const bf16_t*)gate, E, top_k, (const bf16_t*)norm_w, eps);
   return hipGetLastError();
 }
-hipError_t launch_moe_lists(const int32_t* sel_idx, const float* sel_w, int T, int E, int top_k, int32_t* counts,
-                            int32_t* offsets, int32_t* tok_of, float* w_of, hipStream_t s) {
-  hipLaunchKernelGGL(moe_lists_kernel, dim3(1), dim3(256), 0, s, sel_idx, sel_w, T, E, top_k, counts, offsets, tok_of,
-                     w_of);
+hipError_t launch_moe_lists(const int32_t* sel_idx, int T, int E, int top_k, int32_t* tok_of, int32_t* row_of,
+                            int32_t* tile_tab, int32_t* n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(moe_lists_kernel, dim3(1), dim3(1024), 0, s, sel_idx, T, E, top_k, tok_of, row_of, tile_tab, n_tiles);
+  return hipGetLastError();
+}
+hipError_t launch_moe_combine(void* out, const void* h, const void* y, const int32_t* sel_idx, const float* sel_w,
+                              const int32_t* row_of, int T, int D, int top_k, hipStream_t s) {
+  hipLaunchKernelGGL(moe_combine_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)h, (const bf16_t*)y,
+                     sel_idx, sel_w, row_of, D, top_k);
   return hipGetLastError();
 }

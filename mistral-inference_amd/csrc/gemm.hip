@@ -2,7 +2,7 @@
 //
 // Replaces the reference's nn.Linear GEMMs at prefill (transformer_layers.py:66,93,105-106;
 // transformer.py:235) with the residual add / SiLU*mul / bf16->fp32 widening fused into the epilogue,
-// and (grouped form) moe.py:28-32's per-expert gather -> FFN -> weighted scatter-add.
+// and (token-grouped form, one launch for all experts) moe.py:28-32's per-expert gather -> expert FFN.
 //
 // Both operands are K-contiguous ("B^T input"), so A and W fragments are 16-byte row slices.
 // 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.  Operands are
@@ -36,12 +36,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int M = g.m_count ? *g.m_count : g.M;
-  const int base = g.row_base ? *g.row_base : 0;
-  const int m_tiles = (g.M + BM - 1) / BM;
-  const int m_tile = blockIdx.x % m_tiles, n_tile = blockIdx.x / m_tiles;
-  if (m_tile * BM >= M) return;
   constexpr int NOUT = (EPI == GEMM_SWIGLU) ? 64 : 128;  // output columns per block
+
+  // ---- block -> (m_tile, n_tile).  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, dispatch); every XCD has
+  // its own 4 MiB L2.  Blocks are grouped in 8 x 8 supertiles (64 = the blocks one XCD runs at a time) and a
+  // supertile stays on ONE XCD, so the blocks running together there share 8 A panels and 8 W panels K-slice by
+  // K-slice instead of fetching 64 + 64 (guide T1; a pure speed choice, results do not depend on it).
+  const int grouped = g.tile_tab != nullptr;
+  const int m_tiles = grouped ? g.max_m_tiles : (g.M + BM - 1) / BM;
+  const int n_tiles = (g.N + NOUT - 1) / NOUT;
+  const int MS = (m_tiles + 7) >> 3, NS = (n_tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int st = (q >> 6) * 8 + xcd, wi = q & 63;
+  if (st >= MS * NS) return;
+  const int m_tile = (st % MS) * 8 + (wi & 7), n_tile = (st / MS) * 8 + (wi >> 3);
+  if (m_tile >= m_tiles || n_tile >= n_tiles) return;
+
+  // rows of this m-tile: plain = [m_tile*128, +128) of [0, M); grouped = one tile of one expert
+  int row0, rows_valid;
+  const bf16_t *w0 = g.w0, *w1 = g.w1;
+  if (grouped) {
+    if (m_tile >= *g.n_tiles_ptr) return;
+    const int e = g.tile_tab[m_tile * 4];
+    row0 = g.tile_tab[m_tile * 4 + 1];
+    rows_valid = g.tile_tab[m_tile * 4 + 2];
+    w0 = reinterpret_cast<const bf16_t*>(g.expert_tab[e * 3 + g.w_sel0]);
+    if (g.w_sel1 >= 0) w1 = reinterpret_cast<const bf16_t*>(g.expert_tab[e * 3 + g.w_sel1]);
+  } else {
+    row0 = m_tile * BM;
+    rows_valid = min(BM, g.M - row0);
+  }
 
   // ---- global -> LDS staging assignment: thread owns 16-byte slot (tid & 7) of rows (tid >> 3) + 32 j
   const int slot = tid & 7;
@@ -50,14 +74,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = (tid >> 3) + 32 * j;
-    int m = base + min(m_tile * BM + r, M - 1);
+    int m = row0 + min(r, rows_valid - 1);
     if (g.a_gather) m = g.a_gather[m];
     arow[j] = g.a + (size_t)m * g.lda + slot * 8;
     if (EPI == GEMM_SWIGLU) {
       const int jj = min(n_tile * 64 + (r & 63), g.N - 1);
-      brow[j] = ((r < 64) ? g.w0 : g.w1) + (size_t)jj * g.K + slot * 8;
+      brow[j] = ((r < 64) ? w0 : w1) + (size_t)jj * g.K + slot * 8;
     } else {
-      brow[j] = seg_row(g, min(n_tile * BN + r, g.N - 1)) + slot * 8;
+      const int n = min(n_tile * BN + r, g.N - 1);
+      brow[j] = (grouped ? w0 + (size_t)n * g.K : seg_row(g, n)) + slot * 8;
     }
   }
   u32x4 ra[4], rb[4];
@@ -121,27 +146,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[mt][nt][r] is row wm*64 + mt*16 + (lane>>4)*4 + r, column (lane & 15) of its tile
+  // ---- epilogue.  acc[mt][nt][r] is tile row wm*64 + mt*16 + (lane>>4)*4 + r, column (lane & 15) of its 16x16 tile
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m_tile * BM + wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
-      if (m >= M) continue;
+      const int rl = wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
+      if (rl >= rows_valid) continue;
+      const size_t orow = (size_t)(row0 + rl);
       if (EPI == GEMM_SWIGLU) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int j = n_tile * NOUT + wn * 32 + s * 16 + (lane & 15);
           if (j < g.N)
-            reinterpret_cast<bf16_t*>(g.out)[(size_t)(base + m) * g.ldo + j] = f_to_bf(swiglu_bf(acc[mt][s][r], acc[mt][2 + s][r]));
+            reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + j] = f_to_bf(swiglu_bf(acc[mt][s][r], acc[mt][2 + s][r]));
         }
       } else {
-        size_t orow = (size_t)(base + m);
-        float scale = 1.f;
-        if (EPI == GEMM_MOE_ACCUM) {
-          scale = g.row_scale[base + m];
-          orow = (size_t)g.out_scatter[base + m];
-        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int n = n_tile * BN + wn * 64 + nt * 16 + (lane & 15);
@@ -151,9 +171,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             reinterpret_cast<float*>(g.out)[orow * g.ldo + n] = y;
           } else if (EPI == GEMM_RESIDUAL) {
             reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + n] = f_to_bf(bf_to_f(g.residual[orow * g.ldo + n]) + y);
-          } else if (EPI == GEMM_MOE_ACCUM) {
-            bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + orow * g.ldo + n;
-            *o = f_to_bf(bf_to_f(*o) + bf_round(scale * y));
           } else {
             reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + n] = f_to_bf(y);
           }
@@ -167,17 +184,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.K % 8 != 0 || g.M <= 0 || g.N <= 0) return hipErrorInvalidValue;
-  const int m_tiles = (g.M + BM - 1) / BM;
+  const int m_tiles = g.tile_tab ? g.max_m_tiles : (g.M + BM - 1) / BM;
   const int nout = (g.epi == GEMM_SWIGLU) ? 64 : 128;
   const int n_tiles = (g.N + nout - 1) / nout;
-  const dim3 grid((unsigned)(m_tiles * n_tiles)), block(256);
+  const int supertiles = ((m_tiles + 7) / 8) * ((n_tiles + 7) / 8);
+  const dim3 grid((unsigned)(((supertiles + 7) / 8) * 64 * 8)), block(256);
   const size_t lds = 4 * TILE_BYTES;
   switch (g.epi) {
     case GEMM_STORE: hipLaunchKernelGGL((gemm_kernel<GEMM_STORE>), grid, block, lds, s, g); break;
     case GEMM_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<GEMM_RESIDUAL>), grid, block, lds, s, g); break;
     case GEMM_SWIGLU: hipLaunchKernelGGL((gemm_kernel<GEMM_SWIGLU>), grid, block, lds, s, g); break;
     case GEMM_LOGITS: hipLaunchKernelGGL((gemm_kernel<GEMM_LOGITS>), grid, block, lds, s, g); break;
-    case GEMM_MOE_ACCUM: hipLaunchKernelGGL((gemm_kernel<GEMM_MOE_ACCUM>), grid, block, lds, s, g); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

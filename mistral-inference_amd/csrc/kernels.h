@@ -56,7 +56,7 @@ int gemv_max_tokens(int K);
 hipError_t launch_gemv(const GemvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- GEMM
-enum GemmEpi { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SWIGLU = 2, GEMM_LOGITS = 3, GEMM_MOE_ACCUM = 4 };
+enum GemmEpi { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SWIGLU = 2, GEMM_LOGITS = 3 };
 
 struct GemmArgs {
   int epi;
@@ -70,12 +70,14 @@ struct GemmArgs {
   void* out;
   int ldo;
   const bf16_t* residual;
-  // grouped form (MoE prefill): this launch handles compact rows [base, base + count) of an expert
-  const int32_t* m_count;     // device: actual row count (<= M) or nullptr
-  const int32_t* row_base;    // device: first compact row of this expert, or nullptr (0)
-  const int32_t* a_gather;    // device: A row = a_gather[base + m]   (nullptr: base + m)
-  const int32_t* out_scatter; // device: out row = out_scatter[base + m] (nullptr: base + m)
-  const float* row_scale;     // device: expert weight of compact row base + m (MOE_ACCUM)
+  // Token-grouped form (MoE prefill, moe.py:28-32): ONE launch covers every expert.  Compact rows are the (token,
+  // slot) pairs sorted by expert; tile i of `tile_tab` is {expert, first compact row, valid rows (<= 128), 0}.
+  const int32_t* tile_tab;        // device [max_m_tiles][4] or nullptr (plain GEMM)
+  const int32_t* n_tiles_ptr;     // device: number of valid entries in tile_tab
+  int max_m_tiles;                // host upper bound (grid sizing)
+  const void* const* expert_tab;  // device [E][3] (w1, w2, w3) pointers
+  int w_sel0, w_sel1;             // which of the three matrices feed w0 / w1 (w_sel1 < 0: unused)
+  const int32_t* a_gather;        // device: A row of compact row r is a[a_gather[r]] (nullptr: a[r])
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -123,6 +125,11 @@ hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hi
 // ---------------------------------------------------------------------------------------------- MoE
 hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate,
                              int E, int top_k, const void* norm_w, float eps, hipStream_t s);
-// builds per-expert token lists for the grouped prefill GEMMs
-hipError_t launch_moe_lists(const int32_t* sel_idx, const float* sel_w, int T, int E, int top_k, int32_t* counts,
-                            int32_t* offsets, int32_t* tok_of, float* w_of, hipStream_t s);
+// Sort the (token, slot) pairs by expert: tok_of[r] = token of compact row r, row_of[t*top_k + kk] = compact row of
+// that pair, tile_tab / n_tiles = the grouped GEMM's m-tile table (128 rows per tile, tiles never span experts).
+hipError_t launch_moe_lists(const int32_t* sel_idx, int T, int E, int top_k, int32_t* tok_of, int32_t* row_of,
+                            int32_t* tile_tab, int32_t* n_tiles, hipStream_t s);
+// out[t] = bf16(h[t] + R_t), R_t = sum over the token's experts in ascending id of bf16(w * y[row]), accumulated in
+// bf16 from zero (moe.py:28-32 + transformer_layers.py:168)
+hipError_t launch_moe_combine(void* out, const void* h, const void* y, const int32_t* sel_idx, const float* sel_w,
+                              const int32_t* row_of, int T, int D, int top_k, hipStream_t s);
