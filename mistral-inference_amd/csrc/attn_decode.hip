@@ -291,15 +291,17 @@ void launch_r(const AttnDecodeArgs& a, bool two_pass, hipStream_t s) {
 }  // namespace
 
 int attn_decode_splits(int W) {
-  static int slots = 0;  // ring slots per block; MI_ATTN_SPLIT_SLOTS overrides (tuning)
+  static int slots = 0;  // minimum ring slots per block; MI_ATTN_SPLIT_SLOTS overrides (tuning)
   if (slots == 0) {
     const char* e = getenv("MI_ATTN_SPLIT_SLOTS");
     slots = e ? atoi(e) : 128;
     if (slots < 16) slots = 128;
   }
-  int n = (W + slots - 1) / slots;
+  // at most 32 splits (the one-round-trip combine holds 32 partials per thread): widen the blocks beyond that
+  int per = slots;
+  if ((W + per - 1) / per > 32) per = (((W + 31) / 32) + 15) & ~15;
+  int n = (W + per - 1) / per;
   if (n < 1) n = 1;
-  if (n > 64) n = 64;
   return n;
 }
 

@@ -127,17 +127,20 @@ __global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* out, const bf16_t
   st16(out + p * 8, o);
 }
 
-// moe.py:25-27.  One wave per token.  logits_e = bf16(x . Wg[e]) ; top-k ; softmax over the k ; bf16.
+// moe.py:25-27.  One block per token, one wave per expert: logit_e = bf16(x . Wg[e]) ; top-k ; softmax over the k ;
+// bf16.  (A single wave per token serialises E dot products behind one another: 30 us per decode layer.)
 constexpr int MOE_MAX_E = 16;
-__global__ __launch_bounds__(64) void moe_router_kernel(int32_t* sel_idx, float* sel_w, const bf16_t* x, int ldx, int D,
-                                                        const bf16_t* gate, int E, int top_k, const bf16_t* norm_w,
-                                                        float eps) {
-  const int t = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void moe_router_kernel(int32_t* sel_idx, float* sel_w, const bf16_t* x, int ldx, int D,
+                                                          const bf16_t* gate, int E, int top_k, const bf16_t* norm_w,
+                                                          float eps) {
+  __shared__ float s_logit[MOE_MAX_E];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, e = threadIdx.x >> 6;  // wave e <-> expert e
   const bf16_t* xr = x + (size_t)t * ldx;
-  float inv = 1.f;
-  if (norm_w) {
-    float ss = 0.f;
-    for (int p = lane; p < (D >> 3); p += 64) {
+  const bf16_t* gr = gate + (size_t)e * D;
+  const int np = D >> 3;
+  float ss = 0.f;
+  if (norm_w) {  // every wave needs the same 1/rms: recomputing it (8 KB from L2) is cheaper than a block reduction
+    for (int p = lane; p < np; p += 64) {
       const u32x4 v = ld16(xr + p * 8);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -147,55 +150,38 @@ __global__ __launch_bounds__(64) void moe_router_kernel(int32_t* sel_idx, float*
       }
     }
     ss = wave_sum(ss);
-    inv = 1.0f / sqrtf(ss / (float)D + eps);
   }
-  float acc[MOE_MAX_E];
-#pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) acc[e] = 0.f;
-  for (int p = lane; p < (D >> 3); p += 64) {
+  const float inv = norm_w ? 1.0f / sqrtf(ss / (float)D + eps) : 1.f;
+  float acc = 0.f;
+  for (int p = lane; p < np; p += 64) {
     const u32x4 v = ld16(xr + p * 8);
-    float xf[8];
-    if (norm_w) {
-      const u32x4 wv = ld16(norm_w + p * 8);
+    const u32x4 g = ld16(gr + p * 8);
+    const u32x4 wv = norm_w ? ld16(norm_w + p * 8) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xf[2 * i] = bf_round(bf_round(bf_lo(v[i]) * inv) * bf_lo(wv[i]));
-        xf[2 * i + 1] = bf_round(bf_round(bf_hi(v[i]) * inv) * bf_hi(wv[i]));
+    for (int i = 0; i < 4; ++i) {
+      float x0 = bf_lo(v[i]), x1 = bf_hi(v[i]);
+      if (norm_w) {
+        x0 = bf_round(bf_round(x0 * inv) * bf_lo(wv[i]));
+        x1 = bf_round(bf_round(x1 * inv) * bf_hi(wv[i]));
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xf[2 * i] = bf_lo(v[i]);
-        xf[2 * i + 1] = bf_hi(v[i]);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < MOE_MAX_E; ++e) {
-      if (e < E) {
-        const u32x4 g = ld16(gate + (size_t)e * D + p * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[e] = fmaf(bf_lo(g[i]), xf[2 * i], acc[e]);
-          acc[e] = fmaf(bf_hi(g[i]), xf[2 * i + 1], acc[e]);
-        }
-      }
+      acc = fmaf(bf_lo(g[i]), x0, acc);
+      acc = fmaf(bf_hi(g[i]), x1, acc);
     }
   }
-  float logit[MOE_MAX_E];
-#pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) logit[e] = (e < E) ? bf_round(wave_sum(acc[e])) : -INFINITY;
-  if (lane == 0) {
+  acc = wave_sum(acc);
+  if (lane == 0) s_logit[e] = bf_round(acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
     float tw[4];
     int ti[4];
     unsigned taken = 0;
     for (int k = 0; k < top_k; ++k) {
       int best = -1;
       float bv = -INFINITY;
-#pragma unroll
-      for (int e = 0; e < MOE_MAX_E; ++e)
-        if (e < E && !((taken >> e) & 1u) && (best < 0 || logit[e] > bv)) {
-          best = e;
-          bv = logit[e];
+      for (int j = 0; j < E; ++j)
+        if (!((taken >> j) & 1u) && (best < 0 || s_logit[j] > bv)) {  // ties: lowest expert id
+          best = j;
+          bv = s_logit[j];
         }
       taken |= 1u << best;
       ti[k] = best;
@@ -332,7 +318,7 @@ hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hi
 hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate,
                              int E, int top_k, const void* norm_w, float eps, hipStream_t s) {
   if (E > MOE_MAX_E || top_k > 4 || top_k > E) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(moe_router_kernel, dim3(T), dim3(64), 0, s, sel_idx, sel_w, (const bf16_t*)x, ldx, D,
+  hipLaunchKernelGGL(moe_router_kernel, dim3(T), dim3(64 * E), 0, s, sel_idx, sel_w, (const bf16_t*)x, ldx, D,
                      (const bf16_t*)gate, E, top_k, (const bf16_t*)norm_w, eps);
   return hipGetLastError();
 }
