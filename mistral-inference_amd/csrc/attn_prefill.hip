@@ -29,7 +29,7 @@ constexpr int KS_BYTES = KT * DH * 2;
 constexpr int VT_BYTES = DH * VT_STRIDE;
 constexpr float LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[KS_BYTES + VT_BYTES];
   char* Ks = smem;
   char* Vt = smem + KS_BYTES;
@@ -133,11 +133,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
     }
   };
 
-  gload(0);
+  // No register prefetch of the next tile: it would push the kernel past 256 registers, i.e. to one wave per SIMD.
+  // Two resident blocks per CU (2 waves per SIMD) hide each other's staging latency and barriers instead.
   for (int it = 0; it < n_tiles; ++it) {
+    gload(it);
     lstore();
     __syncthreads();
-    if (it + 1 < n_tiles) gload(it + 1);
 
     const int t_lo = kp_lo + it * KT;
     const int t_hi = min(t_lo + KT - 1, kp_hi);
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = fast_exp2(m_run - m_new);
+      const bool moved = m_new != m_run;
       m_run = m_new;
       float psum = 0.f;
       uint32_t pb[2][2][4];
@@ -184,15 +186,17 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float p0 = exp2f(st[mb][r] - m_new), p1 = exp2f(st[mb][r + 1] - m_new);
+          const float p0 = fast_exp2(st[mb][r] - m_new), p1 = fast_exp2(st[mb][r + 1] - m_new);
           psum += p0 + p1;
-          pb[mb][r >> 3][(r & 7) >> 1] = pack_bf2(p0, p1);
+          pb[mb][r >> 3][(r & 7) >> 1] = cvt_pk_bf16(p0, p1);
         }
       l_run = l_run * alpha + psum;
+      if (__any(moved)) {  // exact: when no lane's running max moved, every alpha is 1 and the rescale is a no-op
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+      }
       // ---- O^T += V^T . P^T
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)

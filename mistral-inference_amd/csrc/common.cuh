@@ -80,6 +80,15 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Packed fp32 -> bf16 (RNE) in one instruction; gfx950 has no builtin for it (guide T12).
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// raw v_exp_f32 (2^x): no denormal range fix-up - callers pass x <= 0 where flushing tiny results to 0 is intended
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // The reference's SiLU runs on a bf16 tensor: silu evaluated in fp32, rounded to bf16; then the product
