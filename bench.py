@@ -204,10 +204,13 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == opt.gpus, f"--gpus {opt.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    local = local % torch.cuda.device_count()  # (test rigs may run several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
-        torch.distributed.init_process_group("nccl")  # RCCL
+        # "nccl" is RCCL on ROCm (xGMI between the GPUs of a node).  MI_DIST_BACKEND=gloo exists only so that the
+        # pipeline path can be exercised on a single-GPU box (RCCL refuses two ranks on one device).
+        torch.distributed.init_process_group(os.environ.get("MI_DIST_BACKEND", "nccl"))
 
     params, model_name = PRESETS[opt.model]
     params = dict(params)

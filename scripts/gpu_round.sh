@@ -2,24 +2,8 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -q -p no:cacheprovider --timeout 400 > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
-timeout 900 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/bench.log 2>&1
-rm -rf gpurun_out/prof
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o decode -- python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/prof_bench.log 2>&1)
-find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
-tail -n 3 gpurun_out/pytest_gpu.log
-for f in gpurun_out/bench.log; do
-grep -h '"metric"' $f | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print('$f', d['value'], 'tok/s', d['ms_per_step'], 'ms', 'step frac', d['hbm_roofline_step']['frac'], 'prefill', d['prefill']['tokens_per_s'], d['prefill']['tflops'], 'TF', d.get('roofline',{}).get('achieved'))
-"; done
-python - <<'PY'
-import csv,re
-rows = list(csv.DictReader(open("gpurun_out/prof/decode_kernel_stats.csv")))
-for r in rows[:8]:
-    n = re.sub(r"\(anonymous namespace\)::","",r["Name"])[:60]
-    if "at::native" in n: continue
-    print(f"{n:60s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f}")
-PY
+timeout 900 python -m pytest tests/test_gpu_pipeline.py -m gpu -q -p no:cacheprovider --timeout 400 > gpurun_out/pytest_pp.log 2>&1
+echo "pytest exit $?" >> gpurun_out/pytest_pp.log
+MI_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 16 --warmup 4 > gpurun_out/bench_pp2_gloo.log 2>&1
+echo "pp2 exit $?" >> gpurun_out/bench_pp2_gloo.log
+tail -n 6 gpurun_out/pytest_pp.log; tail -n 4 gpurun_out/bench_pp2_gloo.log | cut -c1-600

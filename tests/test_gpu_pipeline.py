@@ -1,0 +1,62 @@
+"""The HIP pipeline path with 2 ranks: real kernels, per-rank layer ranges, device-tensor send/recv and the logits
+broadcast.  Both ranks share the one GPU of the test box, so the transport is gloo (RCCL refuses two ranks on one
+device); on a multi-GPU node the same code runs over "nccl" = RCCL (bench.py --gpus N)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, name, tmp, q):
+    for p in (os.path.join(ROOT, "mistral-inference_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from golden_util import Case
+        from hip_util import write_checkpoint
+        from mistral_inference.generate import generate
+        from mistral_inference.transformer import Transformer
+        case = Case(name)
+        folder = os.path.join(tmp, "ckpt")
+        if rank == 0:
+            write_checkpoint(folder, case.args, case.weights())
+        dist.barrier()
+        m = Transformer.from_folder(folder, max_batch_size=case.max_batch_size, num_pipeline_ranks=world, device="cuda:0",
+                                    dtype=torch.bfloat16)
+        prompts = case.prompts if rank == 0 else [[0] * len(p) for p in case.prompts]
+        toks, lps = generate(prompts, m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size)
+        q.put((rank, toks, lps, m.n_local_layers, sorted(m.layers.keys())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["dense_bf16", "swa_chunk_bf16", "moe_bf16"])
+def test_two_stage_pipeline_on_hip(name, tmp_path):
+    from golden_util import Case
+    case = Case(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_toks, ref_lps = case.tokens(), case.logprobs()
+    (_, t0, lp0, n0, k0), (_, t1, lp1, n1, k1) = res
+    assert (n0, n1) == (1, 1) and k0 == ["0"] and k1 == ["1"]
+    assert t0 == t1  # every rank samples from the same broadcast logits
+    for b, (mine, ref) in enumerate(zip(t0, ref_toks)):
+        n = next((i for i, (x, y) in enumerate(zip(mine, ref)) if x != y), len(ref))
+        assert n >= 1, (name, b, mine, ref)
+        npl = len(case.prompts[b]) - 1 + n
+        assert max(abs(x - y) for x, y in zip(lp0[b][:npl], ref_lps[b][:npl])) <= 6e-2
