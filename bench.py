@@ -276,7 +276,7 @@ def main() -> None:
         "config": {"workload": f"{model_name} dims, {params['n_layers']} layers, random-init bf16, "
                                f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
                    "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
-                   "decode_launch": "eager" if opt.no_graph else "hipGraph replay",
+                   "decode_launch": "eager" if (opt.no_graph or world > 1) else "hipGraph replay",
                    "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
         "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                               "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},

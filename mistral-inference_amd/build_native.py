@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
-SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip"]
-HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"),
+SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
+           os.path.join(CSRC, "grid_barrier.cuh"),
            os.path.join(HERE, "..", "include", "mistral_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -32,14 +33,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose: bool = True, extra_flags=()) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build_safe(verbose: bool = True) -> str:
+    """Second build with -DMI_SAFE_LOADS (compiler-counted loads, no hand-written vmcnt): the differential-test twin."""
+    return build(verbose=verbose, extra_flags=("-DMI_SAFE_LOADS",), obj_dir=OBJ + "_safe",
+                 lib=os.path.join(HERE, "lib", "libmistral_hip_safe.so"))
+
+
+def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = LIB) -> str:
+    os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if _stale(o, [s] + HEADERS):
             jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
 
@@ -54,11 +61,12 @@ def build(verbose: bool = True, extra_flags=()) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
-    return LIB
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
     print(build(verbose="-q" not in sys.argv))
+    print(build_safe(verbose="-q" not in sys.argv))

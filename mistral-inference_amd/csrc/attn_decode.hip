@@ -12,6 +12,7 @@
 // and merged once at the end: lanes -> waves (LDS) -> splits (global fp32 partials; the last block to
 // arrive for a (sequence, kv head) combines them - agent-scope release/acquire, guide section 6 G16).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.cuh"
 #include "kernels.h"
@@ -90,15 +91,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   // steps in flight (ping-pong register sets A/B, 16 KiB per wave outstanding): the kernel is pure HBM
   // latency/bandwidth, so depth is what matters.  The loads are inline asm that hipcc does not count, waited for by
   // hand with vmcnt(2*UK) = "the other set may stay in flight" (common.cuh; guide section 5.7): hipcc's own
-  // bookkeeping drains vmcnt to 0 every iteration.  Out-of-range slots are clamped to a valid one and masked
-  // through `valid`.
-  constexpr int UK = 4;
-  static_assert(2 * UK == 8, "vm_wait8");
+  // bookkeeping drains vmcnt to 0 every iteration.
+  constexpr int UK = (R <= 4) ? 4 : 2;  // R >= 6 needs the registers for its accumulators: half-size sets, no AGPR spills
   const int s_first = s_begin + wid * 4 + g;
   const int s_clamp = max(kv_len - 1, 0);
   const int n_steps = (s_end > s_begin) ? (s_end - s_begin + 16 * UK - 1) / (16 * UK) : 0;  // block-uniform
   u32x4 setA[2 * UK], setB[2 * UK];  // [0, UK): K rows, [UK, 2UK): V rows
-  auto load_step = [&](int it, u32x4 (&kv)[2 * UK]) {   // callers guarantee it < n_steps (block-uniform)
+  // ALWAYS exactly 2*UK unconditional asm loads (slots past the block's range are clamped to a valid slot and masked
+  // in reduce_step): static wait counts, and - just as important - no control-flow merge between an asm load and its
+  // wait, so hipcc never has a reason to copy a register whose data is still in flight (guide section 5.7 item 1).
+  auto load_step = [&](int it, u32x4 (&kv)[2 * UK]) {
     const int s0 = s_first + it * 16 * UK;
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
@@ -136,20 +138,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
       }
     }
   };
-  // Every asm load is waited for before its registers can be reused: the wait for step `it` allows the 2*UK loads
-  // of step it+1 to stay in flight when that step exists, and is a full drain when it does not.
-  if (n_steps > 0) load_step(0, setA);
-  if (n_steps > 1) load_step(1, setB);
+  // Two sets in flight; the set being reduced is waited for with "the other set's 2*UK loads may stay in flight".
+  // Steps beyond n_steps reduce nothing (every slot is masked) and their loads are drained before the registers are
+  // reused by the merge code below.
+  auto wait_set = [&](u32x4 (&kv)[2 * UK], auto n) {
+    if constexpr (UK == 4) vm_wait8<decltype(n)::value>(kv);
+    else vm_wait4<decltype(n)::value>(kv);
+  };
+  load_step(0, setA);
+  load_step(1, setB);
   for (int it = 0; it < n_steps; it += 2) {
-    if (it + 1 < n_steps) vm_wait8<2 * UK>(setA); else vm_wait8<0>(setA);
+    wait_set(setA, std::integral_constant<int, 2 * UK>{});
     reduce_step(it, setA);
-    if (it + 2 < n_steps) load_step(it + 2, setA);
-    if (it + 1 < n_steps) {
-      if (it + 2 < n_steps) vm_wait8<2 * UK>(setB); else vm_wait8<0>(setB);
-      reduce_step(it + 1, setB);
-      if (it + 3 < n_steps) load_step(it + 3, setB);
-    }
+    load_step(it + 2, setA);
+    wait_set(setB, std::integral_constant<int, 2 * UK>{});
+    reduce_step(it + 1, setB);
+    load_step(it + 3, setB);
   }
+  wait_set(setA, std::integral_constant<int, 0>{});
+  wait_set(setB, std::integral_constant<int, 0>{});
 
   // 4 lane groups -> wave
   merge_from<R>(st, 16);

@@ -42,6 +42,15 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 // AFTER the ones being waited for (loads retire in order), and the "+v" operands pin every consumer of those
 // registers behind the wait (form (ii) of the guide).  Compiler-issued loads elsewhere in the kernel only ever
 // over-wait because of the extra outstanding loads, never under-wait.
+// -DMI_SAFE_LOADS builds the same kernels with ordinary compiler-counted loads and no hand-written waits
+// (lib/libmistral_hip_safe.so): slower, but free of the asm-load hazards by construction; tests/test_gpu_safe_variant.py
+// requires the two builds to agree BIT FOR BIT.
+#ifdef MI_SAFE_LOADS
+__device__ __forceinline__ void ld16_asm_nt(u32x4& dst, const void* p) { dst = ld16_nt(p); }
+__device__ __forceinline__ void ld16_asm(u32x4& dst, const void* p) { dst = ld16(p); }
+template <int N> __device__ __forceinline__ void vm_wait8(u32x4 (&)[8]) {}
+template <int N> __device__ __forceinline__ void vm_wait4(u32x4 (&)[4]) {}
+#else
 __device__ __forceinline__ void ld16_asm_nt(u32x4& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
 }
@@ -58,6 +67,31 @@ __device__ __forceinline__ void vm_wait8(u32x4 (&r)[8]) {
 template <int N>
 __device__ __forceinline__ void vm_wait4(u32x4 (&r)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+#endif
+
+// ---- agent-coherent accesses for data exchanged between workgroups INSIDE one launch (fused decode engine).
+// Write-through (sc0 sc1) stores + sc0 sc1 loads on both sides are one of the valid hand-off forms of
+// MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility" and need no release/acquire
+// fences: the bytes leave the XCD's non-coherent L2 on the store, and the loads do not hit a stale L1/L2 copy.
+__device__ __forceinline__ void ld16_asm_coherent(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ uint32_t ld_u32_coherent_sync(const void* p) {  // load + full wait in one statement
+  uint32_t r;
+  asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t ld_u16_coherent_sync(const void* p) {
+  uint32_t r;
+  asm volatile("global_load_ushort %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void st_u32_wt(void* p, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_u16_wt(void* p, uint32_t v) {
+  asm volatile("global_store_short %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Sum over the 64 lanes of a wave; every lane gets the total.

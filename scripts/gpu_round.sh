@@ -2,8 +2,14 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-timeout 900 python -m pytest tests/test_gpu_pipeline.py -m gpu -q -p no:cacheprovider --timeout 400 > gpurun_out/pytest_pp.log 2>&1
-echo "pytest exit $?" >> gpurun_out/pytest_pp.log
-MI_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 16 --warmup 4 > gpurun_out/bench_pp2_gloo.log 2>&1
-echo "pp2 exit $?" >> gpurun_out/bench_pp2_gloo.log
-tail -n 6 gpurun_out/pytest_pp.log; tail -n 4 gpurun_out/bench_pp2_gloo.log | cut -c1-600
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+timeout 900 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/bench.log 2>&1
+MISTRAL_HIP_LIB=$REPO/mistral-inference_amd/lib/libmistral_hip_safe.so timeout 900 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/bench_safe.log 2>&1
+tail -n 5 gpurun_out/pytest_gpu.log
+for f in gpurun_out/bench.log gpurun_out/bench_safe.log; do
+grep -h '"metric"' $f | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('$f', d['value'], 'tok/s', d['ms_per_step'], 'ms', 'step frac', d['hbm_roofline_step']['frac'], 'prefill', d['prefill']['tokens_per_s'], d['prefill']['tflops'], 'TF', d.get('roofline',{}).get('achieved'))
+"; done
