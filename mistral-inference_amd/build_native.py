@@ -33,10 +33,11 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_safe(verbose: bool = True) -> str:
-    """Second build with -DMI_SAFE_LOADS (compiler-counted loads, no hand-written vmcnt): the differential-test twin."""
-    return build(verbose=verbose, extra_flags=("-DMI_SAFE_LOADS",), obj_dir=OBJ + "_safe",
-                 lib=os.path.join(HERE, "lib", "libmistral_hip_safe.so"))
+def build_asm_twin(verbose: bool = True) -> str:
+    """Twin build with -DMI_ASM_LOADS (hand-counted inline-asm loads, see csrc/common.cuh): NOT the shipped library, only
+    the partner of the bitwise differential test and a tuning aid."""
+    return build(verbose=verbose, extra_flags=("-DMI_ASM_LOADS",), obj_dir=OBJ + "_asm",
+                 lib=os.path.join(HERE, "lib", "libmistral_hip_asm.so"))
 
 
 def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = LIB) -> str:
@@ -69,4 +70,4 @@ def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = L
 
 if __name__ == "__main__":
     print(build(verbose="-q" not in sys.argv))
-    print(build_safe(verbose="-q" not in sys.argv))
+    print(build_asm_twin(verbose="-q" not in sys.argv))

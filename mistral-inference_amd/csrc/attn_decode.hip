@@ -105,8 +105,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
       const int sl = min(s0 + 16 * u, s_clamp);
-      ld16_asm_nt(kv[u], kbase + (size_t)sl * row_stride);
-      ld16_asm_nt(kv[UK + u], vbase + (size_t)sl * row_stride);
+      if constexpr (R <= 6) {
+        ld16_asm_nt(kv[u], kbase + (size_t)sl * row_stride);
+        ld16_asm_nt(kv[UK + u], vbase + (size_t)sl * row_stride);
+      } else {  // 256+ registers: hipcc shuffles values through AGPRs - never hide loads from it here
+        kv[u] = ld16_nt(kbase + (size_t)sl * row_stride);
+        kv[UK + u] = ld16_nt(vbase + (size_t)sl * row_stride);
+      }
     }
   };
   auto reduce_step = [&](int it, const u32x4 (&kv)[2 * UK]) {
@@ -141,8 +146,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   // Two sets in flight; the set being reduced is waited for with "the other set's 2*UK loads may stay in flight".
   // Steps beyond n_steps reduce nothing (every slot is masked) and their loads are drained before the registers are
   // reused by the merge code below.
-  auto wait_set = [&](u32x4 (&kv)[2 * UK], auto n) {
-    if constexpr (UK == 4) vm_wait8<decltype(n)::value>(kv);
+  auto wait_set = [&](u32x4 (&kv)[2 * UK], auto n) {  // (no-op in the default build and for R > 6)
+    if constexpr (R > 6) return;
+    else if constexpr (UK == 4) vm_wait8<decltype(n)::value>(kv);
     else vm_wait4<decltype(n)::value>(kv);
   };
   load_step(0, setA);

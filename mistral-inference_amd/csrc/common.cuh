@@ -35,16 +35,17 @@ __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
 }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-// ---- loads hipcc does not count (cdna_hip_programming.md section 5.7).
-// hipcc's s_waitcnt insertion tracks only its most recent batch across a loop back-edge and drains vmcnt to 0
-// every iteration, which collapses a two-batch-deep weight stream to one batch in flight.  These asm loads are
-// invisible to that bookkeeping; the kernel waits for them itself with vm_wait<N>(regs...) - `N` = loads issued
-// AFTER the ones being waited for (loads retire in order), and the "+v" operands pin every consumer of those
-// registers behind the wait (form (ii) of the guide).  Compiler-issued loads elsewhere in the kernel only ever
-// over-wait because of the extra outstanding loads, never under-wait.
-// -DMI_SAFE_LOADS builds the same kernels with ordinary compiler-counted loads and no hand-written waits
-// (lib/libmistral_hip_safe.so): slower, but free of the asm-load hazards by construction; tests/test_gpu_safe_variant.py
-// requires the two builds to agree BIT FOR BIT.
+// ---- the weight / KV streams' loads.
+// DEFAULT build: ordinary non-temporal loads, counted by hipcc.  With unconditional (clamped-address) loads, ping-pong
+// register sets and no register copies in the loop, hipcc's own s_waitcnt placement keeps the streams deep enough:
+// measured 317.6 vs 320.2 tokens/s against the hand-counted variant below.
+// -DMI_ASM_LOADS (lib/libmistral_hip_asm.so, an opt-in twin used for tuning and for the bitwise differential test
+// tests/test_gpu_safe_variant.py): inline-asm loads that hipcc does not count (cdna_hip_programming.md section 5.7),
+// waited for by hand with vm_wait<N>(regs...) - N = loads issued AFTER the ones being waited for (loads retire in
+// order), the "+v" operands pin every consumer behind the wait (form (ii) of the guide).  That variant is NOT shipped
+// by default: an asm load's destination is unprotected until its wait, and hipcc did copy such registers while the
+// data was in flight in two situations met during development (a long prologue between issue and wait; AGPR spilling
+// at 256+ registers) - silent, timing-dependent corruption that only the differential test caught.
 #ifdef MI_SAFE_LOADS
 __device__ __forceinline__ void ld16_asm_nt(u32x4& dst, const void* p) { dst = ld16_nt(p); }
 __device__ __forceinline__ void ld16_asm(u32x4& dst, const void* p) { dst = ld16(p); }

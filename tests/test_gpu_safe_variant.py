@@ -1,9 +1,10 @@
-"""Differential test for the hand-counted asm loads (common.cuh: ld16_asm* / vm_wait*).
+"""Differential test: shipped build (compiler-counted loads) vs the -DMI_ASM_LOADS twin (hand-counted inline-asm loads).
 
-Those loads are invisible to hipcc's bookkeeping: a compiler-inserted copy of a destination register before our wait, or
-a wrong count, would corrupt results silently and only under unlucky timing.  libmistral_hip_safe.so is the same source
-built with -DMI_SAFE_LOADS (ordinary compiler-counted loads).  Both builds must produce BIT-IDENTICAL outputs over
-GEMV shapes x token counts x epilogues, decode attention for every GQA ratio, and whole-model generate() runs."""
+Asm loads are invisible to hipcc's bookkeeping: a compiler-inserted copy of a destination register before our wait, or
+a wrong count, corrupts results silently and only under unlucky timing (this test caught exactly that during
+development).  Both builds of the same source must produce BIT-IDENTICAL outputs over GEMV shapes x token counts x
+epilogues, decode attention for every GQA ratio, and whole-model generate() runs - and each must agree with itself run
+to run."""
 import os
 import subprocess
 import sys
@@ -26,14 +27,14 @@ def _run(lib, path, reps):
 
 
 def test_fast_and_safe_builds_agree_bitwise(tmp_path):
-    assert os.path.exists(os.path.join(LIBDIR, "libmistral_hip_safe.so")), "build it: python mistral-inference_amd/build_native.py"
-    fast = _run("libmistral_hip.so", str(tmp_path / "fast.pt"), 6)
-    safe = _run("libmistral_hip_safe.so", str(tmp_path / "safe.pt"), 6)
+    assert os.path.exists(os.path.join(LIBDIR, "libmistral_hip_asm.so")), "build it: python mistral-inference_amd/build_native.py"
+    fast = _run("libmistral_hip_asm.so", str(tmp_path / "asm.pt"), 6)
+    safe = _run("libmistral_hip.so", str(tmp_path / "shipped.pt"), 6)
     assert fast.keys() == safe.keys() and len(fast) > 500
     bad = [k for k in fast if not torch.equal(fast[k].view(torch.uint8) if fast[k].dtype != torch.float64 else fast[k],
                                               safe[k].view(torch.uint8) if safe[k].dtype != torch.float64 else safe[k])]
     assert not bad, bad[:10]
     # and the fast build agrees with itself run to run (timing-dependent corruption shows up as flakiness)
-    again = _run("libmistral_hip.so", str(tmp_path / "fast2.pt"), 6)
-    bad = [k for k in fast if not torch.equal(fast[k], again[k])]
+    again = _run("libmistral_hip.so", str(tmp_path / "shipped2.pt"), 6)
+    bad = [k for k in safe if not torch.equal(safe[k], again[k])]
     assert not bad, bad[:10]
