@@ -268,10 +268,15 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
   const bool gemv = T <= GEMV_MAX_T;
   bf16_t* h = (bf16_t*)bt->h;
 
-  if (branch == MI_BRANCH_DECODE)
-    MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, s), "decode_prep"));
-  if (m->tok_embeddings)
-    MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, s), "embedding"));
+  if (branch == MI_BRANCH_DECODE && m->tok_embeddings) {
+    MI_TRY(hip_rc(launch_decode_prep_embedding(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, h,
+                                               m->tok_embeddings, bt->input_ids, D, m->vocab_size, s), "decode_prep+embedding"));
+  } else {
+    if (branch == MI_BRANCH_DECODE)
+      MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, s), "decode_prep"));
+    if (m->tok_embeddings)
+      MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, s), "embedding"));
+  }
 
   for (int l = 0; l < m->n_layers; ++l) {
     const mi_layer_t& L = m->layers[l];

@@ -78,6 +78,18 @@ __device__ __forceinline__ void vm_wait4(u32x4 (&r)[4]) {
 __device__ __forceinline__ void ld16_asm_coherent(u32x4& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
 }
+// waits for ld16_asm_coherent: always real (these loads are asm in every build)
+template <int N>
+__device__ __forceinline__ void vm_wait8_asm(u32x4 (&r)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+               : "n"(N)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait4_asm(u32x4 (&r)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
 __device__ __forceinline__ uint32_t ld_u32_coherent_sync(const void* p) {  // load + full wait in one statement
   uint32_t r;
   asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");

@@ -116,6 +116,28 @@ __global__ void decode_prep_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_
   if (b == 0) q_start[B] = B;
 }
 
+// Decode step on the rank that owns the embedding: decode_prep + embedding gather in ONE launch (block t = sequence t;
+// T == B at decode).  Saves a launch per token; the metadata words are consumed only by later launches.
+__global__ __launch_bounds__(256) void decode_prep_embedding_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before,
+                                                                    int32_t* tok_seq, int32_t* tok_pos, int B, bf16_t* out,
+                                                                    const bf16_t* table, const int64_t* ids, int D, int vocab) {
+  const int t = blockIdx.x;
+  if (threadIdx.x == 0) {
+    const int p = (int)kv_seqlens[t];
+    kv_before[t] = p;
+    tok_pos[t] = p;
+    tok_seq[t] = t;
+    q_start[t] = t;
+    kv_seqlens[t] = p + 1;
+    if (t == 0) q_start[B] = B;
+  }
+  long id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const bf16_t* src = table + (size_t)id * D;
+  bf16_t* dst = out + (size_t)t * D;
+  for (int p = threadIdx.x; p < (D >> 3); p += 256) st16(dst + p * 8, ld16(src + p * 8));
+}
+
 // out = bf16(a + b) (transformer_layers.py:168 for the MoE prefill path)
 __global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* out, const bf16_t* a, const bf16_t* b, size_t npieces) {
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -307,6 +329,13 @@ hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv
   if (B > 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(decode_prep_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, s, kv_seqlens, q_start, kv_before,
                      tok_seq, tok_pos, B);
+  return hipGetLastError();
+}
+hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
+                                        int32_t* tok_pos, int B, void* out, const void* table, const int64_t* ids, int D,
+                                        int vocab, hipStream_t s) {
+  hipLaunchKernelGGL(decode_prep_embedding_kernel, dim3(B), dim3(256), 0, s, kv_seqlens, q_start, kv_before, tok_seq, tok_pos, B,
+                     (bf16_t*)out, (const bf16_t*)table, ids, D, vocab);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s) {

@@ -177,11 +177,20 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   }
   const bool single = pair_mode && a.mode != GEMV_QKV_ROPE && a.mode != GEMV_MOE_W2 && (a.N + 1) / 2 < single_below;
   const int units = pair_mode ? (single ? a.N : (a.N + 1) / 2) : a.N;
-  // Persistent-style grid: at most g_gemv_max_blocks blocks (512 = 2 per CU measured best on MI355X; all co-resident), and every wave
-  // gets the same number k of units (e.g. W1|W3: 14336 units -> 512 blocks x 4 waves x 7 units) so there is no
-  // partially filled last round of blocks; the two-batch load pipeline runs across a wave's units.
-  const int k = (units + 4 * g_gemv_max_blocks - 1) / (4 * g_gemv_max_blocks);
-  int blocks = (units + 4 * k - 1) / (4 * k);
+  // Persistent-style grid: every wave gets the same number k of units (no partially filled last round of blocks; the
+  // two-batch load pipeline runs across a wave's units).  Preferred: the smallest k for which the block count is a
+  // multiple of the 256 CUs (even load per CU), at most 4 per CU, and divides the units exactly - e.g. W1|W3: 14336
+  // units -> 512 blocks x 4 waves x 7 units; q|k|v: 3072 units -> 768 blocks x 1.  Otherwise the smallest k that fits
+  // g_gemv_max_blocks (512 = 2 blocks per CU measured best on MI355X).
+  int blocks = 0;
+  for (int k = 1; k <= 64 && !blocks; ++k) {
+    const int b = (units + 4 * k - 1) / (4 * k);
+    if (b <= 1024 && b % 256 == 0 && b * 4 * k == units && (b <= g_gemv_max_blocks || k == 1)) blocks = b;
+  }
+  if (!blocks) {
+    const int k = (units + 4 * g_gemv_max_blocks - 1) / (4 * g_gemv_max_blocks);
+    blocks = (units + 4 * k - 1) / (4 * k);
+  }
   if (blocks < 1) blocks = 1;
   if (a.mode == GEMV_MOE_W2) {
     const size_t lds = (size_t)a.top_k * a.K * 2;

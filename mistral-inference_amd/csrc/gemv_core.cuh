@@ -109,9 +109,15 @@ __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int 
 
 template <int NX, int NW, int AFTER>
 __device__ __forceinline__ void x_wait(XRegs<NX, NW>& xr) {
-  if constexpr (NX == 8) vm_wait8<AFTER>(xr.x);
-  if constexpr (NX == 4) vm_wait4<AFTER>(xr.x);
-  if constexpr (NW == 4) vm_wait4<AFTER>(xr.w);
+  if constexpr (AFTER == 0) {  // fused engine: the activation loads are agent-coherent asm loads in every build
+    if constexpr (NX == 8) vm_wait8_asm<0>(xr.x);
+    if constexpr (NX == 4) vm_wait4_asm<0>(xr.x);
+    if constexpr (NW == 4) vm_wait4_asm<0>(xr.w);
+  } else {
+    if constexpr (NX == 8) vm_wait8<AFTER>(xr.x);
+    if constexpr (NX == 4) vm_wait4<AFTER>(xr.x);
+    if constexpr (NW == 4) vm_wait4<AFTER>(xr.w);
+  }
 }
 
 // AFTER = asm loads issued after the activation loads (2 * BATCH in the stand-alone kernels, 0 in the fused engine).
@@ -327,6 +333,28 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   for (int t = 0; t < TT; ++t) acc.v[0][t] = acc.v[1][t] = 0.f;
   int jc = 0;
 
+  // Epilogue operands are fetched EARLY (token position once, the unit's RoPE entry / residual pair when the unit
+  // starts) so that the end of a unit is arithmetic + one store instead of a chain of dependent loads.
+  const int tl = lane < T ? lane : 0;
+  int ep_pos = 0;
+  if (MODE == GEMV_QKV_ROPE) ep_pos = a.tok_pos[tl];
+  float2 ep_cs = make_float2(1.f, 0.f);
+  uint32_t ep_res = 0;
+  auto prefetch_epilogue = [&](int uu) {
+    if constexpr (FUSED) return;  // (fused engine: these operands are written by other workgroups; read late, coherently)
+    const int r0 = (ROWS == 2) ? 2 * uu : uu;
+    if (MODE == GEMV_QKV_ROPE && r0 < a.n1) {
+      const int i = (r0 % a.head_dim) >> 1;
+      ep_cs = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)ep_pos * (a.head_dim >> 1) + i) * 2);
+    }
+    if (MODE == GEMV_RESIDUAL) {
+      const bf16_t* rs = a.residual + (size_t)tl * a.ldo + r0;
+      if (ROWS == 2 && r0 + 1 < a.N) ep_res = *reinterpret_cast<const uint32_t*>(rs);
+      else ep_res = rs[0];
+    }
+  };
+  if (u < units) prefetch_epilogue(u);
+
   auto finish_unit = [&]() {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
@@ -360,7 +388,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
           bf16_t* o = reinterpret_cast<bf16_t*>(outp) + (size_t)t * a.ldo + r0;
           if (MODE == GEMV_RESIDUAL) {
             const bf16_t* rs = a.residual + (size_t)t * a.ldo + r0;
-            if (FUSED) {  // the residual stream was written by other workgroups of this launch
+            if (!FUSED) {
+              y0 = bf_lo(ep_res) + y0;
+              if (two) y1 = bf_hi(ep_res) + y1;
+            } else if (FUSED) {  // the residual stream was written by other workgroups of this launch
               if (two) {
                 const uint32_t rr = ld_u32_coherent_sync(rs);
                 y0 = bf_lo(rr) + y0;
@@ -368,16 +399,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
               } else {
                 y0 = bf_lo(ld_u16_coherent_sync(rs)) + y0;
               }
-            } else {
-              y0 = bf_to_f(rs[0]) + y0;
-              if (two) y1 = bf_to_f(rs[1]) + y1;
             }
           }
           if (MODE == GEMV_QKV_ROPE) {
-            const int pos = a.tok_pos[t];
+            const int pos = FUSED ? a.tok_pos[t] : ep_pos;
             if (r0 < a.n1) {  // q or k rows: rotate the adjacent pair (rope.py:13-23)
               const int i = (r0 % a.head_dim) >> 1;
-              const float2 cs = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (a.head_dim >> 1) + i) * 2);
+              float2 cs = ep_cs;
+              if (FUSED) cs = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (a.head_dim >> 1) + i) * 2);
               const float re = __fsub_rn(__fmul_rn(y0, cs.x), __fmul_rn(y1, cs.y));
               const float im = __fadd_rn(__fmul_rn(y0, cs.y), __fmul_rn(y1, cs.x));
               y0 = re;
@@ -417,6 +446,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
       jc = 0;
       finish_unit();
       u += nwaves;
+      if (u < units) prefetch_epilogue(u);
     }
   };
   while (u < units) {

@@ -120,6 +120,9 @@ hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void*
                            const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s);
 hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
                               int32_t* tok_pos, int B, hipStream_t s);
+hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
+                                        int32_t* tok_pos, int B, void* out, const void* table, const int64_t* ids, int D,
+                                        int vocab, hipStream_t s);
 hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- MoE

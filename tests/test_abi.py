@@ -42,3 +42,24 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".h", ".cuh")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "mistral_oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_unsupported_shapes_fail_loudly_before_any_device_work():
+    """mi_forward validates the model description first: wrong head_dim / GQA ratio / MoE width come back as MI_ERR_SHAPE
+    with a message, never as a silent wrong answer (checked without a GPU: validation precedes every launch)."""
+    import ctypes as C
+    from mistral_inference import _hip
+    L = _hip.lib()
+    layers = (_hip.MiLayer * 1)()
+    m = _hip.MiModel()
+    m.dim, m.n_heads, m.n_kv_heads, m.head_dim, m.hidden_dim, m.vocab_size, m.n_layers = 256, 4, 2, 64, 512, 100, 1
+    m.layers = C.cast(layers, C.POINTER(_hip.MiLayer))
+    bt = _hip.MiBatch()
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"head_dim" in L.mi_last_error_detail()
+    m.head_dim, m.n_heads, m.n_kv_heads = 128, 6, 2   # ratio 3: no kernel
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"GQA" in L.mi_last_error_detail()
+    m.n_heads, m.num_experts, m.top_k = 4, 32, 2
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"MoE" in L.mi_last_error_detail()
+    m.num_experts = m.top_k = 0
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -1     # valid model, empty batch -> MI_ERR_ARG
+    assert L.mi_attn_decode(1, 1, 128, 1, 1, 16, 1, 4, 2, 64, 1, 1, None) == -2   # head_dim 64

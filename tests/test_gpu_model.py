@@ -197,3 +197,48 @@ def test_fails_loudly_off_device(tmp_path):
     m32 = Transformer.from_folder(folder, max_batch_size=2, device="cuda", dtype=torch.float32)
     with pytest.raises(RuntimeError, match="bf16"):
         m32.forward(torch.tensor([1, 2, 3], device="cuda"), [3])
+
+
+def test_decode_batch_larger_than_gemv_limit(tmp_path):
+    """12 sequences decoding together: T = 12 > 8 takes the MFMA GEMM kernels with the decode attention branch."""
+    from mistral_inference.cache import BufferCache
+    args = mo.OracleArgs(dim=256, n_layers=2, head_dim=128, hidden_dim=512, n_heads=4, n_kv_heads=2, norm_eps=1e-5,
+                         vocab_size=512, sliding_window=8)
+    w = mo.synth_weights(args, seed=11)
+    model = _load(tmp_path, args, w, max_batch_size=12)
+    prompts = [[(3 * i + 7 * b + 1) % 512 for i in range(3 + (b % 5))] for b in range(12)]
+    lens = [len(p) for p in prompts]
+    cache = BufferCache(2, 12, 32, 2, 128, 8, device="cuda", dtype=BF)
+    ocache = mo.OracleCache(2, 12, 32, 2, 128, 8, dtype=BF)
+    om = mo.OracleModel(args, w)
+    flat = sum(prompts, [])
+    got = model.forward(torch.tensor(flat, device="cuda"), lens, cache).cpu()
+    ref = om.forward(torch.tensor(flat), lens, ocache)
+    assert (got - ref).abs().max().item() <= LOGIT_ATOL
+    for step in range(10):  # crosses the W=8 ring wrap for every sequence
+        nxt = torch.tensor([(5 * b + step) % 512 for b in range(12)])
+        got = model.forward(nxt.cuda(), [1] * 12, cache).cpu()
+        ref = om.forward(nxt, [1] * 12, ocache)
+        assert (got - ref).abs().max().item() <= LOGIT_ATOL, step
+    assert cache.kv_seqlens.tolist() == [n + 10 for n in lens]
+
+
+def test_softmax_fp32_false_and_module_level_block(tmp_path):
+    from mistral_inference.transformer import Transformer
+    case = Case("dense_bf16")
+    folder = write_checkpoint(tmp_path / "c", case.args, case.weights())
+    m = Transformer.from_folder(folder, max_batch_size=4, device="cuda", dtype=BF, softmax_fp32=False)
+    m32 = Transformer.from_folder(folder, max_batch_size=4, device="cuda", dtype=BF)
+    ids = torch.tensor(sum(case.prompts, []), device="cuda")
+    lens = [len(p) for p in case.prompts]
+    a, b = m.forward(ids, lens), m32.forward(ids, lens)
+    assert a.dtype == BF and b.dtype == torch.float32 and torch.equal(a.float(), b)  # widening is exact
+    # module-level TransformerBlock.forward (cache=None) == the runner's first layer
+    blk = m32.layers["0"]
+    h0 = m32.tok_embeddings.weight[ids]
+    pos = torch.cat([torch.arange(n) for n in lens]).cuda()
+    out = blk(h0, m32.freqs_cis[pos]).float().cpu()
+    om = mo.OracleModel(case.args, case.weights())
+    col = []
+    om.forward_partial(ids.cpu(), lens, None, collect=col)
+    assert (out - col[0].float()).abs().max().item() <= 4e-2 * max(1.0, col[0].float().abs().max().item())
