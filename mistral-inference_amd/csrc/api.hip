@@ -304,6 +304,11 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       g.out = ws.qkv; g.ldo = qkv_cols;
       MI_TRY(hip_rc(launch_gemm(g, s), "qkv gemm"));
       MI_TRY(hip_rc(launch_rope(ws.qkv, qkv_cols, T, H, Hkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
+      // decode branch with more than 8 sequences: the ring write that the GEMV epilogue does otherwise; it must
+      // precede the attention (cache.py:83-92 `update` then read, transformer_layers.py:77-81)
+      if (branch == MI_BRANCH_DECODE)
+        MI_TRY(hip_rc(launch_kv_write(ck, cv, W, ws.qkv + nq, ws.qkv + nq + nkv, qkv_cols, T, nkv, bt->tok_seq, bt->tok_pos,
+                                      bt->q_start, s), "kv_write (decode)"));
     }
 
     // ---- attention

@@ -120,28 +120,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (kt + 1 < nk) gload(kt + 1);
     const char* a_s = sA + buf * TILE_BYTES;
     const char* b_s = sB + buf * TILE_BYTES;
+    // all 16 fragment reads of this K step are issued first; hipcc's lgkmcnt ladder then lets the MFMAs of the first
+    // half start while the second half's reads are still in flight
+    bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
       const int fs = ks * 4 + (lane >> 4);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int r = wm * 64 + mt * 16 + (lane & 15);
-        af[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_s + lds_off(r, fs)));
+        af[ks][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_s + lds_off(r, fs)));
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         int r;
         if (EPI == GEMM_SWIGLU) r = (nt >> 1) * 64 + wn * 32 + (nt & 1) * 16 + (lane & 15);
         else r = wn * 64 + nt * 16 + (lane & 15);
-        bfr[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_s + lds_off(r, fs)));
+        bfr[ks][nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_s + lds_off(r, fs)));
       }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
-    }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][mt], bfr[ks][nt], acc[mt][nt], 0, 0, 0);
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
