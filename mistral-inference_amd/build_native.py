@@ -12,9 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
-SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip", "engine.hip"]
+SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
-           os.path.join(CSRC, "grid_barrier.cuh"),
            os.path.join(HERE, "..", "include", "mistral_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -31,13 +30,6 @@ def _stale(target: str, deps) -> bool:
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
-
-
-def build_asm_twin(verbose: bool = True) -> str:
-    """Twin build with -DMI_ASM_LOADS (hand-counted inline-asm loads, see csrc/common.cuh): NOT the shipped library, only
-    the partner of the bitwise differential test and a tuning aid."""
-    return build(verbose=verbose, extra_flags=("-DMI_ASM_LOADS",), obj_dir=OBJ + "_asm",
-                 lib=os.path.join(HERE, "lib", "libmistral_hip_asm.so"))
 
 
 def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = LIB) -> str:
@@ -70,4 +62,3 @@ def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = L
 
 if __name__ == "__main__":
     print(build(verbose="-q" not in sys.argv))
-    print(build_asm_twin(verbose="-q" not in sys.argv))

@@ -12,7 +12,6 @@
 // and merged once at the end: lanes -> waves (LDS) -> splits (global fp32 partials; the last block to
 // arrive for a (sequence, kv head) combines them - agent-scope release/acquire, guide section 6 G16).
 #include <cstdlib>
-#include <type_traits>
 
 #include "common.cuh"
 #include "kernels.h"
@@ -88,30 +87,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
 
   // Each lane group walks slots s_begin + wid*4 + g + 16*j, UK slots (K and V rows = 2*UK loads) per step, two
-  // steps in flight (ping-pong register sets A/B, 16 KiB per wave outstanding): the kernel is pure HBM
-  // latency/bandwidth, so depth is what matters.  The loads are inline asm that hipcc does not count, waited for by
-  // hand with vmcnt(2*UK) = "the other set may stay in flight" (common.cuh; guide section 5.7): hipcc's own
-  // bookkeeping drains vmcnt to 0 every iteration.
+  // steps in flight (ping-pong register sets A/B refilled in place, 16 KiB per wave outstanding): the kernel is pure
+  // HBM latency/bandwidth, so depth is what matters.
   constexpr int UK = (R <= 4) ? 4 : 2;  // R >= 6 needs the registers for its accumulators: half-size sets, no AGPR spills
   const int s_first = s_begin + wid * 4 + g;
   const int s_clamp = max(kv_len - 1, 0);
   const int n_steps = (s_end > s_begin) ? (s_end - s_begin + 16 * UK - 1) / (16 * UK) : 0;  // block-uniform
   u32x4 setA[2 * UK], setB[2 * UK];  // [0, UK): K rows, [UK, 2UK): V rows
-  // ALWAYS exactly 2*UK unconditional asm loads (slots past the block's range are clamped to a valid slot and masked
-  // in reduce_step): static wait counts, and - just as important - no control-flow merge between an asm load and its
-  // wait, so hipcc never has a reason to copy a register whose data is still in flight (guide section 5.7 item 1).
+  // ALWAYS exactly 2*UK unconditional loads (slots past the block's range are clamped to a valid slot and masked in
+  // reduce_step): no branch around a load, so hipcc's wait for one set leaves the other set's loads in flight.
   auto load_step = [&](int it, u32x4 (&kv)[2 * UK]) {
     const int s0 = s_first + it * 16 * UK;
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
       const int sl = min(s0 + 16 * u, s_clamp);
-      if constexpr (R <= 6) {
-        ld16_asm_nt(kv[u], kbase + (size_t)sl * row_stride);
-        ld16_asm_nt(kv[UK + u], vbase + (size_t)sl * row_stride);
-      } else {  // 256+ registers: hipcc shuffles values through AGPRs - never hide loads from it here
-        kv[u] = ld16_nt(kbase + (size_t)sl * row_stride);
-        kv[UK + u] = ld16_nt(vbase + (size_t)sl * row_stride);
-      }
+      kv[u] = ld16_nt(kbase + (size_t)sl * row_stride);
+      kv[UK + u] = ld16_nt(vbase + (size_t)sl * row_stride);
     }
   };
   auto reduce_step = [&](int it, const u32x4 (&kv)[2 * UK]) {
@@ -143,26 +134,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
       }
     }
   };
-  // Two sets in flight; the set being reduced is waited for with "the other set's 2*UK loads may stay in flight".
-  // Steps beyond n_steps reduce nothing (every slot is masked) and their loads are drained before the registers are
-  // reused by the merge code below.
-  auto wait_set = [&](u32x4 (&kv)[2 * UK], auto n) {  // (no-op in the default build and for R > 6)
-    if constexpr (R > 6) return;
-    else if constexpr (UK == 4) vm_wait8<decltype(n)::value>(kv);
-    else vm_wait4<decltype(n)::value>(kv);
-  };
+  // Two sets in flight.  Steps beyond n_steps reduce nothing (every slot is masked).
   load_step(0, setA);
   load_step(1, setB);
   for (int it = 0; it < n_steps; it += 2) {
-    wait_set(setA, std::integral_constant<int, 2 * UK>{});
     reduce_step(it, setA);
     load_step(it + 2, setA);
-    wait_set(setB, std::integral_constant<int, 2 * UK>{});
     reduce_step(it + 1, setB);
     load_step(it + 3, setB);
   }
-  wait_set(setA, std::integral_constant<int, 0>{});
-  wait_set(setB, std::integral_constant<int, 0>{});
 
   // 4 lane groups -> wave
   merge_from<R>(st, 16);

@@ -35,77 +35,14 @@ __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
 }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-// ---- the weight / KV streams' loads.
-// DEFAULT build: ordinary non-temporal loads, counted by hipcc.  With unconditional (clamped-address) loads, ping-pong
-// register sets and no register copies in the loop, hipcc's own s_waitcnt placement keeps the streams deep enough:
-// measured 317.6 vs 320.2 tokens/s against the hand-counted variant below.
-// -DMI_ASM_LOADS (lib/libmistral_hip_asm.so, an opt-in twin used for tuning and for the bitwise differential test
-// tests/test_gpu_safe_variant.py): inline-asm loads that hipcc does not count (cdna_hip_programming.md section 5.7),
-// waited for by hand with vm_wait<N>(regs...) - N = loads issued AFTER the ones being waited for (loads retire in
-// order), the "+v" operands pin every consumer behind the wait (form (ii) of the guide).  That variant is NOT shipped
-// by default: an asm load's destination is unprotected until its wait, and hipcc did copy such registers while the
-// data was in flight in two situations met during development (a long prologue between issue and wait; AGPR spilling
-// at 256+ registers) - silent, timing-dependent corruption that only the differential test caught.
-#ifdef MI_SAFE_LOADS
-__device__ __forceinline__ void ld16_asm_nt(u32x4& dst, const void* p) { dst = ld16_nt(p); }
-__device__ __forceinline__ void ld16_asm(u32x4& dst, const void* p) { dst = ld16(p); }
-template <int N> __device__ __forceinline__ void vm_wait8(u32x4 (&)[8]) {}
-template <int N> __device__ __forceinline__ void vm_wait4(u32x4 (&)[4]) {}
-#else
-__device__ __forceinline__ void ld16_asm_nt(u32x4& dst, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void ld16_asm(u32x4& dst, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait8(u32x4 (&r)[8]) {
-  asm volatile("s_waitcnt vmcnt(%8)"
-               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-               : "n"(N)
-               : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait4(u32x4 (&r)[4]) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
-}
-#endif
-
-// ---- agent-coherent accesses for data exchanged between workgroups INSIDE one launch (fused decode engine).
-// Write-through (sc0 sc1) stores + sc0 sc1 loads on both sides are one of the valid hand-off forms of
-// MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility" and need no release/acquire
-// fences: the bytes leave the XCD's non-coherent L2 on the store, and the loads do not hit a stale L1/L2 copy.
-__device__ __forceinline__ void ld16_asm_coherent(u32x4& dst, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
-}
-// waits for ld16_asm_coherent: always real (these loads are asm in every build)
-template <int N>
-__device__ __forceinline__ void vm_wait8_asm(u32x4 (&r)[8]) {
-  asm volatile("s_waitcnt vmcnt(%8)"
-               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-               : "n"(N)
-               : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait4_asm(u32x4 (&r)[4]) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
-}
-__device__ __forceinline__ uint32_t ld_u32_coherent_sync(const void* p) {  // load + full wait in one statement
-  uint32_t r;
-  asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ uint32_t ld_u16_coherent_sync(const void* p) {
-  uint32_t r;
-  asm volatile("global_load_ushort %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
-  return r;
-}
-__device__ __forceinline__ void st_u32_wt(void* p, uint32_t v) {
-  asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st_u16_wt(void* p, uint32_t v) {
-  asm volatile("global_store_short %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
+// The weight / KV streams use ld16_nt directly and leave the s_waitcnt bookkeeping to hipcc.  With unconditional
+// (clamped-address) loads, ping-pong register sets refilled in place and no register copies in the loop, the
+// compiler's own wait placement keeps two batches in flight (checked in the ISA: the wait for one set is
+// `vmcnt(<loads of the other set>)`).  A hand-counted inline-asm variant of these loads (cdna_hip_programming.md
+// section 5.7) was tried and measured ~1 % faster end to end, and was removed: an asm load's destination registers are
+// unprotected until the hand-written wait, and hipcc moved such registers while the data was in flight in three
+// different places during development (long prologue between issue and wait; AGPR shuffling at 256 registers; the
+// R = 2 decode-attention instance on rings wider than ~5000 slots) - silent, timing-dependent corruption.
 
 // Sum over the 64 lanes of a wave; every lane gets the total.
 __device__ __forceinline__ float wave_sum(float v) {

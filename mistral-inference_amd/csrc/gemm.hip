@@ -5,13 +5,15 @@
 // and (token-grouped form, one launch for all experts) moe.py:28-32's per-expert gather -> expert FFN.
 //
 // Both operands are K-contiguous ("B^T input"), so A and W fragments are 16-byte row slices.
-// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.  Operands are
-// staged HBM -> VGPR -> LDS (double-buffered, one barrier per K step, next tile's global loads issued
-// before the current tile's MFMAs); the LDS image is XOR-swizzled on the 16-byte slot index
-// (slot ^= row & 7) so the ds_read_b128 fragment reads are conflict-free.
+// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.  Operands go HBM -> LDS by
+// LDS-DMA (`global_load_lds_dwordx4`, double-buffered, one barrier per K step, the next tile's DMA issued before the
+// current tile's MFMAs; register staging only when K is not a multiple of 64); the LDS image is XOR-swizzled on the
+// 16-byte slot index (slot ^= row & 7) so the ds_read_b128 fragment reads are conflict-free.
 //
 // SWIGLU form: the B tile holds 64 rows of W1 and the matching 64 rows of W3, every wave accumulates
 // both for the same (token, j) and the epilogue is elementwise in registers.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -28,7 +30,7 @@ __device__ __forceinline__ const bf16_t* seg_row(const GemmArgs& g, int r) {
   return g.w2 + (size_t)(r - g.n1) * g.K;
 }
 
-template <int EPI>
+template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -67,13 +69,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     rows_valid = min(BM, g.M - row0);
   }
 
-  // ---- global -> LDS staging assignment: thread owns 16-byte slot (tid & 7) of rows (tid >> 3) + 32 j
-  const int slot = tid & 7;
+  // ---- global -> LDS staging.
+  // GLDS (K % 64 == 0): `global_load_lds_dwordx4` - the DMA writes wave-uniform base + lane * 16, i.e. one instruction
+  //   fills 8 consecutive 128-byte tile rows; wave w, instruction j covers rows (4w + j) * 8 .. + 8, lane l sits at
+  //   (row + (l >> 3), LDS slot l & 7).  The XOR swizzle the fragment reads expect is applied on the SOURCE address
+  //   (the lane fetches global slot (l & 7) ^ (row & 7)); the LDS destination stays linear (guide section 5.4 rule 21).
+  //   No staging VGPRs, no ds_write pass.
+  // otherwise: through registers; thread owns LDS slot (tid & 7) of rows (tid >> 3) + 32 j and writes it swizzled.
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int slot = GLDS ? ((lane & 7) ^ ((lane >> 3) & 7)) : (tid & 7);
   const bf16_t* arow[4];
   const bf16_t* brow[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int r = (tid >> 3) + 32 * j;
+    const int r = GLDS ? ((wu * 4 + j) * 8 + (lane >> 3)) : ((tid >> 3) + 32 * j);
     int m = row0 + min(r, rows_valid - 1);
     if (g.a_gather) m = g.a_gather[m];
     arow[j] = g.a + (size_t)m * g.lda + slot * 8;
@@ -104,6 +113,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       st16(sB + buf * TILE_BYTES + lds_off(r, slot), rb[j]);
     }
   };
+  auto dma_tile = [&](int kt, int buf) {  // GLDS: 8 async 1-KiB pieces per wave (4 of A, 4 of B)
+    const int koff = kt * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = (wu * 4 + j) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(sA + buf * TILE_BYTES + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(sB + buf * TILE_BYTES + piece), 16, 0, 0);
+    }
+  };
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -112,12 +132,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (g.K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  if (GLDS) {
+    dma_tile(0, 0);
+  } else {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();  // (with LDS-DMA in flight hipcc makes this vmcnt(0) + barrier)
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) {
+      if (GLDS) dma_tile(kt + 1, buf ^ 1);  // lands during this step's MFMAs
+      else gload(kt + 1);
+    }
     const char* a_s = sA + buf * TILE_BYTES;
     const char* b_s = sB + buf * TILE_BYTES;
     // all 16 fragment reads of this K step are issued first; hipcc's lgkmcnt ladder then lets the MFMAs of the first
@@ -146,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][mt], bfr[ks][nt], acc[mt][nt], 0, 0, 0);
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    if (!GLDS && kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
 
@@ -194,12 +221,22 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   const int supertiles = ((m_tiles + 7) / 8) * ((n_tiles + 7) / 8);
   const dim3 grid((unsigned)(((supertiles + 7) / 8) * 64 * 8)), block(256);
   const size_t lds = 4 * TILE_BYTES;
+  static int use_glds = -1;  // MI_GEMM_GLDS=0 forces the register-staged path (A/B testing)
+  if (use_glds < 0) {
+    const char* e = getenv("MI_GEMM_GLDS");
+    use_glds = e ? atoi(e) : 1;
+  }
+  const bool glds = use_glds && (g.K % BK == 0);
+#define MI_LAUNCH_GEMM(E)                                                                  \
+  if (glds) hipLaunchKernelGGL((gemm_kernel<E, true>), grid, block, lds, s, g);            \
+  else hipLaunchKernelGGL((gemm_kernel<E, false>), grid, block, lds, s, g)
   switch (g.epi) {
-    case GEMM_STORE: hipLaunchKernelGGL((gemm_kernel<GEMM_STORE>), grid, block, lds, s, g); break;
-    case GEMM_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<GEMM_RESIDUAL>), grid, block, lds, s, g); break;
-    case GEMM_SWIGLU: hipLaunchKernelGGL((gemm_kernel<GEMM_SWIGLU>), grid, block, lds, s, g); break;
-    case GEMM_LOGITS: hipLaunchKernelGGL((gemm_kernel<GEMM_LOGITS>), grid, block, lds, s, g); break;
+    case GEMM_STORE: MI_LAUNCH_GEMM(GEMM_STORE); break;
+    case GEMM_RESIDUAL: MI_LAUNCH_GEMM(GEMM_RESIDUAL); break;
+    case GEMM_SWIGLU: MI_LAUNCH_GEMM(GEMM_SWIGLU); break;
+    case GEMM_LOGITS: MI_LAUNCH_GEMM(GEMM_LOGITS); break;
     default: return hipErrorInvalidValue;
   }
+#undef MI_LAUNCH_GEMM
   return hipGetLastError();
 }

@@ -22,7 +22,7 @@ using namespace gemv_core;
 template <int TT, int MODE, int ROWS>
 __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_body<TT, MODE, ROWS, false>(a, smem, blockIdx.x, gridDim.x, blockIdx.y, NoSync{});
+  gemv_body<TT, MODE, ROWS>(a, smem, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // MoE down-projection + combine for one token per blockIdx.y (moe.py:28-32 at decode):
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   int u = blockIdx.x * 4 + wid;
   int ul = u, kl = 0, jl = 0;
   u32x4 bufA[BATCH], bufB[BATCH];
-  auto issue = [&](u32x4 (&buf)[BATCH]) {  // branch-free around the asm loads (see gemv_core.cuh)
+  auto issue = [&](u32x4 (&buf)[BATCH]) {  // branch-free around the loads (see gemv_core.cuh)
     const bool live = ul < units;
     const bf16_t* base = w2[0];
 #pragma unroll
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   int jc = 0, kc = 0;
   float r0 = 0.f, r1 = 0.f;
   auto step = [&](u32x4 (&buf)[BATCH]) {
-    vm_wait8<BATCH>(buf);
     fma_batch<1, 2>(buf, jc * U, xs + (size_t)kc * a.K, a.K, lane, acc);
     issue(buf);
     if (++jc == nb) {

@@ -1,5 +1,5 @@
 // Core of the weight-streaming GEMV (see gemv.hip for the design notes): batch loads, FMA, activation staging and the
-// per-wave unit loop, shared by the stand-alone kernels (gemv.hip) and the fused decode engine (engine.hip).
+// per-wave unit loop.
 #pragma once
 #include "common.cuh"
 #include "kernels.h"
@@ -13,28 +13,23 @@ struct Acc {
   float v[2][TT];
 };
 
-struct NoSync {
-  __device__ __forceinline__ void arrive() {}
-  __device__ __forceinline__ void wait() {}
-};
-
 struct RowPair {
   const bf16_t* a;
   const bf16_t* b;  // nullptr when the unit has one row
 };
 
-// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows: always exactly BATCH asm loads, so the
-// hand-written vmcnt counts are static.  Chunk offsets past K are clamped to the row's last 16 bytes (fma_batch
-// skips them) and a missing second row aliases the first (the epilogue drops it).  Never a `cond ? load : 0`: that
-// makes hipcc branch around each load and wait vmcnt(0) after it (cdna_hip_programming.md, ".s-level traps" (c)).
+// One batch = chunks [c0, c0 + BATCH/ROWS) of each of the unit's ROWS rows: always exactly BATCH unconditional loads.
+// Chunk offsets past K are clamped to the row's last 16 bytes (fma_batch skips them) and a missing second row aliases
+// the first (the epilogue drops it).  Never a `cond ? load : 0`: that makes hipcc branch around each load and wait
+// vmcnt(0) after it (cdna_hip_programming.md, ".s-level traps" (c)).
 template <int ROWS>
 __device__ __forceinline__ void load_batch(const RowPair& r, int c0, int K, int lane, u32x4 (&buf)[BATCH]) {
   constexpr int U = BATCH / ROWS;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int e = min(((c0 + u) * 64 + lane) * 8, K - 8);
-    ld16_asm_nt(buf[u], r.a + e);
-    if (ROWS == 2) ld16_asm_nt(buf[U + u], r.b + e);
+    buf[u] = ld16_nt(r.a + e);
+    if (ROWS == 2) buf[U + u] = ld16_nt(r.b + e);
   }
 }
 
@@ -88,9 +83,8 @@ struct XRegs {
   u32x4 w[NW > 0 ? NW : 1];
 };
 
-// Issues exactly NX + NW asm loads (clamped / dummy where there is nothing to load).  COHERENT: the activations were
-// written by other workgroups of this launch (fused engine) and are read with agent-coherent loads.
-template <int TT, int NX, int NW, bool COHERENT = false>
+// Issues exactly NX + NW loads (clamped / dummy where there is nothing to load).
+template <int TT, int NX, int NW>
 __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w) {
   const int npieces = K >> 3;
   const int total = TT * npieces;
@@ -100,28 +94,13 @@ __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int 
   for (int i = 0; i < NX; ++i) {
     const int q = min((int)threadIdx.x + i * 256, total - 1);
     const int t = q / npieces, p = q - t * npieces;
-    if (COHERENT) ld16_asm_coherent(xr.x[i], x + (size_t)min(t, T - 1) * ldx + p * 8);
-    else ld16_asm(xr.x[i], x + (size_t)min(t, T - 1) * ldx + p * 8);
-    if (i < NW) ld16_asm(xr.w[i], wsrc + p * 8);  // (norm weights are constants)
+    xr.x[i] = ld16(x + (size_t)min(t, T - 1) * ldx + p * 8);
+    if (i < NW) xr.w[i] = ld16(wsrc + p * 8);
   }
   return fits;
 }
 
-template <int NX, int NW, int AFTER>
-__device__ __forceinline__ void x_wait(XRegs<NX, NW>& xr) {
-  if constexpr (AFTER == 0) {  // fused engine: the activation loads are agent-coherent asm loads in every build
-    if constexpr (NX == 8) vm_wait8_asm<0>(xr.x);
-    if constexpr (NX == 4) vm_wait4_asm<0>(xr.x);
-    if constexpr (NW == 4) vm_wait4_asm<0>(xr.w);
-  } else {
-    if constexpr (NX == 8) vm_wait8<AFTER>(xr.x);
-    if constexpr (NX == 4) vm_wait4<AFTER>(xr.x);
-    if constexpr (NW == 4) vm_wait4<AFTER>(xr.w);
-  }
-}
-
-// AFTER = asm loads issued after the activation loads (2 * BATCH in the stand-alone kernels, 0 in the fused engine).
-template <int TT, int NX, int NW, int AFTER>
+template <int TT, int NX, int NW>
 __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red,
                                          const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w, float eps) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -129,7 +108,6 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t
   float ss[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) ss[t] = 0.f;
-  x_wait<NX, NW, AFTER>(xr);  // stand-alone: both weight batches stay in flight under the prologue
   if (in_regs) {
     const int total = TT * npieces;
 #pragma unroll
@@ -247,14 +225,9 @@ __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf1
 
 // ROWS = rows per unit (2 everywhere except the plain/residual/logits modes on small N, where single-row units
 // double the number of waves so that a 4096-row matrix still fills 256 CUs x 16 waves).
-//
-// FUSED = false: the stand-alone kernels (activation loads first, then two weight batches, prologue under them).
-// FUSED = true : inside the persistent decode engine - the two weight batches are issued FIRST (weights never depend
-// on the previous operator) between `sync.arrive()` and `sync.wait()` of a grid barrier that orders this operator
-// after the one producing its activations; the barrier wait overlaps with 16 KiB of weights in flight per wave.
-template <int TT, int MODE, int ROWS, bool FUSED, typename SYNC>
-__device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int block_id, int n_blocks, int problem,
-                                          SYNC&& sync) {
+// Order: activation loads first (L2 hits), then two weight batches, and the prologue finishes under them.
+template <int TT, int MODE, int ROWS>
+__device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int block_id, int n_blocks, int problem) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)TT * a.K * 2);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -285,21 +258,18 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   constexpr int NX = kNormMode ? 4 : 8, NW = kNormMode ? 4 : 0;
   XRegs<NX, NW> xr;
   bool in_regs = false;
-  if constexpr (!FUSED) in_regs = x_issue<TT, NX, NW>(xr, x, a.ldx, T, a.K, a.norm_w);
+  in_regs = x_issue<TT, NX, NW>(xr, x, a.ldx, T, a.K, a.norm_w);
 
   // load cursor over the flattened (unit, batch) sequence of this wave: always two batches ahead of the math
   int u = block_id * 4 + wid;
   int ul = u, jl = 0;
   RowPair rpl = unit_rows<MODE, ROWS>(a, min(ul, units - 1), e1, e3);
   u32x4 bufA[BATCH], bufB[BATCH];
-  // Past the wave's last unit `issue` loads BATCH times one L2-resident line instead, so that every wait below can
-  // use the static count "the other buffer's BATCH loads may stay in flight" (branching between counted and draining
-  // waits makes hipcc spill the buffers).  Those trailing loads are never consumed; that is safe because bufA/bufB
-  // are loop-carried (their registers are not reused inside the loop) and nothing executes after the loop.
+  // Past the wave's last unit `issue` loads BATCH times one L2-resident line instead of branching around the loads:
+  // the row pointers and chunk offset are SELECTED (real rows, or one dummy line) and the BATCH loads are issued
+  // unconditionally, which keeps the loop body one basic block and the compiler's wait for one buffer at
+  // "the other buffer's BATCH loads may stay in flight".  The trailing loads are never consumed.
   const RowPair dummy = {x, x};
-  // Branch-free around the loads: the row pointers and chunk offset are SELECTED (real rows, or one dummy line past
-  // the wave's last unit) and the BATCH asm loads are issued unconditionally - no control-flow merge ever sits
-  // between an asm load and its wait, so hipcc has no reason to copy a register whose data is still in flight.
   auto issue = [&](u32x4 (&buf)[BATCH]) {
     const bool live = ul < units;
     RowPair r;
@@ -312,21 +282,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
       if (ul < units) rpl = unit_rows<MODE, ROWS>(a, ul, e1, e3);
     }
   };
-  if constexpr (FUSED) sync.arrive();  // this block's stores of the previous operator are published ...
-  issue(bufA);                          // ... the next operator's weights start streaming ...
+  issue(bufA);
   issue(bufB);
-  if constexpr (FUSED) {
-    sync.wait();                        // ... and only then do we wait for everybody else's stores
-    // The two batches have been in flight for the whole barrier.  Make them architecturally "landed" before any
-    // other code runs: an asm load's destination is unprotected until its wait (guide section 5.7 item 1), and the
-    // staging code below is long enough for the register allocator to move those registers around.
-    vm_wait8<0>(bufA);
-    vm_wait8<0>(bufB);
-    in_regs = x_issue<TT, NX, NW, true>(xr, x, a.ldx, T, a.K, a.norm_w);
-    x_finish<TT, NX, NW, 0>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
-  } else {
-    x_finish<TT, NX, NW, 2 * BATCH>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
-  }
+  x_finish<TT, NX, NW>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
 
   Acc<TT> acc;
 #pragma unroll
@@ -341,7 +299,6 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   float2 ep_cs = make_float2(1.f, 0.f);
   uint32_t ep_res = 0;
   auto prefetch_epilogue = [&](int uu) {
-    if constexpr (FUSED) return;  // (fused engine: these operands are written by other workgroups; read late, coherently)
     const int r0 = (ROWS == 2) ? 2 * uu : uu;
     if (MODE == GEMV_QKV_ROPE && r0 < a.n1) {
       const int i = (r0 % a.head_dim) >> 1;
@@ -374,8 +331,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
       const int t = lane;
       if (MODE == GEMV_SWIGLU || MODE == GEMV_MOE_W13) {
         bf16_t* o = reinterpret_cast<bf16_t*>(outp) + (size_t)t * a.ldo + u;
-        if (FUSED) st_u16_wt(o, f_to_bf_bits(swiglu_bf(v0, v1)));
-        else *o = f_to_bf(swiglu_bf(v0, v1));
+        *o = f_to_bf(swiglu_bf(v0, v1));
       } else {
         const int r0 = (ROWS == 2) ? 2 * u : u;
         const bool two = (ROWS == 2) && (r0 + 1 < a.N);
@@ -387,26 +343,13 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
           float y0 = bf_round(v0), y1 = bf_round(v1);
           bf16_t* o = reinterpret_cast<bf16_t*>(outp) + (size_t)t * a.ldo + r0;
           if (MODE == GEMV_RESIDUAL) {
-            const bf16_t* rs = a.residual + (size_t)t * a.ldo + r0;
-            if (!FUSED) {
-              y0 = bf_lo(ep_res) + y0;
-              if (two) y1 = bf_hi(ep_res) + y1;
-            } else if (FUSED) {  // the residual stream was written by other workgroups of this launch
-              if (two) {
-                const uint32_t rr = ld_u32_coherent_sync(rs);
-                y0 = bf_lo(rr) + y0;
-                y1 = bf_hi(rr) + y1;
-              } else {
-                y0 = bf_lo(ld_u16_coherent_sync(rs)) + y0;
-              }
-            }
+            y0 = bf_lo(ep_res) + y0;
+            if (two) y1 = bf_hi(ep_res) + y1;
           }
           if (MODE == GEMV_QKV_ROPE) {
-            const int pos = FUSED ? a.tok_pos[t] : ep_pos;
+            const int pos = ep_pos;
             if (r0 < a.n1) {  // q or k rows: rotate the adjacent pair (rope.py:13-23)
-              const int i = (r0 % a.head_dim) >> 1;
-              float2 cs = ep_cs;
-              if (FUSED) cs = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (a.head_dim >> 1) + i) * 2);
+              const float2 cs = ep_cs;
               const float re = __fsub_rn(__fmul_rn(y0, cs.x), __fmul_rn(y1, cs.y));
               const float im = __fadd_rn(__fmul_rn(y0, cs.y), __fmul_rn(y1, cs.x));
               y0 = re;
@@ -421,10 +364,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
               *reinterpret_cast<uint32_t*>(ring) = pack_bf2(y0, y1);
             }
           }
-          if (FUSED) {
-            if (two) st_u32_wt(o, pack_bf2(y0, y1));
-            else st_u16_wt(o, f_to_bf_bits(y0));
-          } else if (two) {
+          if (two) {
             *reinterpret_cast<uint32_t*>(o) = pack_bf2(y0, y1);
           } else {
             o[0] = f_to_bf(y0);
@@ -439,7 +379,6 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   // One step = consume the oldest batch, refill the same registers with the batch two ahead (ping-pong between
   // bufA and bufB: no register copies, so the compiler's wait for bufA leaves bufB's eight loads in flight).
   auto step = [&](u32x4 (&buf)[BATCH]) {
-    vm_wait8<BATCH>(buf);  // the other buffer's BATCH loads were issued after this one's and may stay in flight
     fma_batch<TT, ROWS>(buf, jc * U, xs, a.K, lane, acc);
     issue(buf);
     if (++jc == nb) {
@@ -453,12 +392,6 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
     step(bufA);
     if (u < units) step(bufB);
   }
-  if constexpr (FUSED) {
-    // code follows this operator: the trailing (dummy) loads must have landed before their registers are reused
-    vm_wait8<0>(bufA);
-    vm_wait8<0>(bufB);
-  }
 }
-
 
 }  // namespace gemv_core

@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
-timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -q -p no:cacheprovider --timeout 900 -x > gpurun_out/pytest_gpu.log 2>&1
+timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 -x > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -n 3 gpurun_out/pytest_gpu.log
 timeout 900 python bench.py --steps 32 --warmup 4 --no-cpu-baseline > gpurun_out/bench.log 2>&1

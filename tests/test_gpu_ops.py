@@ -62,7 +62,7 @@ def _lin_ref(x, ws):
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 9, 64, 200])
-@pytest.mark.parametrize("K,N", [(256, 512), (4096, 1024), (1024, 4096)])
+@pytest.mark.parametrize("K,N", [(256, 512), (4096, 1024), (1024, 4096), (14336, 512)])
 def test_linear_store(M, K, N):
     h = _hip()
     x, w = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=1 / math.sqrt(K))
@@ -142,7 +142,7 @@ def _ring_case(B, W, Hkv, Dh, lens, seed):
 
 
 @pytest.mark.parametrize("H,Hkv", [(4, 2), (32, 8), (8, 8), (12, 2), (16, 2)])
-@pytest.mark.parametrize("W,lens", [(16, [5, 16, 40]), (300, [1, 299, 300]), (4096, [4096, 17, 5000])])
+@pytest.mark.parametrize("W,lens", [(16, [5, 16, 40]), (300, [1, 299, 300]), (4096, [4096, 17, 5000]), (9000, [9000, 5000])])
 def test_attn_decode(H, Hkv, W, lens):
     """lens[b] = tokens seen INCLUDING the new one (already in the ring)."""
     h = _hip()
@@ -160,6 +160,25 @@ def test_attn_decode(H, Hkv, W, lens):
     # the arrival counters must be left at zero: a second call gives the same answer
     again = h.attn_decode(q.cuda(), ck.cuda(), cv.cuda(), H, pos.cuda()).cpu()
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("H,Hkv", [(4, 2), (4, 4), (32, 8), (12, 2)])
+@pytest.mark.parametrize("W", [5000, 8192, 16384])
+def test_attn_decode_wide_ring_constant_v(H, Hkv, W):
+    """V == 1 everywhere: softmax weights sum to one, so every output element must be exactly 1.0 whatever K is, and
+    two launches must agree bit for bit.  A size-independent property for rings the oracle is too slow for; it is the
+    case that exposed in-flight register corruption in an earlier hand-scheduled load variant."""
+    h = _hip()
+    g = torch.Generator().manual_seed(W + H)
+    ck = torch.randn(1, W, Hkv, 128, generator=g).to(BF).cuda()
+    cv = torch.ones(1, W, Hkv, 128, dtype=BF).cuda()
+    q = torch.randn(1, H * 128, generator=g).to(BF).cuda()
+    for n in (W, W // 2 + 3, 3 * W):
+        pos = torch.tensor([n - 1], dtype=torch.int32).cuda()
+        a = h.attn_decode(q, ck, cv, H, pos)
+        b = h.attn_decode(q, ck, cv, H, pos)
+        assert torch.equal(a, b)
+        assert bool((a.float() == 1.0).all()), (n, float((a.float() - 1).abs().max()))
 
 
 @pytest.mark.parametrize("H,Hkv", [(4, 2), (32, 8)])
