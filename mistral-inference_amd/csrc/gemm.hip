@@ -215,6 +215,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.K % 8 != 0 || g.M <= 0 || g.N <= 0) return hipErrorInvalidValue;
+  static int use_256 = -1;  // MI_GEMM_256=0 keeps every shape on the 128x128 kernel (A/B testing)
+  if (use_256 < 0) {
+    const char* e = getenv("MI_GEMM_256");
+    use_256 = e ? atoi(e) : 1;
+  }
+  if (use_256 && gemm256_applicable(g)) return launch_gemm256(g, s);
   const int m_tiles = g.tile_tab ? g.max_m_tiles : (g.M + BM - 1) / BM;
   const int nout = (g.epi == GEMM_SWIGLU) ? 64 : 128;
   const int n_tiles = (g.N + nout - 1) / nout;

@@ -1,0 +1,353 @@
+// bf16 MFMA GEMM, 256x256x64 block tile, for the large prefill shapes: out[M,N] = epilogue(A[M,K] . W[N,K]^T).
+//
+// Same contract and epilogues as gemm.hip (transformer_layers.py:66,93,105-106; transformer.py:235); launch_gemm
+// picks this kernel when M >= 256, K % 64 == 0 and the problem is not the token-grouped MoE form.
+//
+// Why a second tile shape: the 128x128 kernel moves 32 KiB of operands through LDS per 128x128x64 MACs and is bound by
+// LDS bandwidth (DMA writes ~64-85 B/clk + fragment reads 256 B/clk against 16 clk per MFMA): ~37 % of the MFMA peak.
+// 256x256 halves the LDS bytes per flop.  Structure (cdna_hip_programming.md section 5, "256^2 8-phase template",
+// written from its description):
+//   * 8 waves = 2 (M) x 4 (N); a wave owns 64 rows of each 128-row A half and 32 columns of each 128-column B half,
+//     i.e. four 64x32 quadrants (ha, hb), 16 MFMA 16x16x32 each per K tile;
+//   * LDS = 2 stages x {A0, A1, B0, B1} x 16 KiB half tiles (128 rows x 128 B, 16-byte slot XOR-swizzled by row & 7,
+//     the swizzle applied on the DMA's SOURCE address);
+//   * one K tile = 4 phases, one quadrant each.  A phase (a) re-stages ONE half tile whose last reader finished a
+//     phase earlier (2 `global_load_lds_dwordx4` per lane), (b) reads the fragments it is missing, (c) lgkmcnt(0) +
+//     raw s_barrier, (d) 16 MFMAs.  The DMAs are never drained inside the loop: the single `s_waitcnt vmcnt(6)` per
+//     K tile (phase 4) retires the NEXT tile's four halves and leaves the three halves issued after them in flight
+//     across the barrier.
+// Hazards, by construction:  RAW - tile t+1's halves are waited for (vmcnt) by every wave BEFORE phase 4's barrier and
+// first read AFTER it.  WAR - a half is re-staged in the phase after the one whose barrier followed its last reads
+// (lgkmcnt(0) precedes every barrier).
+#include <cstdlib>
+
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB: 128 rows x 128 B
+constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 KiB
+
+__device__ __forceinline__ const bf16_t* seg_row256(const GemmArgs& g, int r) {
+  if (r < g.n0) return g.w0 + (size_t)r * g.K;
+  if (r < g.n1) return g.w1 + (size_t)(r - g.n0) * g.K;
+  return g.w2 + (size_t)(r - g.n1) * g.K;
+}
+
+__device__ __forceinline__ void dma16(const bf16_t* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_barrier is not a memory operation for the compiler: the asm statements (memory clobber) on both sides keep every
+// LDS read and every DMA on its side of the barrier.
+__device__ __forceinline__ void raw_barrier() {
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_reads_done_then_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+}
+
+template <int EPI, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NOUT = (EPI == GEMM_SWIGLU) ? 128 : 256;  // output columns per block
+  // bf16 outputs: MFMAs issued as W-fragment x A-fragment (transposed 16x16 result tiles, see the epilogue); fp32
+  // logits: A x W, whose 4-byte stores already cover 64-byte row segments and measured faster than 16-byte ones.
+  constexpr bool kSwap = EPI != GEMM_LOGITS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  // ---- block -> tile.  Block b runs on XCD b % 8; a 4 (m) x 8 (n) supertile = the 32 blocks one XCD runs at a time
+  // stays on one XCD so that its blocks share 4 A panels and 8 W panels in that XCD's L2 (guide T1; speed only).
+  const int m_tiles = (g.M + 255) >> 8, n_tiles = (g.N + NOUT - 1) / NOUT;
+  const int MS = (m_tiles + 3) >> 2, NS = (n_tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int st = (q >> 5) * 8 + xcd, wi = q & 31;
+  if (st >= MS * NS) return;
+  const int m_tile = (st % MS) * 4 + (wi & 3), n_tile = (st / MS) * 8 + (wi >> 2);
+  if (m_tile >= m_tiles || n_tile >= n_tiles) return;
+  const int row0 = m_tile * 256;
+
+  // ---- DMA sources.  One instruction fills 8 consecutive 128-B rows of a half tile; wave w, piece j covers rows
+  // (2w + j) * 8 .. + 8; lane l lands at (row + (l >> 3), slot l & 7) and fetches global slot (l & 7) ^ (row & 7).
+  const int sslot = (lane & 7) ^ ((lane >> 3) & 7);
+  const bf16_t* src[4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wid * 2 + j) * 8 + (lane >> 3);
+      const int m = min(row0 + h * 128 + r, g.M - 1);
+      src[h][j] = g.a + (size_t)m * g.lda + sslot * 8;
+      if (EPI == GEMM_SWIGLU) {
+        const int n = min(n_tile * 128 + r, g.N - 1);
+        src[2 + h][j] = (h == 0 ? g.w0 : g.w1) + (size_t)n * g.K + sslot * 8;
+      } else {
+        const int n = min(n_tile * 256 + h * 128 + r, g.N - 1);
+        src[2 + h][j] = seg_row256(g, n) + sslot * 8;
+      }
+    }
+  char* const my_piece = smem + wid * 2048;  // this wave's two 1-KiB pieces inside any half tile
+#define STAGE_HALF(HALF, KT, STAGE)                                                              \
+  do {                                                                                           \
+    char* dst_ = my_piece + (STAGE) * STAGE_BYTES + (HALF) * HALF_BYTES;                         \
+    dma16(src[HALF][0] + (size_t)(KT) * BK, dst_);                                               \
+    dma16(src[HALF][1] + (size_t)(KT) * BK, dst_ + 1024);                                        \
+  } while (0)
+
+  // ---- fragment addressing (MFMA 16x16x32: lane holds row lane & 15, k = (lane >> 4) * 8 .. + 8 of each 32-wide k step)
+  const int fq = lane >> 4;
+  const int sw0 = ((fq) ^ (lane & 7)) << 4, sw1 = ((4 + fq) ^ (lane & 7)) << 4;
+  const int a_off = (wr * 64 + (lane & 15)) * 128;
+  const int b_off = 2 * HALF_BYTES + (wc * 32 + (lane & 15)) * 128;
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[2][4];      // [k step][row fragment] of the A half in use
+  bf16x8 bfr[2][2][2];  // [B half][k step][column fragment]
+
+#define READ_A(HA, SB)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+    af[0][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + sw0)); \
+    af[1][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + sw1)); \
+  }
+#define READ_B(HB, SB)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
+    bfr[HB][0][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((SB) + (HB) * HALF_BYTES + b_off + j * 2048 + sw0)); \
+    bfr[HB][1][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((SB) + (HB) * HALF_BYTES + b_off + j * 2048 + sw1)); \
+  }
+#define SEGMENT_END()                          \
+  do {                                         \
+    lds_reads_done_then_barrier();             \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+#define MFMA_END()                             \
+  do {                                         \
+    if (STAGGER) {                             \
+      __builtin_amdgcn_sched_barrier(0);       \
+      raw_barrier();                           \
+      __builtin_amdgcn_sched_barrier(0);       \
+    }                                          \
+  } while (0)
+#define MFMA_QUAD(HA, HB)                                                                                       \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+    acc[HA][HB][i][j] = kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[HB][ks][j], af[ks][i], acc[HA][HB][i][j], 0, 0, 0) \
+                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[HB][ks][j], acc[HA][HB][i][j], 0, 0, 0);
+
+  const int nk = g.K / BK;
+  // ---- prologue: all of tile 0, then A0 B0 B1 of tile 1 (its A1 is staged by phase 1 of tile 0)
+  STAGE_HALF(0, 0, 0);
+  STAGE_HALF(2, 0, 0);
+  STAGE_HALF(3, 0, 0);
+  STAGE_HALF(1, 0, 0);
+  if (nk > 1) {
+    STAGE_HALF(0, 1, 1);
+    STAGE_HALF(2, 1, 1);
+    STAGE_HALF(3, 1, 1);
+    wait_vm<6>();
+  } else {
+    wait_vm<0>();
+  }
+  raw_barrier();
+  // Every phase is two segments, [stage + fragment reads] | barrier | [16 MFMAs] | barrier.  The wr = 1 waves run one
+  // barrier behind the wr = 0 waves (each SIMD hosts one wave of either group), so while one wave of a SIMD issues
+  // its MFMAs the other one does its LDS reads, and the matrix pipe never waits for a read segment.  The hazard
+  // rules of the header still hold with one barrier of slack less: a half tile is re-staged in the read segment after
+  // the one (two barriers earlier for the same wave, one for the other group) in which it was last read, and tile
+  // t + 1 is waited for in phase 4's first segment and read two barriers later.
+  if (STAGGER && wr == 1) raw_barrier();
+
+  for (int t = 0; t < nk; ++t) {
+    const int s = t & 1;
+    const char* sb = smem + s * STAGE_BYTES;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // phase 1: quadrant (0, 0)
+    if (more1) STAGE_HALF(1, t + 1, s ^ 1);  // A1 of the other stage: last read in phase 3 of tile t - 1
+    READ_B(0, sb)
+    READ_A(0, sb)
+    SEGMENT_END();
+    MFMA_QUAD(0, 0)
+    MFMA_END();
+    // phase 2: quadrant (0, 1)
+    if (more2) STAGE_HALF(0, t + 2, s);  // A0: read in phase 1
+    READ_B(1, sb)
+    SEGMENT_END();
+    MFMA_QUAD(0, 1)
+    MFMA_END();
+    // phase 3: quadrant (1, 1)
+    if (more2) STAGE_HALF(2, t + 2, s);  // B0: read in phase 1
+    READ_A(1, sb)
+    SEGMENT_END();
+    MFMA_QUAD(1, 1)
+    MFMA_END();
+    // phase 4: quadrant (1, 0); retire tile t + 1 (everything issued before the last three halves)
+    if (more2) {
+      STAGE_HALF(3, t + 2, s);  // B1: read in phase 2
+      wait_vm<6>();
+    } else {
+      wait_vm<0>();
+    }
+    SEGMENT_END();
+    MFMA_QUAD(1, 0)
+    MFMA_END();
+  }
+  if (STAGGER && wr == 0) raw_barrier();
+#undef STAGE_HALF
+#undef READ_A
+#undef READ_B
+#undef MFMA_QUAD
+#undef SEGMENT_END
+#undef MFMA_END
+
+  if constexpr (!kSwap) {
+    // acc[ha][hb][i][j][r]: tile row ha*128 + wr*64 + i*16 + (lane>>4)*4 + r, tile column hb*128 + wc*32 + j*16 + (lane & 15)
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + ha * 128 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+          if (row >= g.M) continue;
+          float* o = reinterpret_cast<float*>(g.out) + (size_t)row * g.ldo;
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = n_tile * 256 + hb * 128 + wc * 32 + j * 16 + (lane & 15);
+              if (n < g.N) o[n] = bf_round(acc[ha][hb][i][j][r]);
+            }
+        }
+    return;
+  }
+  // ---- epilogue.  The MFMAs were issued as W-fragment x A-fragment, i.e. they produced the transposed 16x16 tiles:
+  // acc[ha][hb][i][j][r] is tile row ha*128 + wr*64 + i*16 + (lane & 15), tile column hb*128 + wc*32 + j*16 +
+  // (lane >> 4)*4 + r - four CONSECUTIVE output columns per lane, so results (and the residual) move as 8-byte
+  // (bf16) / 16-byte (fp32 logits) accesses instead of 2-byte ones.
+  const int cq = (lane >> 4) * 4;
+  const bool wide_ok = (g.ldo & 3) == 0 && (reinterpret_cast<size_t>(g.out) & 15) == 0 &&
+                       (EPI != GEMM_RESIDUAL || (reinterpret_cast<size_t>(g.residual) & 7) == 0);
+#pragma unroll
+  for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + ha * 128 + wr * 64 + i * 16 + (lane & 15);
+      if (row >= g.M) continue;
+      const size_t ob = (size_t)row * g.ldo;
+      if (EPI == GEMM_SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n_tile * 128 + wc * 32 + j * 16 + cq;
+          float y[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = swiglu_bf(acc[ha][0][i][j][r], acc[ha][1][i][j][r]);
+          bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + ob + n;
+          if (n + 3 < g.N && wide_ok) {
+            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < g.N) o[r] = f_to_bf(y[r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = n_tile * 256 + hb * 128 + wc * 32 + j * 16 + cq;
+            if (n >= g.N) continue;
+            const bool full = (n + 3 < g.N) && wide_ok;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = bf_round(acc[ha][hb][i][j][r]);
+            if (EPI == GEMM_LOGITS) {
+              float* o = reinterpret_cast<float*>(g.out) + ob + n;
+              if (full) {
+                *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (n + r < g.N) o[r] = y[r];
+              }
+            } else {
+              bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + ob + n;
+              if (full) {
+                if (EPI == GEMM_RESIDUAL) {
+                  const uint2 rs = *reinterpret_cast<const uint2*>(g.residual + ob + n);
+                  y[0] += bf_lo(rs.x); y[1] += bf_hi(rs.x); y[2] += bf_lo(rs.y); y[3] += bf_hi(rs.y);
+                }
+                *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (n + r < g.N) o[r] = f_to_bf(EPI == GEMM_RESIDUAL ? bf_to_f(g.residual[ob + n + r]) + y[r] : y[r]);
+              }
+            }
+          }
+      }
+    }
+}
+
+template <int EPI, bool STAGGER>
+hipError_t launch_var(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, STAGGER>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<EPI, STAGGER>), grid, dim3(512), LDS_BYTES, s, g);
+  return hipGetLastError();
+}
+template <int EPI>
+hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  static int stagger = -1;  // MI_GEMM_STAGGER=0: both wave groups in lockstep (A/B testing)
+  if (stagger < 0) {
+    const char* e = getenv("MI_GEMM_STAGGER");
+    stagger = e ? atoi(e) : 1;
+  }
+  return stagger ? launch_var<EPI, true>(g, grid, s) : launch_var<EPI, false>(g, grid, s);
+}
+
+}  // namespace
+
+bool gemm256_applicable(const GemmArgs& g) {
+  return g.tile_tab == nullptr && g.a_gather == nullptr && g.M >= 256 && g.K % BK == 0 && g.K >= 2 * BK;
+}
+
+hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s) {
+  const int nout = (g.epi == GEMM_SWIGLU) ? 128 : 256;
+  const int m_tiles = (g.M + 255) >> 8, n_tiles = (g.N + nout - 1) / nout;
+  const int supertiles = ((m_tiles + 3) >> 2) * ((n_tiles + 7) >> 3);
+  const dim3 grid((unsigned)(((supertiles + 7) / 8) * 8 * 32));
+  switch (g.epi) {
+    case GEMM_STORE: return launch_one<GEMM_STORE>(g, grid, s);
+    case GEMM_RESIDUAL: return launch_one<GEMM_RESIDUAL>(g, grid, s);
+    case GEMM_SWIGLU: return launch_one<GEMM_SWIGLU>(g, grid, s);
+    case GEMM_LOGITS: return launch_one<GEMM_LOGITS>(g, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -80,6 +80,8 @@ struct GemmArgs {
   const int32_t* a_gather;        // device: A row of compact row r is a[a_gather[r]] (nullptr: a[r])
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+bool gemm256_applicable(const GemmArgs& g);  // gemm256.hip: 256x256 tile for the large prefill shapes
+hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- attention
 struct AttnDecodeArgs {

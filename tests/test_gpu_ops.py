@@ -114,6 +114,43 @@ def test_linear_residual_swiglu_logits(M):
     assert bf16_ulp_close(got, F.linear(x, w1).float(), ulps=1.0)[0]
 
 
+@pytest.mark.parametrize("M", [256, 300, 1030])
+@pytest.mark.parametrize("K,N", [(128, 256), (512, 640), (4096, 1024)])
+def test_linear_large_tile(M, K, N):
+    """M >= 256 takes the 256x256 LDS-DMA kernel (gemm256.hip): every epilogue, ragged M and N edges, q|k|v style row
+    segments, and a repeated-launch screen (the K loop keeps DMAs in flight across barriers; a hazard there would show
+    up as run-to-run differences)."""
+    h = _hip()
+    x = rnd(M, K, seed=30)
+    n0 = N // 2
+    ws = [rnd(n0, K, seed=31, scale=1 / math.sqrt(K)), rnd(N - n0 - 64, K, seed=32, scale=1 / math.sqrt(K)),
+          rnd(64, K, seed=33, scale=1 / math.sqrt(K))]
+    ws[0][5, :] += 0.25
+    xc, wc = x.cuda(), tuple(w.cuda() for w in ws)
+    ref = _lin_ref(x, ws)
+    got = h.linear(xc, wc, h.EPI_STORE)
+    ok, err = bf16_ulp_close(got.cpu(), ref.to(BF), ulps=1.0)
+    assert ok, err
+    for _ in range(10):
+        assert torch.equal(h.linear(xc, wc, h.EPI_STORE), got)
+    # logits
+    lg = h.linear(xc, wc, h.EPI_LOGITS).cpu()
+    assert lg.dtype == torch.float32 and torch.equal(lg.to(BF), got.cpu())
+    # residual
+    res = rnd(M, N, seed=34)
+    y = ref.to(BF)
+    r2 = (res + y).float()
+    g2 = h.linear(xc, wc, h.EPI_RESIDUAL, residual=res.cuda()).cpu().float()
+    scale = torch.maximum(torch.maximum(res.float().abs(), y.float().abs()), r2.abs())
+    assert bool(((g2 - r2).abs() <= 1.5 * scale * 2.0 ** -7 + 1e-6).all())
+    # swiglu: W1 = first N/2 rows... use two equal-height matrices
+    w1, w3 = rnd(N, K, seed=35, scale=1 / math.sqrt(K)), rnd(N, K, seed=36, scale=1 / math.sqrt(K))
+    r3 = (F.silu(F.linear(x, w1)) * F.linear(x, w3)).float()
+    g3 = h.linear(xc, (w1.cuda(), w3.cuda()), h.EPI_SWIGLU).cpu().float()
+    e3 = (g3 - r3).abs()
+    assert bool((e3 <= 4 * r3.abs() * 2.0 ** -7 + 8e-3).all()), float(e3.max())
+
+
 @pytest.mark.parametrize("M", [1, 4])
 def test_linear_fused_norm(M):
     h = _hip()
