@@ -224,6 +224,9 @@ int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, con
   if (!out || !qkv || B <= 0 || max_q_len <= 0 || W <= 0) return fail(MI_ERR_ARG, "mi_attn_prefill");
   if (causal && (!q_start || !kv_before)) return fail(MI_ERR_ARG, "mi_attn_prefill: metadata");
   if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
+  // the kernel forms 32-bit element offsets inside one ring (W * kv_dim) and inside the activation matrix (rows * ld)
+  if ((size_t)W * n_kv_heads * head_dim >= (1ull << 31) || (size_t)B * max_q_len * (size_t)ld >= (1ull << 31))
+    return fail(MI_ERR_UNSUPPORTED, "mi_attn_prefill: ring or activation matrix larger than 2^31 elements");
   AttnPrefillArgs a;
   a.out = out; a.qkv = (const bf16_t*)qkv; a.ld = ld; a.cache_k = (const bf16_t*)cache_k; a.cache_v = (const bf16_t*)cache_v;
   a.W = W; a.B = B; a.max_q_len = max_q_len; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim;

@@ -17,6 +17,8 @@
 // K tile: row-major in LDS, 16-byte slots XOR-swizzled by (key & 15) -> conflict-free ds_read_b128.
 // V tile: transposed on the way in (4 keys x 8 d per thread, register transpose, ds_write_b64), row
 // stride 136 B -> conflict-free ds_read_b64.
+#include <type_traits>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -34,10 +36,19 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
   char* Ks = smem;
   char* Vt = smem + KS_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // provably wave-uniform: everything derived from it (this wave's query range, `skip`, `full`) becomes scalar control
+  // flow; with a VGPR-derived wave id hipcc predicated the 32-score masking code lane by lane on every tile.
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hf = lane >> 5, ql = lane & 31;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int R = a.H / a.Hkv, kvh = h / R;
+  // Block -> (query tile, head).  Workgroup i runs on XCD i % 8 and every XCD has its own L2: consecutive ids cycle
+  // through the KV heads (id % Hkv), so with Hkv = 8 all blocks of one KV head share one XCD and its K/V (2 KiB per
+  // position) stays L2-resident instead of every XCD streaming all heads.  Within a KV head the heaviest query tiles
+  // (causal work grows with the tile index) are handed out first so that short ones fill the tail of the launch.
+  const int R = a.H / a.Hkv;
+  const int kvh = blockIdx.x % a.Hkv, wq = blockIdx.x / a.Hkv;
+  const int n_qt = gridDim.x / a.H;
+  const int qt = n_qt - 1 - wq / R, h = kvh * R + wq % R, b = blockIdx.y;
   const int nq_cols = a.H * DH, kv_dim = a.Hkv * DH;
 
   int row0, s_b, p_b;
@@ -97,22 +108,35 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
   const bf16_t* ring_v0 = a.cache_v ? a.cache_v + ((size_t)b * W) * kv_dim + (size_t)kvh * DH : a.qkv;
   const bf16_t* act_k0 = a.qkv + nq_cols + (size_t)kvh * DH;
   const bf16_t* act_v0 = act_k0 + kv_dim;
-  auto key_ptr = [&](int kp, bool is_v) -> const bf16_t* {
-    const int slot = (kp < p_b) ? (kp % W) : 0;                  // only cached keys live in the ring
-    const int arow = (kp < p_b) ? 0 : (row0 + kp - p_b);
-    const bf16_t* r = (is_v ? ring_v0 : ring_k0) + (size_t)slot * kv_dim;
-    const bf16_t* x = (is_v ? act_v0 : act_k0) + (size_t)arow * a.ld;
-    return (kp < p_b) ? r : x;
-  };
-  auto gload = [&](int it) {
+  // kp % W costs ~17 VALU instructions per load when done per lane (there is no integer divide); the tile's first key
+  // is wave-uniform, so the modulo is taken ONCE per tile on the scalar side and a lane only adds its key offset and
+  // wraps (offsets are < 64: one conditional subtract when W >= 64, the general modulo only for toy windows).
+  // Element offsets are 32-bit: slot * kv_dim < W * kv_dim and row * ld < T * ld are checked on the host (< 2^31).
+  const bool big_w = W >= KT;
+  auto gload_impl = [&](int it, auto big) {
+    constexpr bool BIG = decltype(big)::value;
     const int t_lo = kp_lo + it * KT;
+    const int slot_lo = __builtin_amdgcn_readfirstlane(t_lo % W);
+    auto key_off = [&](int kp) -> int {  // element offset relative to the ring / activation base
+      int slot = slot_lo + (kp - t_lo);
+      if constexpr (BIG) slot = (slot >= W) ? slot - W : slot;
+      else slot = kp % W;
+      const int arow = row0 + kp - p_b;
+      return (kp < p_b) ? slot * kv_dim : arow * a.ld;
+    };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int kpk = min(t_lo + k_key0 + 16 * j, kp_hi);
-      rk[j] = ld16(key_ptr(kpk, false) + k_slot * 8);
+      const bf16_t* kb = (kpk < p_b) ? ring_k0 : act_k0;
+      rk[j] = ld16(kb + key_off(kpk) + k_slot * 8);
       const int kpv = min(t_lo + v_kq * 4 + j, kp_hi);
-      rv[j] = ld16(key_ptr(kpv, true) + v_ds * 8);
+      const bf16_t* vb = (kpv < p_b) ? ring_v0 : act_v0;
+      rv[j] = ld16(vb + key_off(kpv) + v_ds * 8);
     }
+  };
+  auto gload = [&](int it) {  // one scalar branch per tile instead of one per load
+    if (big_w) gload_impl(it, std::true_type{});
+    else gload_impl(it, std::false_type{});
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -133,12 +157,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
     }
   };
 
-  // No register prefetch of the next tile: it would push the kernel past 256 registers, i.e. to one wave per SIMD.
-  // Two resident blocks per CU (2 waves per SIMD) hide each other's staging latency and barriers instead.
+  // Split staging (guide T14): the NEXT tile's global loads are issued before this tile's math and sit in registers
+  // (rk/rv) until the barrier that ends the tile; only then are they written to LDS.  HBM/L2 latency is hidden under
+  // the MFMAs instead of being exposed once per tile.
+  gload(0);
+  lstore();
+  __syncthreads();
   for (int it = 0; it < n_tiles; ++it) {
-    gload(it);
-    lstore();
-    __syncthreads();
+    if (it + 1 < n_tiles) gload(it + 1);
 
     const int t_lo = kp_lo + it * KT;
     const int t_hi = min(t_lo + KT - 1, kp_hi);
@@ -159,44 +185,57 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
           st[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[mb], 0, 0, 0);
         }
       }
-      // ---- mask, online softmax (this lane: query ql, keys of its half)
+      // ---- mask, online softmax (this lane: query ql, keys of its half).  Scores stay RAW (unscaled): the
+      // 1/sqrt(d) * log2(e) factor is folded into the exponent's fma, p = exp2(s * sc - m * sc).
       const bool full = a.causal ? (t_hi <= qp_w_lo && t_lo > qp_w_hi - W && t_lo + KT - 1 <= kp_hi) : (t_lo + KT - 1 <= kp_hi);
+      // visible keys of this lane's query: vis_lo < kp <= vis_hi
+      const int vis_hi = a.causal ? min(kp_hi, qp) : kp_hi;
+      const int vis_lo = a.causal ? qp - W : -1;
+      if (!full) {  // ONE scalar branch around the whole masking pass (diagonal / window-edge / ragged tiles only)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kp = t_lo + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const bool vis = (kp <= vis_hi) & (kp > vis_lo);
+            st[mb][r] = vis ? st[mb][r] : -INFINITY;
+          }
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float s = st[mb][r] * sc;
-          if (!full) {
-            const int kp = t_lo + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const bool vis = (kp <= kp_hi) && (!a.causal || (kp <= qp && kp > qp - W));
-            s = vis ? s : -INFINITY;
-          }
-          st[mb][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);
-      const bool moved = m_new != m_run;
-      m_run = m_new;
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[mb][r]);
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // max with lane ^ 32 (guide T12)
+      }
+      // Deferred rescale (guide T13): keep the old running max while no lane's maximum grew by more than 2^8 in the
+      // exponent domain - P is then bounded by 256 instead of 1, which bf16/fp32 hold without loss of relative
+      // precision - and skip the 64-multiply rescale of O.  The decision is wave-uniform, taken before this tile's
+      // P.V, and l and O always see the same factor.
+      const float m_cand = fmaxf(m_run, mx);
+      float alpha = 1.0f;
+      if (__any((m_cand - m_run) * sc > 8.0f)) {
+        alpha = fast_exp2((m_run - m_cand) * sc);
+        m_run = m_cand;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+      }
+      const float nm = -m_run * sc;
       float psum = 0.f;
       uint32_t pb[2][2][4];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float p0 = fast_exp2(st[mb][r] - m_new), p1 = fast_exp2(st[mb][r + 1] - m_new);
+          const float p0 = fast_exp2(fmaf(st[mb][r], sc, nm)), p1 = fast_exp2(fmaf(st[mb][r + 1], sc, nm));
           psum += p0 + p1;
           pb[mb][r >> 3][(r & 7) >> 1] = cvt_pk_bf16(p0, p1);
         }
       l_run = l_run * alpha + psum;
-      if (__any(moved)) {  // exact: when no lane's running max moved, every alpha is 1 and the rescale is a no-op
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-      }
       // ---- O^T += V^T . P^T
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
@@ -215,11 +254,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
           }
         }
     }
-    __syncthreads();
+    __syncthreads();  // every wave is done reading this tile
+    if (it + 1 < n_tiles) {
+      lstore();
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*128 + d]
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);  // (once per block: not worth a permlane)
   if (wave_active && qi < s_b) {
     const float inv = 1.0f / l_tot;
     bf16_t* orow = reinterpret_cast<bf16_t*>(a.out) + (size_t)(row0 + qi) * nq_cols + (size_t)h * DH;
@@ -240,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
 
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
   if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
-  dim3 grid((a.max_q_len + 127) / 128, a.H, a.causal ? a.B : 1), block(256);
+  dim3 grid(((a.max_q_len + 127) / 128) * a.H, a.causal ? a.B : 1), block(256);
   hipLaunchKernelGGL(attn_prefill_kernel, grid, block, 0, s, a);
   return hipGetLastError();
 }
