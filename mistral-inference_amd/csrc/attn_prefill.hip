@@ -8,7 +8,10 @@
 // read straight from the ring at slot kp % W, new keys from the post-RoPE activation rows - nothing is
 // concatenated or replicated.
 //
-// Block = (128-query tile, q head, sequence), 4 waves x 32 query rows.  Per 64-key tile:
+// Block = (query tile, q head, sequence), NW waves x 32 query rows: 8 waves (256 queries) when the launch still fills
+// the chip that way, else 4 waves (128 queries, two blocks per CU) - a bigger query tile halves the K/V staging and
+// barrier cost per flop.  K/V tiles are double-buffered in LDS: the next tile's global loads are issued before this
+// tile's math, written to the OTHER buffer after it, and one barrier per tile publishes them.  Per 64-key tile:
 //   S^T = K . Q^T   (mfma 32x32x16; swapped so that a lane owns ONE query column: the softmax row
 //                    reductions are in-lane plus one exchange with lane^32 - guide T12)
 //   O^T += V^T . P^T with P^T taken directly from the S^T accumulator registers: the contraction index
@@ -17,6 +20,7 @@
 // K tile: row-major in LDS, 16-byte slots XOR-swizzled by (key & 15) -> conflict-free ds_read_b128.
 // V tile: transposed on the way in (4 keys x 8 d per thread, register transpose, ds_write_b64), row
 // stride 136 B -> conflict-free ds_read_b64.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.cuh"
@@ -31,10 +35,12 @@ constexpr int KS_BYTES = KT * DH * 2;
 constexpr int VT_BYTES = DH * VT_STRIDE;
 constexpr float LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[KS_BYTES + VT_BYTES];
-  char* Ks = smem;
-  char* Vt = smem + KS_BYTES;
+constexpr int BUF_BYTES = KS_BYTES + VT_BYTES;  // one K tile + one transposed V tile
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(AttnPrefillArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x BUF_BYTES
+  constexpr int NT = NW * 64, QB = NW * 32;  // threads, queries per block
 
   const int tid = threadIdx.x, lane = tid & 63;
   // provably wave-uniform: everything derived from it (this wave's query range, `skip`, `full`) becomes scalar control
@@ -61,24 +67,24 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
     s_b = a.max_q_len;
     p_b = 0;
   }
-  if (qt * 128 >= s_b) return;
+  if (qt * QB >= s_b) return;
   const int W = a.W;
   const int n_old = min(p_b, W);
 
   // key-position range this block needs
-  const int qp_blk_lo = p_b + qt * 128;
-  const int qp_blk_hi = p_b + min(qt * 128 + 127, s_b - 1);
+  const int qp_blk_lo = p_b + qt * QB;
+  const int qp_blk_hi = p_b + min(qt * QB + QB - 1, s_b - 1);
   const int kp_lo = a.causal ? max(p_b - n_old, qp_blk_lo - W + 1) : 0;
   const int kp_hi = a.causal ? qp_blk_hi : s_b - 1;
   const int n_tiles = (kp_hi - kp_lo + KT) / KT;
 
   // this wave's queries
-  const int qi = qt * 128 + wid * 32 + ql;            // index inside the sequence
+  const int qi = qt * QB + wid * 32 + ql;             // index inside the sequence
   const int qi_c = min(qi, s_b - 1);
   const int qp = p_b + qi_c;
-  const int qp_w_lo = p_b + qt * 128 + wid * 32;       // wave's lowest / highest query position
-  const int qp_w_hi = p_b + min(qt * 128 + wid * 32 + 31, s_b - 1);
-  const bool wave_active = (qt * 128 + wid * 32) < s_b;
+  const int qp_w_lo = p_b + qt * QB + wid * 32;        // wave's lowest / highest query position
+  const int qp_w_hi = p_b + min(qt * QB + wid * 32 + 31, s_b - 1);
+  const bool wave_active = (qt * QB + wid * 32) < s_b;
 
   bf16x8 qf[8];
   {
@@ -95,10 +101,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
   float m_run = -1e30f, l_run = 0.f;
   const float sc = rsqrtf((float)DH) * LOG2E;
 
-  // ---- staging assignment
-  const int k_slot = tid & 15, k_key0 = tid >> 4;   // K: keys k_key0 + 16 j, 16-byte slot k_slot
-  const int v_kq = tid & 15, v_ds = tid >> 4;       // V: keys 4 v_kq + j, d slice v_ds*8..+8
-  u32x4 rk[4], rv[4];
+  // ---- staging assignment.  K: 16-byte piece p = tid + NT*j -> key p >> 4, slot p & 15.  V: a thread takes the same
+  // 16-byte d slice of KPT consecutive keys (4 with 256 threads, 2 with 512) and transposes them in registers.
+  constexpr int PPT = 1024 / NT;  // K pieces (and V keys) per thread
+  constexpr int KPT = PPT;
+  const int k_slot = tid & 15, k_key0 = tid >> 4;
+  const int v_kg = tid % (64 / KPT), v_ds = tid / (64 / KPT);  // key group, d slice (8 d)
+  u32x4 rk[PPT], rv[KPT];
   // Source row of key position kp: ring slot (kp % W) for keys older than this forward, activation row otherwise.
   // Both candidate addresses are formed and SELECTED (v_cndmask), and the load itself is unconditional from a
   // clamped position: a `cond ? load : 0` makes hipcc branch around every load and wait vmcnt(0) after each one
@@ -125,11 +134,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
       return (kp < p_b) ? slot * kv_dim : arow * a.ld;
     };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kpk = min(t_lo + k_key0 + 16 * j, kp_hi);
+    for (int j = 0; j < PPT; ++j) {
+      const int kpk = min(t_lo + k_key0 + (NT / 16) * j, kp_hi);
       const bf16_t* kb = (kpk < p_b) ? ring_k0 : act_k0;
       rk[j] = ld16(kb + key_off(kpk) + k_slot * 8);
-      const int kpv = min(t_lo + v_kq * 4 + j, kp_hi);
+      const int kpv = min(t_lo + v_kg * KPT + j, kp_hi);
       const bf16_t* vb = (kpv < p_b) ? ring_v0 : act_v0;
       rv[j] = ld16(vb + key_off(kpv) + v_ds * 8);
     }
@@ -138,52 +147,76 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
     if (big_w) gload_impl(it, std::true_type{});
     else gload_impl(it, std::false_type{});
   };
-  auto lstore = [&]() {
+  auto lstore = [&](char* buf) {
+    char* Ks = buf;
+    char* Vt = buf + KS_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key = k_key0 + 16 * j;
+    for (int j = 0; j < PPT; ++j) {
+      const int key = k_key0 + (NT / 16) * j;
       st16(Ks + key * (DH * 2) + ((k_slot ^ (key & 15)) << 4), rk[j]);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      // d = v_ds*8 + 2c (low halves) and 2c+1 (high halves); 4 keys packed per row
-      u32x2 lo, hi;
-      lo[0] = (rv[0][c] & 0xffffu) | (rv[1][c] << 16);
-      lo[1] = (rv[2][c] & 0xffffu) | (rv[3][c] << 16);
-      hi[0] = (rv[0][c] >> 16) | (rv[1][c] & 0xffff0000u);
-      hi[1] = (rv[2][c] >> 16) | (rv[3][c] & 0xffff0000u);
-      *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_kq * 8) = lo;
-      *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_kq * 8) = hi;
+      // d = v_ds*8 + 2c (low halves) and 2c+1 (high halves); KPT keys packed per row
+      if constexpr (KPT == 4) {
+        u32x2 lo, hi;
+        lo[0] = (rv[0][c] & 0xffffu) | (rv[1][c] << 16);
+        lo[1] = (rv[2][c] & 0xffffu) | (rv[3][c] << 16);
+        hi[0] = (rv[0][c] >> 16) | (rv[1][c] & 0xffff0000u);
+        hi[1] = (rv[2][c] >> 16) | (rv[3][c] & 0xffff0000u);
+        *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_kg * 8) = lo;
+        *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_kg * 8) = hi;
+      } else {
+        const uint32_t lo = (rv[0][c] & 0xffffu) | (rv[1][c] << 16);
+        const uint32_t hi = (rv[0][c] >> 16) | (rv[1][c] & 0xffff0000u);
+        *reinterpret_cast<uint32_t*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_kg * 4) = lo;
+        *reinterpret_cast<uint32_t*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_kg * 4) = hi;
+      }
     }
   };
 
-  // Split staging (guide T14): the NEXT tile's global loads are issued before this tile's math and sit in registers
-  // (rk/rv) until the barrier that ends the tile; only then are they written to LDS.  HBM/L2 latency is hidden under
-  // the MFMAs instead of being exposed once per tile.
+  // Split staging (guide T14) into a double-buffered LDS image: tile it+1's global loads are issued before tile it's
+  // math and sit in registers (rk/rv) until the math is done; they are then written to the other buffer - whose last
+  // readers passed the barrier that ended tile it-1 - and the barrier that ends tile it publishes them.
   gload(0);
-  lstore();
+  lstore(smem);
   __syncthreads();
   for (int it = 0; it < n_tiles; ++it) {
     if (it + 1 < n_tiles) gload(it + 1);
+    const char* Ks = smem + (it & 1) * BUF_BYTES;
+    const char* Vt = Ks + KS_BYTES;
 
     const int t_lo = kp_lo + it * KT;
     const int t_hi = min(t_lo + KT - 1, kp_hi);
     const bool skip = !wave_active || (a.causal && (t_lo > qp_w_hi || t_hi <= qp_w_lo - W));
     if (!skip) {
       // ---- S^T = K . Q^T
+      // Fragment reads are issued four k-steps (8 ds_read_b128) ahead of the MFMAs that consume them and the two
+      // 32-key accumulators alternate, so neither the LDS latency nor the dependent-accumulate latency of a
+      // 32x32x16 MFMA sits between consecutive MFMAs (the straightforward read -> wait -> mfma loop ran this phase
+      // as one serial chain).
       f32x16 st[2];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
-        const int key = mb * 32 + ql;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int slot = kk * 2 + hf;
-          const bf16x8 kf = __builtin_bit_cast(
-              bf16x8, *reinterpret_cast<const u32x4*>(Ks + key * (DH * 2) + ((slot ^ (key & 15)) << 4)));
-          st[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[mb], 0, 0, 0);
-        }
+      for (int kh = 0; kh < 2; ++kh) {
+        bf16x8 kf[4][2];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const int key = mb * 32 + ql, slot = (kh * 4 + k4) * 2 + hf;
+            kf[k4][mb] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(Ks + key * (DH * 2) + ((slot ^ (key & 15)) << 4)));
+          }
+        __builtin_amdgcn_sched_barrier(0);  // keep the 8 reads ahead of the MFMAs (hipcc sinks them back otherwise)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            st[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k4][mb], qf[kh * 4 + k4], st[mb], 0, 0, 0);
       }
       // ---- mask, online softmax (this lane: query ql, keys of its half).  Scores stay RAW (unscaled): the
       // 1/sqrt(d) * log2(e) factor is folded into the exponent's fma, p = exp2(s * sc - m * sc).
@@ -236,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
           pb[mb][r >> 3][(r & 7) >> 1] = cvt_pk_bf16(p0, p1);
         }
       l_run = l_run * alpha + psum;
-      // ---- O^T += V^T . P^T
+      // ---- O^T += V^T . P^T  (left to hipcc's scheduler, which overlaps the second key half's exponentials with the
+      // first half's MFMAs; hand-pipelining the V^T fragment reads one group ahead measured no better)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -254,11 +288,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
           }
         }
     }
-    __syncthreads();  // every wave is done reading this tile
-    if (it + 1 < n_tiles) {
-      lstore();
-      __syncthreads();
-    }
+    if (it + 1 < n_tiles) lstore(smem + ((it + 1) & 1) * BUF_BYTES);
+    __syncthreads();
   }
 
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*128 + d]
@@ -281,9 +312,30 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
 
 }  // namespace
 
+template <int NW>
+static hipError_t launch_nw(const AttnPrefillArgs& a, hipStream_t s) {
+  static bool attr_set = false;  // 2 x 33 KiB of dynamic LDS: above the 64 KiB default limit
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  constexpr int QB = NW * 32;
+  dim3 grid(((a.max_q_len + QB - 1) / QB) * a.H, a.causal ? a.B : 1), block(NW * 64);
+  hipLaunchKernelGGL((attn_prefill_kernel<NW>), grid, block, 2 * BUF_BYTES, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
   if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
-  dim3 grid(((a.max_q_len + 127) / 128) * a.H, a.causal ? a.B : 1), block(256);
-  hipLaunchKernelGGL(attn_prefill_kernel, grid, block, 0, s, a);
-  return hipGetLastError();
+  static int force = -1;  // MI_ATTN_PREFILL_WAVES=4|8 pins the block shape (A/B testing)
+  if (force < 0) {
+    const char* e = getenv("MI_ATTN_PREFILL_WAVES");
+    force = e ? atoi(e) : 0;
+  }
+  // 256-query blocks once they still give every CU a block (one 8-wave block per CU), else 128-query blocks
+  const long blocks8 = (long)((a.max_q_len + 255) / 256) * a.H * (a.causal ? a.B : 1);
+  const bool eight = force ? force == 8 : blocks8 >= 256;
+  return eight ? launch_nw<8>(a, s) : launch_nw<4>(a, s);
 }

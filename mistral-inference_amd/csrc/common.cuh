@@ -82,3 +82,12 @@ __device__ __forceinline__ float swiglu_bf(float acc1, float acc3) {
   float s = bf_round(a / (1.0f + expf(-a)));
   return s * b;  // caller rounds to bf16
 }
+// Same rounding points with hardware exp2 / rcp (relative error ~1e-6, three orders below a bf16 ulp): for the MFMA
+// GEMM epilogue, where 64 results per lane made the IEEE expf + division chain (~40 instructions each) a visible
+// part of every output tile.
+__device__ __forceinline__ float swiglu_bf_fast(float acc1, float acc3) {
+  const float a = bf_round(acc1), b = bf_round(acc3);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a);
+  const float s = bf_round(a * __builtin_amdgcn_rcpf(1.0f + e));
+  return s * b;
+}

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int s = 0; s < 2; ++s) {
           const int j = n_tile * NOUT + wn * 32 + s * 16 + (lane & 15);
           if (j < g.N)
-            reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + j] = f_to_bf(swiglu_bf(acc[mt][s][r], acc[mt][2 + s][r]));
+            reinterpret_cast<bf16_t*>(g.out)[orow * g.ldo + j] = f_to_bf(swiglu_bf_fast(acc[mt][s][r], acc[mt][2 + s][r]));
         }
       } else {
 #pragma unroll

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
           const int n = n_tile * 128 + wc * 32 + j * 16 + cq;
           float y[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = swiglu_bf(acc[ha][0][i][j][r], acc[ha][1][i][j][r]);
+          for (int r = 0; r < 4; ++r) y[r] = swiglu_bf_fast(acc[ha][0][i][j][r], acc[ha][1][i][j][r]);
           bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + ob + n;
           if (n + 3 < g.N && wide_ok) {
             *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));

@@ -35,3 +35,11 @@ if len(sys.argv) > 2:  # fixed-cost fit: N = 4096, K sweep, per epilogue
             out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == h.EPI_LOGITS else BF)
             us = t(lambda: h.linear(x, (w,), epi, residual=res, out=out))
             print(f"{nm} K={K}: {us:8.1f} us", flush=True)
+if len(sys.argv) > 3:  # per-round cost of the SWIGLU form: N = 2048 k gives k rounds of 256 tiles
+    for N in (2048, 4096, 8192, 14336):
+        K = 4096
+        x = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF)
+        w = ((torch.rand(N, K, device="cuda") * 2 - 1) / K ** 0.5).to(BF)
+        out = torch.empty(M, N, device="cuda", dtype=BF)
+        us = t(lambda: h.linear(x, (w, w), h.EPI_SWIGLU, out=out))
+        print(f"swiglu N={N}: {us:8.1f} us", flush=True)
