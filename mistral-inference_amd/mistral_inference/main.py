@@ -66,14 +66,14 @@ def get_model_cls(model_path: str) -> Type[Transformer]:
 
 def interactive(model_path: str, max_tokens: int = 35, temperature: float = 0.7, num_pipeline_ranks: int = 1,
                 instruct: bool = False, lora_path: Optional[str] = None) -> None:
-    if lora_path is not None:
-        raise NotImplementedError("LoRA adapters: merge them into the checkpoint first")
     num_pipeline_ranks = init_pipeline() if is_torchrun() else num_pipeline_ranks
     should_print = _should_print()
     mistral_tokenizer = load_tokenizer(Path(model_path))
     tokenizer = mistral_tokenizer.instruct_tokenizer.tokenizer
     model = get_model_cls(model_path).from_folder(Path(model_path), max_batch_size=3,
                                                   num_pipeline_ranks=num_pipeline_ranks, dtype=torch.bfloat16)
+    if lora_path is not None:  # reference main.py:131-132
+        model.load_lora(Path(lora_path))
     messages: List = []
     while True:
         length = torch.zeros(1, dtype=torch.int)
@@ -105,12 +105,12 @@ def interactive(model_path: str, max_tokens: int = 35, temperature: float = 0.7,
 
 
 def demo(model_path: str, max_tokens: int = 35, temperature: float = 0, lora_path: Optional[str] = None) -> None:
-    if lora_path is not None:
-        raise NotImplementedError("LoRA adapters: merge them into the checkpoint first")
     num_pipeline_ranks = init_pipeline()
     should_print = _should_print()
     model = get_model_cls(model_path).from_folder(Path(model_path), max_batch_size=3,
                                                   num_pipeline_ranks=num_pipeline_ranks, dtype=torch.bfloat16)
+    if lora_path is not None:  # reference main.py:224-225
+        model.load_lora(Path(lora_path))
     tokenizer = load_tokenizer(Path(model_path)).instruct_tokenizer.tokenizer
     prompts = ["This is a test", "This is another great test", "This is a third test, mistral AI is very good at testing. "]
     encoded = [tokenizer.encode(p, bos=True, eos=False) for p in prompts]

@@ -347,6 +347,44 @@ class Transformer(ModelBase):
         if hasattr(self._backend, "invalidate"):
             self._backend.invalidate()
 
+    # ---- LoRA (reference lora.py:92-139): adapters are MERGED into the frozen weights at load time -------------
+    def load_lora(self, lora_path: Union[Path, str], scaling: float = 2.0) -> None:
+        """Loads a LoRA checkpoint (safetensors with `<linear>.lora_A.weight` / `.lora_B.weight` keys) and folds it
+        into the weights: W <- W + (B @ A) * scaling, every nn.Linear of this rank's layers except `output`."""
+        lora_path = Path(lora_path)
+        assert lora_path.is_file(), f"{lora_path} does not exist or is not a file"
+        self._load_lora_state_dict(safetensors.torch.load_file(str(lora_path)), scaling=scaling)
+
+    def _load_lora_state_dict(self, lora_state_dict: Mapping[str, torch.Tensor], scaling: float = 2.0) -> None:
+        lora_dtypes = set(p.dtype for p in lora_state_dict.values())
+        assert len(lora_dtypes) == 1, (
+            f"LoRA weights have multiple different dtypes {lora_dtypes}. All weights need to have the same dtype")
+        lora_dtype = lora_dtypes.pop()
+        assert lora_dtype == self.dtype, f"LoRA weights dtype differs from model's dtype {lora_dtype} != {self.dtype}"
+        assert all("lora" in key for key in lora_state_dict.keys())
+        if self.dtype != torch.bfloat16 or self.device.type != "cuda":
+            raise RuntimeError("load_lora: the merge runs on the GPU in bf16 (model must be on the device)")
+        logging.info("Loading and merging LoRA weights...")
+        sd = {k: v.to(self.device) for k, v in lora_state_dict.items()}
+        with torch.no_grad():
+            for name, module in self.named_modules():
+                if not isinstance(module, nn.Linear) or name == "output":
+                    continue
+                if name.split(".")[1] not in self.layers:
+                    logging.debug("Skipping parameter %s at pipeline rank %d", name, self.pipeline_rank)
+                    continue
+                if name + ".lora_B.weight" not in sd:
+                    continue
+                a, b = sd[name + ".lora_A.weight"], sd[name + ".lora_B.weight"]  # [r, in], [out, r]
+                r = a.shape[0]
+                pad = (-r) % 8  # the GEMM wants K % 8 == 0: zero columns add nothing
+                at = torch.nn.functional.pad(a.t(), (0, pad)).contiguous()  # [in, r + pad]
+                bp = torch.nn.functional.pad(b, (0, pad)).contiguous()      # [out, r + pad]
+                delta = _hip.linear(bp, (at,), _hip.EPI_STORE)              # bf16(B @ A), fp32 accumulation
+                module.weight.copy_(module.weight + delta * scaling)        # same rounding points as lora.py:131-135
+        if hasattr(self._backend, "invalidate"):
+            self._backend.invalidate()
+
     @staticmethod
     def from_folder(folder: Union[Path, str], max_batch_size: int = 1, num_pipeline_ranks: int = 1,
                     device: Union[torch.device, str] = "cuda", dtype: Optional[torch.dtype] = None,

@@ -5,7 +5,7 @@ import torch
 
 import mistral_oracle as mo
 from golden_util import CASES, Case
-from hip_util import write_checkpoint
+from hip_util import bf16_ulp_close, write_checkpoint
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -242,3 +242,40 @@ def test_softmax_fp32_false_and_module_level_block(tmp_path):
     col = []
     om.forward_partial(ids.cpu(), lens, None, collect=col)
     assert (out - col[0].float()).abs().max().item() <= 4e-2 * max(1.0, col[0].float().abs().max().item())
+
+
+def test_load_lora_merges_like_the_reference(tmp_path):
+    """Transformer.load_lora (reference lora.py:92-139, merged form): W <- W + (B @ A) * scaling in the model dtype for
+    every linear that has adapter keys; ranks that are not a multiple of 8 exercise the zero padding of the GEMM's K.
+    Checked on the merged weights (1 bf16 ulp: fp32 summation order of B @ A) and on logits against the oracle run on
+    weights merged the reference's way on the CPU."""
+    from safetensors.torch import save_file
+    args = mo.OracleArgs(dim=256, n_layers=2, head_dim=128, hidden_dim=512, n_heads=4, n_kv_heads=2, vocab_size=320,
+                         norm_eps=1e-5, rope_theta=1e6, sliding_window=None)
+    weights = mo.synth_weights(args, seed=7)
+    model = _load(tmp_path, args, weights)
+    g = torch.Generator().manual_seed(11)
+    lora, merged = {}, dict(weights)
+    for name, r in (("layers.0.attention.wq", 8), ("layers.0.feed_forward.w2", 5), ("layers.1.attention.wo", 16),
+                    ("layers.1.feed_forward.w1", 3)):
+        w = weights[name + ".weight"]
+        a = (torch.randn(r, w.shape[1], generator=g) * 0.05).to(BF)
+        b = (torch.randn(w.shape[0], r, generator=g) * 0.05).to(BF)
+        lora[name + ".lora_A.weight"], lora[name + ".lora_B.weight"] = a, b
+        merged[name + ".weight"] = w + (b @ a) * 2.0  # lora.py:131-135, bf16 tensors
+    path = tmp_path / "lora.safetensors"
+    save_file(lora, str(path))
+    model.load_lora(path)
+    sd = model.state_dict()
+    for name in merged:
+        ok, err = bf16_ulp_close(sd[name].cpu(), merged[name], ulps=1.0)
+        assert ok, (name, err)
+    prompt = torch.randint(0, args.vocab_size, (17,), generator=g)
+    got = model.forward(prompt.cuda(), [17]).cpu()
+    ref = mo.OracleModel(args, merged).forward(prompt, [17], None)
+    assert float((got - ref).abs().max()) < LOGIT_ATOL
+    # contract errors of the reference loader
+    with pytest.raises(AssertionError):
+        model._load_lora_state_dict({"layers.0.attention.wq.lora_A.weight": torch.zeros(8, 256)})  # fp32 != bf16
+    with pytest.raises(AssertionError):
+        model._load_lora_state_dict({"layers.0.attention.wq.weight": torch.zeros(8, 256, dtype=BF)})  # not a lora key
