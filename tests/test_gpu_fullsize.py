@@ -1,0 +1,75 @@
+"""BASELINE.json configs[1] at FULL size (Mistral-7B-v0.3 dims, 32 layers, 4096-token prompt, sliding_window=4096) - the
+workload bench.py times.  The CPU oracle needs minutes per token here, so parity is checked through size-independent
+properties of the path (the reference's own self-consistency tests, tests/test_generate.py:36-69 and :199-230, are of
+this kind): one-shot prefill == chunked prefill == token-by-token decode on the same tokens, across the ring wrap at
+position 4096; replayed-graph decode == launch-by-launch decode; and run-to-run bit equality."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+TOL = 6e-2  # max-abs on logits between two schedules of the SAME model: 32 layers of bf16 storage (|logits| ~ 3)
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    sys.path.insert(0, ROOT)
+    import bench
+    model = bench.build_model(dict(bench.MISTRAL_7B), 0, 1, "cuda")
+    yield model
+    del model
+    torch.cuda.empty_cache()
+
+
+def _cache(model, n):
+    from mistral_inference.cache import BufferCache
+    a = model.args
+    c = BufferCache(model.n_local_layers, 1, n, a.n_kv_heads, a.head_dim, a.sliding_window, device="cuda", dtype=BF)
+    c.reset()
+    return c
+
+
+def test_full_size_prefill_chunked_decode_agree(full_model):
+    m = full_model
+    T, extra = 4096, 6
+    ids = torch.randint(0, m.args.vocab_size, (T + extra,), generator=torch.Generator().manual_seed(0)).cuda()
+    # (a) one-shot prefill of 4096, then teacher-forced decode across the ring wrap (positions 4096..4101)
+    c = _cache(m, T + extra)
+    one = m.forward(ids[:T], [T], c)[-1].clone()
+    dec = [m.forward(ids[T + i:T + i + 1], [1], c)[0].clone() for i in range(extra)]
+    assert torch.isfinite(one).all() and all(torch.isfinite(d).all() for d in dec)
+    # (b) chunked prefill 3 x ~1365 must give the same last-row logits
+    c2 = _cache(m, T + extra)
+    for lo in range(0, T, 1366):
+        last = m.forward(ids[lo:min(lo + 1366, T)], [min(lo + 1366, T) - lo], c2)[-1]
+    assert float((last - one).abs().max()) < TOL
+    assert int(last.argmax()) == int(one.argmax()) or float(one.max() - one[last.argmax()]) < TOL
+    # (c) the next tokens fed as ONE more chunk (prefill branch over a wrapped ring) == the decode steps
+    chunk = m.forward(ids[T:T + extra], [extra], c2)
+    for i in range(extra):
+        assert float((chunk[i] - dec[i]).abs().max()) < TOL, i
+    # (d) bit-exact repeatability of the whole schedule
+    c3 = _cache(m, T + extra)
+    again = m.forward(ids[:T], [T], c3)[-1]
+    assert torch.equal(again, one)
+    dec2 = [m.forward(ids[T + i:T + i + 1], [1], c3)[0].clone() for i in range(extra)]
+    assert all(torch.equal(a, b) for a, b in zip(dec, dec2))
+
+
+def test_full_size_graph_replay_equals_eager(full_model):
+    m = full_model
+    T, steps = 4096, 5
+    ids = torch.randint(0, m.args.vocab_size, (T + steps,), generator=torch.Generator().manual_seed(1)).cuda()
+    c = _cache(m, T + steps)
+    m.forward(ids[:T], [T], c)
+    eager = [m.forward(ids[T + i:T + i + 1], [1], c)[0].clone() for i in range(steps)]
+    c2 = _cache(m, T + steps)
+    m.forward(ids[:T], [T], c2)
+    with m.graphed_decode(c2):
+        graph = [m.forward(ids[T + i:T + i + 1], [1], c2)[0].clone() for i in range(steps)]
+    assert all(torch.equal(a, b) for a, b in zip(eager, graph))
+    assert torch.equal(c.kv_seqlens, c2.kv_seqlens)
