@@ -391,19 +391,22 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       } else {
         MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
         MI_TRY(hip_rc(launch_moe_router(ws.sel_idx, ws.sel_w, ws.xn, D, T, D, L.gate, E, k, nullptr, 0.f, s), "moe_router"));
-        MI_TRY(hip_rc(launch_moe_lists(ws.sel_idx, T, E, k, ws.tok_of, ws.row_of, ws.tile_tab, ws.n_tiles, s), "moe_lists"));
+        // 256-row m-tiles (gemm256.hip) once an expert averages a few of them, else 128-row tiles (gemm.hip)
+        const int tile_rows = ((long)T * k >= 512L * E && D % 64 == 0 && F % 64 == 0) ? 256 : 128;
+        const int max_m_tiles = (T * k + tile_rows - 1) / tile_rows + E;  // <= ws.max_tiles (sized for 128-row tiles)
+        MI_TRY(hip_rc(launch_moe_lists(ws.sel_idx, T, E, k, ws.tok_of, ws.row_of, ws.tile_tab, ws.n_tiles, tile_rows, s), "moe_lists"));
         // one token-grouped launch per projection covers all experts (tile table built on the device: no host sync)
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.epi = GEMM_SWIGLU; g.M = T * k; g.N = F; g.K = D; g.a = ws.xn; g.lda = D; g.n0 = g.n1 = F;
         g.out = ws.hid; g.ldo = F;
-        g.tile_tab = ws.tile_tab; g.n_tiles_ptr = ws.n_tiles; g.max_m_tiles = ws.max_tiles;
+        g.tile_tab = ws.tile_tab; g.n_tiles_ptr = ws.n_tiles; g.max_m_tiles = max_m_tiles; g.tile_rows = tile_rows;
         g.expert_tab = L.expert_w_dev; g.w_sel0 = 0; g.w_sel1 = 2; g.a_gather = ws.tok_of;
         MI_TRY(hip_rc(launch_gemm(g, s), "moe w13 grouped gemm"));
         memset(&g, 0, sizeof(g));
         g.epi = GEMM_STORE; g.M = T * k; g.N = D; g.K = F; g.a = ws.hid; g.lda = F; g.n0 = g.n1 = D;
         g.out = ws.moe_y; g.ldo = D;
-        g.tile_tab = ws.tile_tab; g.n_tiles_ptr = ws.n_tiles; g.max_m_tiles = ws.max_tiles;
+        g.tile_tab = ws.tile_tab; g.n_tiles_ptr = ws.n_tiles; g.max_m_tiles = max_m_tiles; g.tile_rows = tile_rows;
         g.expert_tab = L.expert_w_dev; g.w_sel0 = 1; g.w_sel1 = -1;
         MI_TRY(hip_rc(launch_gemm(g, s), "moe w2 grouped gemm"));
         MI_TRY(hip_rc(launch_moe_combine(h, h, ws.moe_y, ws.sel_idx, ws.sel_w, ws.row_of, T, D, k, s), "moe combine"));

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) void moe_router_kernel(int32_t* sel_idx, floa
 // scan, LDS-cursor scatter.  Row order inside an expert is arbitrary (it only decides which MFMA tile a row lands
 // in, never its value); the bf16 accumulation ORDER of moe.py is reproduced later by moe_combine_kernel.
 __global__ __launch_bounds__(1024) void moe_lists_kernel(const int32_t* sel_idx, int T, int E, int top_k, int32_t* tok_of,
-                                                         int32_t* row_of, int32_t* tile_tab, int32_t* n_tiles) {
+                                                         int32_t* row_of, int32_t* tile_tab, int32_t* n_tiles, int tile_rows) {
   __shared__ int cnt[MOE_MAX_E];
   __shared__ int off[MOE_MAX_E + 1];
   __shared__ int cur[MOE_MAX_E];
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(1024) void moe_lists_kernel(const int32_t* sel_idx,
     for (int e = 0; e < E; ++e) {
       off[e] = o;
       cur[e] = o;
-      for (int r = 0; r < cnt[e]; r += 128) {  // m-tiles of this expert
+      for (int r = 0; r < cnt[e]; r += tile_rows) {  // m-tiles of this expert
         tile_tab[nt * 4 + 0] = e;
         tile_tab[nt * 4 + 1] = o + r;
-        tile_tab[nt * 4 + 2] = min(128, cnt[e] - r);
+        tile_tab[nt * 4 + 2] = min(tile_rows, cnt[e] - r);
         tile_tab[nt * 4 + 3] = 0;
         ++nt;
       }
@@ -352,8 +352,9 @@ hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int 
   return hipGetLastError();
 }
 hipError_t launch_moe_lists(const int32_t* sel_idx, int T, int E, int top_k, int32_t* tok_of, int32_t* row_of,
-                            int32_t* tile_tab, int32_t* n_tiles, hipStream_t s) {
-  hipLaunchKernelGGL(moe_lists_kernel, dim3(1), dim3(1024), 0, s, sel_idx, T, E, top_k, tok_of, row_of, tile_tab, n_tiles);
+                            int32_t* tile_tab, int32_t* n_tiles, int tile_rows, hipStream_t s) {
+  hipLaunchKernelGGL(moe_lists_kernel, dim3(1), dim3(1024), 0, s, sel_idx, T, E, top_k, tok_of, row_of, tile_tab, n_tiles,
+                     tile_rows);
   return hipGetLastError();
 }
 hipError_t launch_moe_combine(void* out, const void* h, const void* y, const int32_t* sel_idx, const float* sel_w,

@@ -220,6 +220,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     const char* e = getenv("MI_GEMM_256");
     use_256 = e ? atoi(e) : 1;
   }
+  if (g.tile_tab && g.tile_rows == 256) return gemm256_applicable(g) ? launch_gemm256(g, s) : hipErrorInvalidValue;
   if (use_256 && gemm256_applicable(g)) return launch_gemm256(g, s);
   const int m_tiles = g.tile_tab ? g.max_m_tiles : (g.M + BM - 1) / BM;
   const int nout = (g.epi == GEMM_SWIGLU) ? 64 : 128;

@@ -1,7 +1,8 @@
 // bf16 MFMA GEMM, 256x256x64 block tile, for the large prefill shapes: out[M,N] = epilogue(A[M,K] . W[N,K]^T).
 //
 // Same contract and epilogues as gemm.hip (transformer_layers.py:66,93,105-106; transformer.py:235); launch_gemm
-// picks this kernel when M >= 256, K % 64 == 0 and the problem is not the token-grouped MoE form.
+// picks this kernel when M >= 256 and K % 64 == 0, and for the token-grouped MoE form (moe.py:28-32, one launch for all
+// experts) when its tile table was built with 256-row m-tiles.
 //
 // Why a second tile shape: the 128x128 kernel moves 32 KiB of operands through LDS per 128x128x64 MACs and is bound by
 // LDS bandwidth (DMA writes ~64-85 B/clk + fragment reads 256 B/clk against 16 clk per MFMA): ~37 % of the MFMA peak.
@@ -71,14 +72,27 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
 
   // ---- block -> tile.  Block b runs on XCD b % 8; a 4 (m) x 8 (n) supertile = the 32 blocks one XCD runs at a time
   // stays on one XCD so that its blocks share 4 A panels and 8 W panels in that XCD's L2 (guide T1; speed only).
-  const int m_tiles = (g.M + 255) >> 8, n_tiles = (g.N + NOUT - 1) / NOUT;
+  const bool grouped = g.tile_tab != nullptr;  // token-grouped MoE form: m-tiles come from the device tile table
+  const int m_tiles = grouped ? g.max_m_tiles : (g.M + 255) >> 8, n_tiles = (g.N + NOUT - 1) / NOUT;
   const int MS = (m_tiles + 3) >> 2, NS = (n_tiles + 7) >> 3;
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
   const int st = (q >> 5) * 8 + xcd, wi = q & 31;
   if (st >= MS * NS) return;
   const int m_tile = (st % MS) * 4 + (wi & 3), n_tile = (st / MS) * 8 + (wi >> 2);
   if (m_tile >= m_tiles || n_tile >= n_tiles) return;
-  const int row0 = m_tile * 256;
+  int row0, rows_valid;
+  const bf16_t *w0 = g.w0, *w1 = g.w1;
+  if (grouped) {  // one tile of one expert: {expert, first compact row, valid rows (<= 256)}
+    if (m_tile >= *g.n_tiles_ptr) return;
+    const int e = g.tile_tab[m_tile * 4];
+    row0 = g.tile_tab[m_tile * 4 + 1];
+    rows_valid = g.tile_tab[m_tile * 4 + 2];
+    w0 = reinterpret_cast<const bf16_t*>(g.expert_tab[e * 3 + g.w_sel0]);
+    if (g.w_sel1 >= 0) w1 = reinterpret_cast<const bf16_t*>(g.expert_tab[e * 3 + g.w_sel1]);
+  } else {
+    row0 = m_tile * 256;
+    rows_valid = min(256, g.M - row0);
+  }
 
   // ---- DMA sources.  One instruction fills 8 consecutive 128-B rows of a half tile; wave w, piece j covers rows
   // (2w + j) * 8 .. + 8; lane l lands at (row + (l >> 3), slot l & 7) and fetches global slot (l & 7) ^ (row & 7).
@@ -89,14 +103,15 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = (wid * 2 + j) * 8 + (lane >> 3);
-      const int m = min(row0 + h * 128 + r, g.M - 1);
+      int m = row0 + min(h * 128 + r, rows_valid - 1);
+      if (g.a_gather) m = g.a_gather[m];
       src[h][j] = g.a + (size_t)m * g.lda + sslot * 8;
       if (EPI == GEMM_SWIGLU) {
         const int n = min(n_tile * 128 + r, g.N - 1);
-        src[2 + h][j] = (h == 0 ? g.w0 : g.w1) + (size_t)n * g.K + sslot * 8;
+        src[2 + h][j] = (h == 0 ? w0 : w1) + (size_t)n * g.K + sslot * 8;
       } else {
         const int n = min(n_tile * 256 + h * 128 + r, g.N - 1);
-        src[2 + h][j] = seg_row256(g, n) + sslot * 8;
+        src[2 + h][j] = (grouped ? w0 + (size_t)n * g.K : seg_row256(g, n)) + sslot * 8;
       }
     }
   char* const my_piece = smem + wid * 2048;  // this wave's two 1-KiB pieces inside any half tile
@@ -228,8 +243,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = row0 + ha * 128 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
-          if (row >= g.M) continue;
+          const int rl = ha * 128 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+          if (rl >= rows_valid) continue;
+          const int row = row0 + rl;
           float* o = reinterpret_cast<float*>(g.out) + (size_t)row * g.ldo;
 #pragma unroll
           for (int hb = 0; hb < 2; ++hb)
@@ -252,8 +268,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = row0 + ha * 128 + wr * 64 + i * 16 + (lane & 15);
-      if (row >= g.M) continue;
+      const int rl = ha * 128 + wr * 64 + i * 16 + (lane & 15);
+      if (rl >= rows_valid) continue;
+      const int row = row0 + rl;
       const size_t ob = (size_t)row * g.ldo;
       if (EPI == GEMM_SWIGLU) {
 #pragma unroll
@@ -335,12 +352,14 @@ hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
 }  // namespace
 
 bool gemm256_applicable(const GemmArgs& g) {
-  return g.tile_tab == nullptr && g.a_gather == nullptr && g.M >= 256 && g.K % BK == 0 && g.K >= 2 * BK;
+  if (g.K % BK != 0 || g.K < 2 * BK) return false;
+  if (g.tile_tab != nullptr) return g.tile_rows == 256;  // token-grouped form: the tile table decides
+  return g.a_gather == nullptr && g.M >= 256;
 }
 
 hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s) {
   const int nout = (g.epi == GEMM_SWIGLU) ? 128 : 256;
-  const int m_tiles = (g.M + 255) >> 8, n_tiles = (g.N + nout - 1) / nout;
+  const int m_tiles = g.tile_tab ? g.max_m_tiles : (g.M + 255) >> 8, n_tiles = (g.N + nout - 1) / nout;
   const int supertiles = ((m_tiles + 3) >> 2) * ((n_tiles + 7) >> 3);
   const dim3 grid((unsigned)(((supertiles + 7) / 8) * 8 * 32));
   switch (g.epi) {

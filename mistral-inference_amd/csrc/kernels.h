@@ -71,10 +71,11 @@ struct GemmArgs {
   int ldo;
   const bf16_t* residual;
   // Token-grouped form (MoE prefill, moe.py:28-32): ONE launch covers every expert.  Compact rows are the (token,
-  // slot) pairs sorted by expert; tile i of `tile_tab` is {expert, first compact row, valid rows (<= 128), 0}.
+  // slot) pairs sorted by expert; tile i of `tile_tab` is {expert, first compact row, valid rows (<= tile_rows), 0}.
   const int32_t* tile_tab;        // device [max_m_tiles][4] or nullptr (plain GEMM)
   const int32_t* n_tiles_ptr;     // device: number of valid entries in tile_tab
   int max_m_tiles;                // host upper bound (grid sizing)
+  int tile_rows;                  // rows per m-tile the table was built for: 128 (gemm.hip) or 256 (gemm256.hip)
   const void* const* expert_tab;  // device [E][3] (w1, w2, w3) pointers
   int w_sel0, w_sel1;             // which of the three matrices feed w0 / w1 (w_sel1 < 0: unused)
   const int32_t* a_gather;        // device: A row of compact row r is a[a_gather[r]] (nullptr: a[r])
@@ -133,7 +134,7 @@ hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int 
 // Sort the (token, slot) pairs by expert: tok_of[r] = token of compact row r, row_of[t*top_k + kk] = compact row of
 // that pair, tile_tab / n_tiles = the grouped GEMM's m-tile table (128 rows per tile, tiles never span experts).
 hipError_t launch_moe_lists(const int32_t* sel_idx, int T, int E, int top_k, int32_t* tok_of, int32_t* row_of,
-                            int32_t* tile_tab, int32_t* n_tiles, hipStream_t s);
+                            int32_t* tile_tab, int32_t* n_tiles, int tile_rows, hipStream_t s);
 // out[t] = bf16(h[t] + R_t), R_t = sum over the token's experts in ascending id of bf16(w * y[row]), accumulated in
 // bf16 from zero (moe.py:28-32 + transformer_layers.py:168)
 hipError_t launch_moe_combine(void* out, const void* h, const void* y, const int32_t* sel_idx, const float* sel_w,

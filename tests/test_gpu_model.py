@@ -279,3 +279,24 @@ def test_load_lora_merges_like_the_reference(tmp_path):
         model._load_lora_state_dict({"layers.0.attention.wq.lora_A.weight": torch.zeros(8, 256)})  # fp32 != bf16
     with pytest.raises(AssertionError):
         model._load_lora_state_dict({"layers.0.attention.wq.weight": torch.zeros(8, 256, dtype=BF)})  # not a lora key
+
+
+def test_moe_long_prefill_takes_256_row_tiles(tmp_path):
+    """T * top_k >= 512 * E switches the token-grouped expert GEMMs to 256-row m-tiles (gemm256.hip): one MoE layer,
+    1200-token prompt, every token's logits against the oracle.  With ONE layer a router near-tie only affects its own
+    token (routing happens after the attention), so exactly those tokens are excluded."""
+    args = mo.OracleArgs(dim=256, n_layers=1, head_dim=128, hidden_dim=512, n_heads=2, n_kv_heads=1, vocab_size=320,
+                         norm_eps=1e-5, rope_theta=1e6, num_experts=4, num_experts_per_tok=2)
+    w = mo.synth_weights(args, seed=21)
+    model = _load(tmp_path, args, w, max_batch_size=1)
+    T = 1200
+    ids = torch.randint(0, args.vocab_size, (T,), generator=torch.Generator().manual_seed(22))
+    got = model.forward(ids.cuda(), [T]).cpu()
+    mo.ROUTER_TRACE = []
+    ref = mo.OracleModel(args, w).forward(ids, [T], None)
+    trace, mo.ROUTER_TRACE = mo.ROUTER_TRACE, None
+    srt = torch.sort(trace[0], dim=1, descending=True).values
+    gap = srt[:, 1] - srt[:, 2]
+    clear = gap > 2 * srt[:, 1].abs().clamp(min=1e-3) * 2.0 ** -7
+    assert int(clear.sum()) >= 0.8 * T
+    assert float((got[clear] - ref[clear]).abs().max()) <= LOGIT_ATOL
