@@ -225,6 +225,8 @@ def test_attn_decode_wide_ring_constant_v(H, Hkv, W):
     (8, [4, 8, 21], [4, 4, 2]),           # later chunk: ring + new keys, wrap
     (64, [100], [200]),                   # chunk longer than the window over a wrapped ring
     (512, [0], [700]),                    # several key tiles, window cuts early tiles
+    (4096, [0, 0], [1100, 900]),          # with 32 heads: enough 256-query blocks for the 8-wave kernel, ragged tail
+    (512, [600, 30, 0], [700, 520, 300]), # 8-wave kernel over wrapped rings with the window cutting tiles
 ])
 def test_attn_prefill(H, Hkv, W, seen, new):
     h = _hip()
