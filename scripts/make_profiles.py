@@ -58,4 +58,19 @@ if dom:
                "source": f"profiles/{tag}_pmc_fetch_write_size.csv"},
               open(os.path.join(PROF, "pmc_dominant_kernel.json"), "w"), indent=1)
     print("dominant kernel HBM bytes per launch:", int(round(2 * fetch * 1024 + write * 1024)))
+mf = os.path.join(OUT, "pmc", "mfma_counter_collection.csv")
+if os.path.exists(mf):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(mf)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        if "at::native" in k or "rocclr" in k:
+            continue
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(os.path.join(PROF, f"{tag}_pmc_mfma_util.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace (own pass); bench.py --layers 4 --steps 2 --prefill 4096 --no-graph\n")
+        f.write("# derived metrics, mean over dispatches (gfx950 falls back to the gfx94x formulas, MI355X_MICROARCH.md 'rocprofv3 PMC slots')\n")
+        f.write("kernel,dispatches,MfmaUtil_pct,VALUBusy_pct,LdsUtil_pct,LdsBankConflict_per_access\n")
+        for k, d in sorted(acc.items()):
+            m = lambda c: sum(d[c]) / len(d[c]) if d.get(c) else 0.0
+            f.write(f'"{k}",{len(next(iter(d.values())))},{m("MfmaUtil"):.1f},{m("VALUBusy"):.1f},{m("LdsUtil"):.1f},{m("LdsBankConflict"):.3f}\n')
 print("wrote", len(rows), "PMC rows")
