@@ -9,8 +9,9 @@
 // block streams a contiguous slot range for ONE kv head and serves all R = H/Hkv query heads from
 // the same registers.  A wave-load covers 4 slots x 256 B; 16 lanes share a slot, scores are reduced
 // with DPP row rotations; online softmax is kept per 16-lane group (no cross-lane sync in the loop)
-// and merged once at the end: lanes -> waves (LDS) -> splits (global fp32 partials; the last block to
-// arrive for a (sequence, kv head) combines them - agent-scope release/acquire, guide section 6 G16).
+// and merged once at the end: lanes -> waves (LDS) -> splits (global fp32 partials, merged by a second, tiny
+// launch: the kernel boundary is the cross-XCD visibility point.  An in-kernel "last block combines" variant with an
+// agent-scope release/acquire ticket measured slower than that boundary and was dropped).
 #include <cstdlib>
 
 #include "common.cuh"
@@ -44,12 +45,11 @@ __device__ __forceinline__ void merge_from(State<R>& s, int off) {
   }
 }
 
-template <int R, bool TWO_PASS>
+template <int R>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   __shared__ float sm_m[4][R];
   __shared__ float sm_l[4][R];
   __shared__ float sm_acc[4][R][DH];
-  __shared__ int sm_last;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar control flow
@@ -180,63 +180,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
       p_ml[r * 2 + 1] = L;
     }
   }
-
-  if (TWO_PASS) return;  // the combine runs as its own launch (the kernel boundary provides the visibility)
-
-  // arrival ticket; the last block of this (sequence, kv head) combines all splits
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(&a.tickets[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (ticket == a.n_splits - 1);
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    sm_last = last;
-  }
-  __syncthreads();
-  if (!sm_last) return;
-
-  // Combine the splits.  (m, l) of every split go through LDS (one coalesced read) so that the accumulator loads
-  // below are independent of each other and can all be in flight together.
-  const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH;
-  const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2;
-  float* sm_ms = &sm_acc[0][0][0];      // [n_splits * R]   (sm_acc is free again: two barriers since its last read)
-  float* sm_ls = sm_ms + 64 * R;        // n_splits <= 64
-  for (int i = tid; i < a.n_splits * R; i += 256) {
-    const float2 ml = *reinterpret_cast<const float2*>(all_ml + 2 * i);
-    sm_ms[i] = ml.x;
-    sm_ls[i] = ml.y;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < R * DH; idx += 256) {
-    const int r = idx / DH, d = idx % DH;
-    float M = -1e30f;
-    for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, sm_ms[sp * R + r]);
-    float L = 0.f, A = 0.f;
-    int sp = 0;
-    for (; sp + 8 <= a.n_splits; sp += 8) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = all_acc[(size_t)(sp + j) * R * DH + idx];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float e = exp2f(sm_ms[(sp + j) * R + r] - M);
-        L += sm_ls[(sp + j) * R + r] * e;
-        A += v[j] * e;
-      }
-    }
-    for (; sp < a.n_splits; ++sp) {
-      const float e = exp2f(sm_ms[sp * R + r] - M);
-      L += sm_ls[sp * R + r] * e;
-      A += all_acc[(size_t)sp * R * DH + idx] * e;
-    }
-    reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)(kvh * R + r) * DH + d] = f_to_bf(A / L);
-  }
-  if (tid == 0) __hip_atomic_store(&a.tickets[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Second launch of the two-pass form: one block per (sequence, q head), one thread per output element.  All of a
+// Second launch: one block per (sequence, q head), one thread per output element.  All of a
 // thread's loads (the head's (m, l) pairs - same address across the block, so one transaction each - and its own
 // accumulator column) are independent and issued together: one memory round trip instead of a chain.
 template <int NS>  // upper bound on n_splits held in registers
@@ -269,16 +215,11 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
 }
 
 template <int R>
-void launch_r(const AttnDecodeArgs& a, bool two_pass, hipStream_t s) {
+void launch_r(const AttnDecodeArgs& a, hipStream_t s) {
   dim3 grid(a.n_splits, a.Hkv, a.B), block(256);
-  if (two_pass) {
-    hipLaunchKernelGGL((attn_decode_kernel<R, true>), grid, block, 0, s, a);
-    if (a.n_splits <= 16) hipLaunchKernelGGL((attn_decode_combine_kernel<16>), dim3(a.H, a.B), dim3(128), 0, s, a);
-    else if (a.n_splits <= 32) hipLaunchKernelGGL((attn_decode_combine_kernel<32>), dim3(a.H, a.B), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(a.H, a.B), dim3(128), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((attn_decode_kernel<R, false>), grid, block, 0, s, a);
-  }
+  hipLaunchKernelGGL((attn_decode_kernel<R>), grid, block, 0, s, a);
+  if (a.n_splits <= 16) hipLaunchKernelGGL((attn_decode_combine_kernel<16>), dim3(a.H, a.B), dim3(128), 0, s, a);
+  else hipLaunchKernelGGL((attn_decode_combine_kernel<32>), dim3(a.H, a.B), dim3(128), 0, s, a);  // n_splits <= 32
 }
 
 }  // namespace
@@ -306,19 +247,12 @@ size_t attn_decode_partial_floats(int B, int H, int Hkv, int Dh, int W) {
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
   if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
   const int R = a.H / a.Hkv;
-  // Default: partials + a separate combine launch (measured faster than the in-kernel arrival ticket, whose
-  // release -> atomic -> acquire chain costs more than one kernel boundary); MI_ATTN_TWO_PASS=0 selects the ticket.
-  static int two_pass = -1;
-  if (two_pass < 0) {
-    const char* e = getenv("MI_ATTN_TWO_PASS");
-    two_pass = e ? atoi(e) : 1;
-  }
   switch (R) {
-    case 1: launch_r<1>(a, two_pass, s); break;
-    case 2: launch_r<2>(a, two_pass, s); break;
-    case 4: launch_r<4>(a, two_pass, s); break;
-    case 6: launch_r<6>(a, two_pass, s); break;
-    case 8: launch_r<8>(a, two_pass, s); break;
+    case 1: launch_r<1>(a, s); break;
+    case 2: launch_r<2>(a, s); break;
+    case 4: launch_r<4>(a, s); break;
+    case 6: launch_r<6>(a, s); break;
+    case 8: launch_r<8>(a, s); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -213,15 +213,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 }  // namespace
 
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
-  if (g.K % 8 != 0 || g.M <= 0 || g.N <= 0) return hipErrorInvalidValue;
-  static int use_256 = -1;  // MI_GEMM_256=0 keeps every shape on the 128x128 kernel (A/B testing)
-  if (use_256 < 0) {
-    const char* e = getenv("MI_GEMM_256");
-    use_256 = e ? atoi(e) : 1;
-  }
-  if (g.tile_tab && g.tile_rows == 256) return gemm256_applicable(g) ? launch_gemm256(g, s) : hipErrorInvalidValue;
-  if (use_256 && gemm256_applicable(g)) return launch_gemm256(g, s);
+namespace {
+
+hipError_t launch_gemm128(const GemmArgs& g, hipStream_t s) {
   const int m_tiles = g.tile_tab ? g.max_m_tiles : (g.M + BM - 1) / BM;
   const int nout = (g.epi == GEMM_SWIGLU) ? 64 : 128;
   const int n_tiles = (g.N + nout - 1) / nout;
@@ -246,4 +240,76 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   }
 #undef MI_LAUNCH_GEMM
   return hipGetLastError();
+}
+
+// The same problem restricted to output columns [c0, c1): weight row segments, output and residual shifted.
+GemmArgs column_slice(const GemmArgs& g, int c0, int c1) {
+  GemmArgs r = g;
+  r.N = c1 - c0;
+  const size_t esz = (g.epi == GEMM_LOGITS) ? 4 : 2;
+  r.out = reinterpret_cast<char*>(g.out) + (size_t)c0 * esz;
+  if (g.residual) r.residual = g.residual + c0;
+  if (g.epi == GEMM_SWIGLU) {  // w0 = W1, w1 = W3, both [N, K]
+    r.w0 = g.w0 + (size_t)c0 * g.K;
+    r.w1 = g.w1 + (size_t)c0 * g.K;
+    r.n0 = r.n1 = r.N;
+    return r;
+  }
+  const bf16_t* seg_w[3] = {g.w0, g.w1, g.w2};
+  const int seg_lo[3] = {0, g.n0, g.n1}, seg_hi[3] = {g.n0, g.n1, g.N};
+  const bf16_t* w[3] = {nullptr, nullptr, nullptr};
+  int end[3] = {0, 0, 0}, k = 0, done = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int lo = seg_lo[i] > c0 ? seg_lo[i] : c0, hi = seg_hi[i] < c1 ? seg_hi[i] : c1;
+    if (hi <= lo) continue;
+    w[k] = seg_w[i] + (size_t)(lo - seg_lo[i]) * g.K;
+    done += hi - lo;
+    end[k++] = done;
+  }
+  r.w0 = w[0];
+  r.w1 = w[1] ? w[1] : w[0];
+  r.w2 = w[2] ? w[2] : r.w1;
+  r.n0 = end[0];
+  r.n1 = k > 1 ? end[1] : r.N;
+  return r;
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+  if (g.K % 8 != 0 || g.M <= 0 || g.N <= 0) return hipErrorInvalidValue;
+  static int use_256 = -1;  // MI_GEMM_256=0 keeps every shape on the 128x128 kernel (A/B testing)
+  if (use_256 < 0) {
+    const char* e = getenv("MI_GEMM_256");
+    use_256 = e ? atoi(e) : 1;
+  }
+  if (g.tile_tab && g.tile_rows == 256) return gemm256_applicable(g) ? launch_gemm256(g, s) : hipErrorInvalidValue;
+  if (!use_256 || !gemm256_applicable(g)) return launch_gemm128(g, s);
+  if (g.tile_tab) return launch_gemm256(g, s);
+  // One 256x256 block per CU: a tile count that is not a multiple of the 256 CUs leaves the last round partly empty
+  // (q|k|v of Mistral-7B: 384 tiles = 1.5 rounds cost 2).  When the last round would be under 3/4 full, the columns
+  // are split: full rounds on the 256 kernel, the remaining columns on the 128 kernel (two blocks per CU, four times
+  // the tiles) - MI_GEMM_TAIL=0 disables the split.
+  static int split_tail = -1;
+  if (split_tail < 0) {
+    const char* e = getenv("MI_GEMM_TAIL");
+    split_tail = e ? atoi(e) : 1;
+  }
+  const int nout = (g.epi == GEMM_SWIGLU) ? 128 : 256;
+  const int m_tiles = (g.M + 255) / 256, n_tiles = (g.N + nout - 1) / nout;
+  const long tiles = (long)m_tiles * n_tiles;
+  const int rem = (int)(tiles % 256);
+  if (split_tail && tiles > 256 && rem != 0 && rem < 192) {
+    int a = 256, b = m_tiles;  // n_first = largest multiple of 256 / gcd(256, m_tiles) not above n_tiles
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int step = 256 / a;
+    const int n_first = (n_tiles / step) * step;
+    if (n_first > 0 && n_first < n_tiles) {
+      const int c0 = n_first * nout;
+      hipError_t e = launch_gemm256(column_slice(g, 0, c0), s);
+      if (e != hipSuccess) return e;
+      return launch_gemm128(column_slice(g, c0, g.N), s);
+    }
+  }
+  return launch_gemm256(g, s);
 }

@@ -94,7 +94,7 @@ struct AttnDecodeArgs {
   int W, B, H, Hkv, Dh;
   const int32_t* tok_pos;  // [B]
   float* partial;          // scratch
-  int32_t* tickets;        // [B*Hkv], zero on entry, left zero
+  int32_t* tickets;        // reserved: first 4 KiB of the scratch (arrival counters of a removed in-kernel combine)
   int n_splits;
 };
 int attn_decode_splits(int W);

@@ -151,6 +151,35 @@ def test_linear_large_tile(M, K, N):
     assert bool((e3 <= 4 * r3.abs() * 2.0 ** -7 + 8e-3).all()), float(e3.max())
 
 
+def test_linear_tail_round_split():
+    """16 x 24 = 384 tiles of 256x256 would run 1.5 rounds of the 256 CUs: launch_gemm gives the first 4096 columns to the
+    256-tile kernel and the rest to the 128-tile kernel.  Row segments are chosen so that the cut falls INSIDE a segment
+    and the tail spans two; every epilogue; SwiGLU splits at column 2048 of 3072."""
+    h = _hip()
+    M, K, N = 4096, 128, 6144
+    x = rnd(M, K, seed=40)
+    ws = [rnd(3000, K, seed=41, scale=0.09), rnd(1500, K, seed=42, scale=0.09), rnd(1644, K, seed=43, scale=0.09)]
+    xc, wc = x.cuda(), tuple(w.cuda() for w in ws)
+    ref = _lin_ref(x, ws)
+    got = h.linear(xc, wc, h.EPI_STORE)
+    ok, err = bf16_ulp_close(got.cpu(), ref.to(BF), ulps=1.0)
+    assert ok, err
+    lg = h.linear(xc, wc, h.EPI_LOGITS).cpu()
+    assert torch.equal(lg.to(BF), got.cpu())
+    res = rnd(M, N, seed=44)
+    y = ref.to(BF)
+    r2 = (res + y).float()
+    g2 = h.linear(xc, wc, h.EPI_RESIDUAL, residual=res.cuda()).cpu().float()
+    scale = torch.maximum(torch.maximum(res.float().abs(), y.float().abs()), r2.abs())
+    assert bool(((g2 - r2).abs() <= 1.5 * scale * 2.0 ** -7 + 1e-6).all())
+    F_ = 3072
+    w1, w3 = rnd(F_, K, seed=45, scale=0.09), rnd(F_, K, seed=46, scale=0.09)
+    r3 = (F.silu(F.linear(x, w1)) * F.linear(x, w3)).float()
+    g3 = h.linear(xc, (w1.cuda(), w3.cuda()), h.EPI_SWIGLU).cpu().float()
+    e3 = (g3 - r3).abs()
+    assert bool((e3 <= 4 * r3.abs() * 2.0 ** -7 + 8e-3).all()), float(e3.max())
+
+
 @pytest.mark.parametrize("M", [1, 4])
 def test_linear_fused_norm(M):
     h = _hip()
