@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
@@ -99,11 +99,18 @@ int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const
  * kv_before[b] tokens already seen, key position kp is visible to query position qp iff
  * qp - W < kp <= qp; keys kp < p_b are read from the ring (slot kp % W, only the last min(p_b,W)
  * exist), keys kp >= p_b from the activation rows.  qkv: [T, ld] fused buffer (post-RoPE).
- * causal == 0 is the cache=None quirk (transformer_layers.py:165): one segment, no mask.
+ * causal == 0 is the cache=None quirk (transformer_layers.py:165): one segment, no mask - also what one image of the
+ * vision tower's block-diagonal mask is (vision_encoder.py:96-99).
+ * softmax_scale <= 0 selects head_dim^-1/2 (the xformers default the reference relies on, transformer_layers.py:48,88);
+ * the vision tower runs its 64-wide heads zero-padded to 128 and passes 64^-1/2.
  * out: [T, H*Dh]. */
 int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, const void* cache_v, int W, int B,
                     int max_q_len, int n_heads, int n_kv_heads, int head_dim, const int32_t* q_start,
-                    const int32_t* kv_before, int causal, mi_stream_t stream);
+                    const int32_t* kv_before, int causal, float softmax_scale, mi_stream_t stream);
+
+/* nn.GELU() of the vision-language adapter (vision_encoder.py:112-116; exact erf form): x <- bf16(gelu(x)) in place
+ * over [T, N] bf16 rows with row pitch ldx. */
+int mi_gelu(void* x, int ldx, int T, int N, mi_stream_t stream);
 
 /* moe.py:25-27: logits = bf16(x @ Wg^T); top-k on them; fp32 softmax over the k picked, rounded to
  * bf16.  x is [T, D] (norm_w != NULL fuses the RMSNorm).  sel_idx int32 [T, k], sel_w fp32 [T, k]
@@ -152,7 +159,7 @@ enum mi_branch {
 typedef struct mi_batch {
   int32_t T, B, branch;
   int32_t max_q_len;            /* host: max(seqlens) */
-  const int64_t* input_ids;     /* dev [T]; used when model->tok_embeddings != NULL */
+  const int64_t* input_ids;     /* dev [T]; embedded into h when model->tok_embeddings != NULL; NULL: h is the input */
   /* sequence metadata, device int32.  PREFILL/NOCACHE: written by the host (one H2D copy per
    * forward -- the reference rebuilds five tensors per LAYER, cache.py:226-263).
    * DECODE: filled on the device from kv_seqlens by the first kernel of the step. */

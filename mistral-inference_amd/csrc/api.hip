@@ -220,7 +220,7 @@ int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const
 
 int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, const void* cache_v, int W, int B,
                     int max_q_len, int n_heads, int n_kv_heads, int head_dim, const int32_t* q_start,
-                    const int32_t* kv_before, int causal, mi_stream_t stream) {
+                    const int32_t* kv_before, int causal, float softmax_scale, mi_stream_t stream) {
   if (!out || !qkv || B <= 0 || max_q_len <= 0 || W <= 0) return fail(MI_ERR_ARG, "mi_attn_prefill");
   if (causal && (!q_start || !kv_before)) return fail(MI_ERR_ARG, "mi_attn_prefill: metadata");
   if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
@@ -231,7 +231,13 @@ int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, con
   a.out = out; a.qkv = (const bf16_t*)qkv; a.ld = ld; a.cache_k = (const bf16_t*)cache_k; a.cache_v = (const bf16_t*)cache_v;
   a.W = W; a.B = B; a.max_q_len = max_q_len; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim;
   a.q_start = q_start; a.kv_before = kv_before; a.causal = causal;
+  a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)head_dim);
   return hip_rc(launch_attn_prefill(a, (hipStream_t)stream), "attn_prefill");
+}
+
+int mi_gelu(void* x, int ldx, int T, int N, mi_stream_t stream) {
+  if (!x || T <= 0 || N <= 0 || ldx < N) return fail(MI_ERR_ARG, "mi_gelu");
+  return hip_rc(launch_gelu(x, ldx, T, N, (hipStream_t)stream), "gelu");
 }
 
 int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate, int E,
@@ -255,7 +261,6 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
   if (has_cache && (!bt->cache_k || !bt->cache_v || !bt->cache_sizes)) return fail(MI_ERR_ARG, "mi_forward: cache");
   if (branch == MI_BRANCH_DECODE && (T != B || !bt->kv_seqlens)) return fail(MI_ERR_ARG, "mi_forward: decode needs T == B");
   if ((size_t)B * m->n_kv_heads * 4 > TICKET_BYTES) return fail(MI_ERR_SHAPE, "B * n_kv_heads > 1024");
-  if (m->tok_embeddings && !bt->input_ids) return fail(MI_ERR_ARG, "mi_forward: input_ids");
   if (bt->logits && (!m->final_norm || !m->output)) return fail(MI_ERR_ARG, "mi_forward: logits on a rank without LM head");
   hipStream_t s = (hipStream_t)stream;
 
@@ -271,13 +276,16 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
   const bool gemv = T <= GEMV_MAX_T;
   bf16_t* h = (bf16_t*)bt->h;
 
-  if (branch == MI_BRANCH_DECODE && m->tok_embeddings) {
+  // input_ids == NULL: h already holds this stage's input - received from the previous pipeline rank, or the multimodal
+  // embeddings of transformer.py:190-191 (text rows from mi_embedding, image rows from the vision tower)
+  const bool embed = m->tok_embeddings && bt->input_ids;
+  if (branch == MI_BRANCH_DECODE && embed) {
     MI_TRY(hip_rc(launch_decode_prep_embedding(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, h,
                                                m->tok_embeddings, bt->input_ids, D, m->vocab_size, s), "decode_prep+embedding"));
   } else {
     if (branch == MI_BRANCH_DECODE)
       MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, s), "decode_prep"));
-    if (m->tok_embeddings)
+    if (embed)
       MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, s), "embedding"));
   }
 
@@ -326,6 +334,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       a.out = ws.attn; a.qkv = ws.qkv; a.ld = qkv_cols; a.cache_k = (const bf16_t*)ck; a.cache_v = (const bf16_t*)cv;
       a.W = has_cache ? W : T; a.B = B; a.max_q_len = has_cache ? bt->max_q_len : T; a.H = H; a.Hkv = Hkv; a.Dh = Dh;
       a.q_start = bt->q_start; a.kv_before = bt->kv_before; a.causal = has_cache ? 1 : 0;
+      a.scale = 1.0f / sqrtf((float)m->head_dim);
       MI_TRY(hip_rc(launch_attn_prefill(a, s), "attn_prefill"));
       if (has_cache)
         MI_TRY(hip_rc(launch_kv_write(ck, cv, W, ws.qkv + nq, ws.qkv + nq + nkv, qkv_cols, T, nkv, bt->tok_seq, bt->tok_pos,

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  const float sc = rsqrtf((float)DH) * LOG2E;
+  const float sc = a.scale * LOG2E;
 
   // ---- staging assignment.  K: 16-byte piece p = tid + NT*j -> key p >> 4, slot p & 15.  V: a thread takes the same
   // 16-byte d slice of KPT consecutive keys (4 with 256 threads, 2 with 512) and transposes them in registers.

@@ -298,7 +298,21 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(bf16_t* out, const bf1
   }
 }
 
+// nn.GELU() (exact erf form) on a bf16 tensor: evaluated in fp32, rounded once (vision_encoder.py:112-116).
+__global__ __launch_bounds__(256) void gelu_kernel(bf16_t* x, int ldx, int N) {
+  bf16_t* row = x + (size_t)blockIdx.x * ldx;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float v = bf_to_f(row[i]);
+    row[i] = f_to_bf(0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)));
+  }
+}
+
 }  // namespace
+
+hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s) {
+  hipLaunchKernelGGL(gelu_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)x, ldx, N);
+  return hipGetLastError();
+}
 
 hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s) {
   hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)table, ids, D, vocab);

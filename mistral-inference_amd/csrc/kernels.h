@@ -111,10 +111,12 @@ struct AttnPrefillArgs {
   const int32_t* q_start;    // [B+1]
   const int32_t* kv_before;  // [B]
   int causal;
+  float scale;  // softmax scale (already validated: > 0)
 };
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- elementwise
+hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s);
 hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s);
 hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s);
 hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const float* rope_cs, const int32_t* tok_pos,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libmistral_hip.so"))
 
-MI_ABI_VERSION = 1
+MI_ABI_VERSION = 2
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
 BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
 GEMV_MAX_T = 8
@@ -62,7 +62,8 @@ _SIGS = {
     "mi_attn_decode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mi_attn_decode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "mi_attn_prefill": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp,
-                                  _vp, C.c_int, _vp]),
+                                  _vp, C.c_int, C.c_float, _vp]),
+    "mi_gelu": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
     "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
@@ -193,14 +194,23 @@ def attn_decode(q: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, n
 
 def attn_prefill(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int, cache_k: Optional[torch.Tensor],
                  cache_v: Optional[torch.Tensor], W: int, q_start: Optional[torch.Tensor],
-                 kv_before: Optional[torch.Tensor], B: int, max_q_len: int, causal: bool = True) -> torch.Tensor:
+                 kv_before: Optional[torch.Tensor], B: int, max_q_len: int, causal: bool = True,
+                 softmax_scale: float = 0.0) -> torch.Tensor:
+    """softmax_scale <= 0: head_dim ** -0.5."""
     T = qkv.shape[0]
     out = torch.empty((T, n_heads * head_dim), dtype=qkv.dtype, device=qkv.device)
     check(lib().mi_attn_prefill(dev_ptr(out), dev_ptr(qkv), qkv.stride(0), dev_ptr(cache_k), dev_ptr(cache_v), W, B,
                                 max_q_len, n_heads, n_kv_heads, head_dim, dev_ptr(q_start, torch.int32),
-                                dev_ptr(kv_before, torch.int32), 1 if causal else 0, stream_ptr(qkv.device)),
-          "mi_attn_prefill")
+                                dev_ptr(kv_before, torch.int32), 1 if causal else 0, float(softmax_scale),
+                                stream_ptr(qkv.device)), "mi_attn_prefill")
     return out
+
+
+def gelu_(x: torch.Tensor) -> torch.Tensor:
+    """In-place exact GELU on a 2-D bf16 tensor."""
+    assert x.dim() == 2
+    check(lib().mi_gelu(dev_ptr(x), x.stride(0), x.shape[0], x.shape[1], stream_ptr(x.device)), "mi_gelu")
+    return x
 
 
 def moe_router(x: torch.Tensor, gate: torch.Tensor, top_k: int, norm_w: Optional[torch.Tensor] = None, eps: float = 0.0):

@@ -31,8 +31,12 @@ def generate(
     chunk_size: Optional[int] = None,
     eos_id: Optional[int] = None,
 ) -> Tuple[List[List[int]], List[List[float]]]:
-    if images and any(len(i) for i in images):
-        raise NotImplementedError("images: the Pixtral vision tower is outside the forward_partial hot path")
+    images_torch: List[List[torch.Tensor]] = []
+    if images:  # reference generate.py:54-60: one list of [C, H, W] arrays per sample; no chunking with images
+        assert chunk_size is None
+        images_torch = [[torch.as_tensor(im).to(device=model.device, dtype=model.dtype) for im in images_for_sample]
+                        for images_for_sample in images]
+    flattened_images: List[torch.Tensor] = sum(images_torch, [])
     model = model.eval()
     B, V = len(encoded_prompts), model.args.vocab_size
     seqlens = [len(x) for x in encoded_prompts]
@@ -57,7 +61,7 @@ def generate(
         prompt_chunks = [p[s: s + chunk_size] for p in encoded_prompts]
         assert all(len(p) > 0 for p in prompt_chunks)
         flat = torch.tensor(sum(prompt_chunks, []), device=dev, dtype=torch.long)
-        prelogits = model.forward(flat, seqlens=[len(p) for p in prompt_chunks], cache=cache)
+        prelogits = model.forward(flat, seqlens=[len(p) for p in prompt_chunks], cache=cache, images=flattened_images)
         logits = torch.log_softmax(prelogits, dim=-1)
 
         if last_token_prelogits is not None:

@@ -33,6 +33,7 @@ from .cache import BatchMetadata, BufferCache
 from .model import ModelBase
 from .rope import precompute_freqs_cis
 from .transformer_layers import RMSNorm, TransformerBlock
+from .vision_encoder import PATCH_MERGE, PatchMerger, VisionLanguageAdapter, VisionTransformer
 
 ROPE_TABLE_LEN = 128_000  # reference transformer.py:116
 
@@ -159,8 +160,6 @@ class Transformer(ModelBase):
         self.pipeline_rank = pipeline_rank
         self.num_pipeline_ranks = num_pipeline_ranks
         self.softmax_fp32 = softmax_fp32
-        if args.vision_encoder is not None:
-            raise NotImplementedError("the Pixtral vision tower is outside the forward_partial hot path (SURVEY.md 2a)")
         if args.lora is not None:
             raise NotImplementedError("un-merged LoRA is outside the hot path; merge the adapter into the weights")
 
@@ -168,9 +167,19 @@ class Transformer(ModelBase):
         self.tok_embeddings: Optional[nn.Embedding] = None
         self.norm: Optional[RMSNorm] = None
         self.output: Optional[nn.Linear] = None
-        self.vision_encoder = None
+        self.vision_encoder: Optional[VisionTransformer] = None
+        self.vision_language_adapter: Optional[VisionLanguageAdapter] = None
         if pipeline_rank == 0:
             self.tok_embeddings = nn.Embedding(args.vocab_size, args.dim)
+            if args.vision_encoder is not None:  # Pixtral tower lives on the first stage (reference transformer.py:59-76)
+                ve = args.vision_encoder
+                self.vision_encoder = VisionTransformer(ve)
+                self.vision_language_adapter = VisionLanguageAdapter(ve.hidden_size, args.dim, ve.adapter_bias)
+                if ve.add_pre_mm_projector_layer_norm:
+                    self.pre_mm_projector_norm = RMSNorm(ve.hidden_size, eps=1e-5)
+                if ve.mm_projector_id == PATCH_MERGE:
+                    self.patch_merger = PatchMerger(vision_encoder_dim=ve.hidden_size,
+                                                    spatial_merge_size=ve.spatial_merge_size)
         if pipeline_rank == num_pipeline_ranks - 1:
             self.norm = RMSNorm(args.dim, eps=args.norm_eps)
             self.output = nn.Linear(args.dim, args.vocab_size, bias=False)
@@ -210,8 +219,7 @@ class Transformer(ModelBase):
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / dtype casts move the weights: rebuild pointer tables
         out = super()._apply(fn, *a, **k)
-        if hasattr(self._backend, "invalidate"):
-            self._backend.invalidate()
+        self._weights_changed()
         return out
 
     # ---- forward -------------------------------------------------------------------------------
@@ -221,22 +229,56 @@ class Transformer(ModelBase):
         blob = torch.tensor([0, T] + [0] + [0] * T + pos, dtype=torch.int32).to(self.device)
         return BatchMetadata(_hip.BRANCH_NOCACHE, [T], T, blob[:2], blob[2:3], blob[3:3 + T], blob[3 + T:])
 
+    def embed_vision_language_features(self, input_ids: torch.Tensor, images: List[torch.Tensor]) -> torch.Tensor:
+        """Token embeddings with the image-token rows replaced by the adapter's image features, in order (reference
+        transformer.py:122-161)."""
+        assert self.tok_embeddings is not None
+        assert self.vision_encoder is not None
+        assert self.vision_language_adapter is not None
+        ve = self.args.vision_encoder
+        assert ve is not None
+        dev = self.device
+        input_ids = input_ids.to(dev)
+        image_locations = input_ids == ve.image_token_id
+        text_locations = ~image_locations
+        image_features = self.vision_encoder(images)
+        if ve.add_pre_mm_projector_layer_norm:
+            image_features = self.pre_mm_projector_norm(image_features)
+        if ve.mm_projector_id == PATCH_MERGE:
+            img_patch_dims = [(img.shape[1] // ve.patch_size, img.shape[2] // ve.patch_size) for img in images]
+            image_features = self.patch_merger(image_features, image_sizes=img_patch_dims)
+        image_features = self.vision_language_adapter(image_features)
+        N_txt, (N_img, D_img) = int(text_locations.sum()), image_features.shape
+        seq_len = input_ids.shape[0]
+        assert self.args.dim == D_img, f"Text features dim {self.args.dim} should be equal to image features dim {D_img}"
+        assert seq_len == N_txt + N_img, (
+            f"seq_len {seq_len} should be equal to N_txt + N_img {(N_txt, N_img, int(image_locations.sum()))}")
+        combined = torch.empty((seq_len, D_img), dtype=self.dtype, device=dev)
+        if N_txt:
+            combined[text_locations, :] = _hip.embedding(self.tok_embeddings.weight, input_ids[text_locations])
+        combined[image_locations, :] = image_features
+        return combined
+
     def _run(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
-             want_logits: bool):
+             want_logits: bool, images: Optional[List[torch.Tensor]] = None):
         assert len(seqlens) <= self.args.max_batch_size, (
             f"Max batch size is {self.args.max_batch_size}, got batch size of {len(seqlens)}")
         (num_toks,) = input_ids.shape
         assert sum(seqlens) == num_toks, (sum(seqlens), num_toks)
         meta = cache.batch_metadata(seqlens) if cache is not None else self._nocache_metadata(seqlens)
         dev = self.device
-        h = torch.empty((num_toks, self.args.dim), device=dev, dtype=self.dtype)
+        multimodal = self.pipeline_rank == 0 and self.vision_encoder is not None and bool(images)
+        if multimodal:  # reference transformer.py:190-191
+            h = self.embed_vision_language_features(input_ids, images)
+        else:
+            h = torch.empty((num_toks, self.args.dim), device=dev, dtype=self.dtype)
         if self.pipeline_rank > 0:
             torch.distributed.recv(h, src=self.pipeline_rank - 1)
         last = self.pipeline_rank == self.num_pipeline_ranks - 1
         logits = None
         if want_logits and last:
             logits = torch.empty((num_toks, self.vocab_size), device=dev, dtype=torch.float32)
-        ids = input_ids.to(device=dev, dtype=torch.long) if self.pipeline_rank == 0 else None
+        ids = input_ids.to(device=dev, dtype=torch.long) if (self.pipeline_rank == 0 and not multimodal) else None
         self._backend.run_stack(self, h, ids, meta, cache, logits)
         if cache is not None:
             if meta.branch == _hip.BRANCH_DECODE:
@@ -251,9 +293,7 @@ class Transformer(ModelBase):
                         images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """Local forward pass (reference transformer.py:163-219): the activations of this stage's last layer,
         RMS-normalised on the last stage."""
-        if images:
-            raise NotImplementedError("images: the vision tower is outside the hot path")
-        h, _ = self._run(input_ids, seqlens, cache, want_logits=False)
+        h, _ = self._run(input_ids, seqlens, cache, want_logits=False, images=images)
         return h
 
     # ---- decode step as a hipGraph ----------------------------------------------------------------
@@ -301,14 +341,12 @@ class Transformer(ModelBase):
     def forward(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache] = None,
                 images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """Logits [T, vocab] (reference transformer.py:221-242): fp32 unless softmax_fp32=False."""
-        if images:
-            raise NotImplementedError("images: the vision tower is outside the hot path")
         st = self._graphed
         if (st is not None and cache is st["cache"] and cache._seen is not None and cache._seen[0] > 0
                 and all(s == 1 for s in seqlens) and len(seqlens) == len(cache._seen)
                 and (st["graph"] is None or len(seqlens) == st["B"])):
             return self._graphed_step(input_ids, seqlens, cache, st)
-        h, logits = self._run(input_ids, seqlens, cache, want_logits=True)
+        h, logits = self._run(input_ids, seqlens, cache, want_logits=True, images=images)
         if self.num_pipeline_ranks > 1:
             # every rank receives the logits in the model dtype, as the reference does (transformer.py:229-237);
             # the kernel's fp32 logits are bf16-representable, so the narrowing is exact
@@ -334,7 +372,7 @@ class Transformer(ModelBase):
                 keep = k.split(".")[1] in self.layers
             elif any(k.startswith(p) for p in ("vision_encoder", "vision_language_adapter", "patch_merger",
                                                "pre_mm_projector_norm")):
-                raise NotImplementedError(f"vision weights ({k}) are outside the hot path")
+                keep = self.pipeline_rank == 0
             else:
                 raise ValueError(f"Unexpected key {k}")
             if keep:
@@ -344,8 +382,7 @@ class Transformer(ModelBase):
                 skipped.add(k)
         assert set(state_dict.keys()) == skipped.union(set(mine.keys()))
         super().load_state_dict(mine, strict=strict, assign=assign)
-        if hasattr(self._backend, "invalidate"):
-            self._backend.invalidate()
+        self._weights_changed()
 
     # ---- LoRA (reference lora.py:92-139): adapters are MERGED into the frozen weights at load time -------------
     def load_lora(self, lora_path: Union[Path, str], scaling: float = 2.0) -> None:
@@ -419,11 +456,19 @@ class Transformer(ModelBase):
         missing = wanted - set(loaded)
         assert not missing, f"checkpoint is missing {sorted(missing)[:4]}..."
         nn.Module.load_state_dict(model, loaded, strict=True, assign=True)
-        model._backend.invalidate() if hasattr(model._backend, "invalidate") else None
+        model._weights_changed()
         return model.to(device=device, dtype=dtype)
+
+    def _weights_changed(self) -> None:
+        """Pointer tables / derived weight images are rebuilt lazily after any (re)load."""
+        if hasattr(self._backend, "invalidate"):
+            self._backend.invalidate()
+        if self.vision_language_adapter is not None:
+            self.vision_language_adapter.invalidate()
 
     def _check_foreign_key(self, k: str) -> None:
         """A key this rank does not own must still be a known kind (reference raises on anything else)."""
-        known = ("tok_embeddings", "norm", "output", "layers")
+        known = ("tok_embeddings", "norm", "output", "layers", "vision_encoder", "vision_language_adapter", "patch_merger",
+                 "pre_mm_projector_norm")
         if not any(k.startswith(p) for p in known):
             raise ValueError(f"Unexpected key {k}")

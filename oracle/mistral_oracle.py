@@ -296,9 +296,9 @@ class OracleModel:
             starts = [0] * len(seqlens)
         positions = torch.cat([torch.arange(p, p + s) for p, s in zip(starts, seqlens)])
         cs = self.angles[positions]
-        if self.pipeline_rank == 0:
+        if self.pipeline_rank == 0 and h_in is None:
             h = F.embedding(input_ids, self.w["tok_embeddings.weight"])
-        else:
+        else:  # received from the previous rank - or, on rank 0, the multimodal embeddings of transformer.py:190-191
             assert h_in is not None
             h = h_in
         for local_i, i in enumerate(self.layer_ids):

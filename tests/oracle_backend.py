@@ -40,7 +40,8 @@ class OracleStackBackend:
                 run += 1
             seqlens.append(run)
         ids = input_ids if input_ids is not None else torch.zeros(h.shape[0], dtype=torch.long)
-        out = om.forward_partial(ids, seqlens, ocache, h_in=h.clone())
+        # input_ids present: the stack embeds them; absent: h is the input (later pipeline rank / multimodal embeddings)
+        out = om.forward_partial(ids, seqlens, ocache, h_in=None if input_ids is not None else h.clone())
         if logits is not None:
             logits.copy_(F.linear(out, om.w["output.weight"]).float())
         h.copy_(out)
