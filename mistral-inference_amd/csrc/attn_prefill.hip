@@ -336,6 +336,6 @@ hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
   }
   // 256-query blocks once they still give every CU a block (one 8-wave block per CU), else 128-query blocks
   const long blocks8 = (long)((a.max_q_len + 255) / 256) * a.H * (a.causal ? a.B : 1);
-  const bool eight = force ? force == 8 : blocks8 >= 256;
+  const bool eight = force ? force == 8 : blocks8 >= device_cus();
   return eight ? launch_nw<8>(a, s) : launch_nw<4>(a, s);
 }

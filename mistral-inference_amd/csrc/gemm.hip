@@ -286,7 +286,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.tile_tab && g.tile_rows == 256) return gemm256_applicable(g) ? launch_gemm256(g, s) : hipErrorInvalidValue;
   if (!use_256 || !gemm256_applicable(g)) return launch_gemm128(g, s);
   if (g.tile_tab) return launch_gemm256(g, s);
-  // One 256x256 block per CU: a tile count that is not a multiple of the 256 CUs leaves the last round partly empty
+  // One 256x256 block per CU: a tile count that is not a multiple of the CU count (256) leaves the last round partly empty
   // (q|k|v of Mistral-7B: 384 tiles = 1.5 rounds cost 2).  When the last round would be under 3/4 full, the columns
   // are split: full rounds on the 256 kernel, the remaining columns on the 128 kernel (two blocks per CU, four times
   // the tiles) - MI_GEMM_TAIL=0 disables the split.
@@ -298,11 +298,12 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   const int nout = (g.epi == GEMM_SWIGLU) ? 128 : 256;
   const int m_tiles = (g.M + 255) / 256, n_tiles = (g.N + nout - 1) / nout;
   const long tiles = (long)m_tiles * n_tiles;
-  const int rem = (int)(tiles % 256);
-  if (split_tail && tiles > 256 && rem != 0 && rem < 192) {
-    int a = 256, b = m_tiles;  // n_first = largest multiple of 256 / gcd(256, m_tiles) not above n_tiles
+  const int cus = device_cus();
+  const int rem = (int)(tiles % cus);
+  if (split_tail && tiles > cus && rem != 0 && rem < cus * 3 / 4) {
+    int a = cus, b = m_tiles;  // n_first = largest multiple of cus / gcd(cus, m_tiles) not above n_tiles
     while (b) { const int t = a % b; a = b; b = t; }
-    const int step = 256 / a;
+    const int step = cus / a;
     const int n_first = (n_tiles / step) * step;
     if (n_first > 0 && n_first < n_tiles) {
       const int c0 = n_first * nout;

@@ -164,8 +164,8 @@ int gemv_max_tokens(int K) {
 hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   if (g_gemv_max_blocks == 0) {
     const char* e = getenv("MI_GEMV_MAX_BLOCKS");
-    g_gemv_max_blocks = e ? atoi(e) : 512;
-    if (g_gemv_max_blocks <= 0) g_gemv_max_blocks = 512;
+    g_gemv_max_blocks = e ? atoi(e) : 2 * device_cus();  // 2 blocks per CU measured best on MI355X
+    if (g_gemv_max_blocks <= 0) g_gemv_max_blocks = 2 * device_cus();
   }
   const bool pair_mode = !(a.mode == GEMV_SWIGLU || a.mode == GEMV_MOE_W13);
   // single-row units when row pairs would leave CUs without a full set of waves (256 CUs x 4 blocks x 4 waves)
@@ -181,10 +181,11 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   // multiple of the 256 CUs (even load per CU), at most 4 per CU, and divides the units exactly - e.g. W1|W3: 14336
   // units -> 512 blocks x 4 waves x 7 units; q|k|v: 3072 units -> 768 blocks x 1.  Otherwise the smallest k that fits
   // g_gemv_max_blocks (512 = 2 blocks per CU measured best on MI355X).
+  const int cus = device_cus();
   int blocks = 0;
   for (int k = 1; k <= 64 && !blocks; ++k) {
     const int b = (units + 4 * k - 1) / (4 * k);
-    if (b <= 1024 && b % 256 == 0 && b * 4 * k == units && (b <= g_gemv_max_blocks || k == 1)) blocks = b;
+    if (b <= 4 * cus && b % cus == 0 && b * 4 * k == units && (b <= g_gemv_max_blocks || k == 1)) blocks = b;
   }
   if (!blocks) {
     const int k = (units + 4 * g_gemv_max_blocks - 1) / (4 * g_gemv_max_blocks);

@@ -115,6 +115,21 @@ struct AttnPrefillArgs {
 };
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s);
 
+// Compute units of the current device (256 on a full MI355X; fewer in partitioned modes).  Grid-shaping heuristics
+// (rounds of blocks, tail splitting) use it; results never depend on it.
+inline int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 // ---------------------------------------------------------------------------------------------- elementwise
 hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s);
 hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s);
