@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar control flow
   const int g = lane >> 4, dl = lane & 15;
-  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  // Workgroup i runs on XCD i % 8: consecutive ids cycle through the kv heads, so (Hkv = 8) every split of a kv head
+  // - and the combine block that merges them - sits on ONE XCD and the fp32 partials are re-read from that XCD's L2.
+  const int kvh = blockIdx.x % a.Hkv, split = blockIdx.x / a.Hkv, b = blockIdx.y;
   const int pos = a.tok_pos[b];
   const int kv_len = min(pos + 1, a.W);
   int chunk = (a.W + a.n_splits - 1) / a.n_splits;
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 // accumulator column) are independent and issued together: one memory round trip instead of a chain.
 template <int NS>  // upper bound on n_splits held in registers
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs a) {
-  const int d = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
-  const int R = a.H / a.Hkv, kvh = h / R, r = h % R;
+  const int d = threadIdx.x, b = blockIdx.y;
+  const int R = a.H / a.Hkv, kvh = blockIdx.x % a.Hkv, r = blockIdx.x / a.Hkv, h = kvh * R + r;  // same XCD as the splits
   const int bh = b * a.Hkv + kvh;
   const float* all_acc = a.partial + (size_t)bh * a.n_splits * R * DH + (size_t)r * DH + d;
   const float* all_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + (size_t)bh * a.n_splits * R * 2 + r * 2;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
 
 template <int R>
 void launch_r(const AttnDecodeArgs& a, hipStream_t s) {
-  dim3 grid(a.n_splits, a.Hkv, a.B), block(256);
+  dim3 grid(a.n_splits * a.Hkv, a.B), block(256);
   hipLaunchKernelGGL((attn_decode_kernel<R>), grid, block, 0, s, a);
   if (a.n_splits <= 16) hipLaunchKernelGGL((attn_decode_combine_kernel<16>), dim3(a.H, a.B), dim3(128), 0, s, a);
   else hipLaunchKernelGGL((attn_decode_combine_kernel<32>), dim3(a.H, a.B), dim3(128), 0, s, a);  // n_splits <= 32
