@@ -261,36 +261,41 @@ def main() -> None:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt, prefill_s = tmax.tolist()
 
-    if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
-    ctx_len = T0 + Wm + K // 2
-    step_bytes = decode_bytes_per_token(params, ctx_len)
-    ms = dt / K * 1e3
-    step_gbs = step_bytes / (dt / K) / 1e9
-    out = {
-        "metric": "decode tokens/sec/GPU (batch=1, seq=1)", "value": round(K / dt, 2), "unit": "tokens/s",
-        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{model_name} dims, {params['n_layers']} layers, random-init bf16, "
-                               f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
-                   "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
-                   "decode_launch": "eager" if (opt.no_graph or world > 1) else "hipGraph replay",
-                   "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
-        "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
-                              "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
-        "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),
-                    "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
-                    "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
-    }
-    if world == 1 and not params.get("moe"):
-        out["roofline"] = dominant_kernel_roofline(model, iters=4)
-        if not opt.no_cpu_baseline:
+
+    def report() -> dict:
+        ctx_len = T0 + Wm + K // 2
+        step_bytes = decode_bytes_per_token(params, ctx_len)
+        ms = dt / K * 1e3
+        step_gbs = step_bytes / (dt / K) / 1e9
+        out = {
+            "metric": "decode tokens/sec/GPU (batch=1, seq=1)", "value": round(K / dt, 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{model_name} dims, {params['n_layers']} layers, random-init bf16, "
+                                   f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
+                       "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
+                       "decode_launch": "eager" if (opt.no_graph or world > 1) else "hipGraph replay",
+                       "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
+            "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
+                                  "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
+            "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),
+                        "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
+                        "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
+        }
+        if not params.get("moe"):  # the dominant kernel is timed on this rank's own layers (any N)
+            out["roofline"] = dominant_kernel_roofline(model, iters=4)
+        if world == 1 and not params.get("moe") and not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, T0)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+        return out
+
+
+
+    out = report() if rank == 0 else None
+    if world > 1:  # the other ranks wait here while rank 0 times its dominant kernel, then everybody leaves together
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -60,3 +60,23 @@ def test_two_stage_pipeline_on_hip(name, tmp_path):
         assert n >= 1, (name, b, mine, ref)
         npl = len(case.prompts[b]) - 1 + n
         assert max(abs(x - y) for x, y in zip(lp0[b][:npl], ref_lps[b][:npl])) <= 6e-2
+
+
+def test_bench_two_ranks_prints_one_json_line():
+    """bench.py's N > 1 path (pipeline stages, max-over-ranks timing, rank-0 report, orderly shutdown) with two ranks
+    sharing this box's GPU over gloo; on a multi-GPU node the same code runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--layers", "4", "--prefill", "256"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
