@@ -98,6 +98,7 @@ def test_logits_vs_reference_and_oracle(name, tmp_path):
         return keep
 
     worst, compared = 0.0, 0
+    within, elems, abs_sum = 0, 0, 0.0  # BASELINE.json's "within 1e-2 max-abs": see the note below
     refs = [case.t.get(f"prefill_logits.{c}") for c in range(len(pre))] + \
            [case.t.get(f"decode_logits.{s}") for s in range(len(dec))]
     for f, (got, ref) in enumerate(zip(pre + dec, o_pre + o_dec)):
@@ -107,10 +108,23 @@ def test_logits_vs_reference_and_oracle(name, tmp_path):
         if r:
             worst = max(worst, (got[r] - ref[r]).abs().max().item())
             if case.dtype == BF:  # stored outputs of the unmodified reference
-                assert (got[r] - refs[f][r]).abs().max().item() <= LOGIT_ATOL, (name, "vs reference", f)
+                d = (got[r] - refs[f][r]).abs()
+                assert d.max().item() <= LOGIT_ATOL, (name, "vs reference", f)
+                within += int((d <= 1e-2).sum())
+                elems += d.numel()
+                abs_sum += float(d.sum())
     total = sum(sum(s) for s in schedule)
     assert compared >= 0.5 * total, (name, "too many tie-ambiguous rows", compared, total)
     assert worst <= LOGIT_ATOL, (name, "vs bf16 oracle", worst)
+    if elems:
+        # The north star asks for logits within 1e-2 max-abs of the reference.  Logits are bf16 VALUES (the LM head
+        # rounds to bf16 before .float(), transformer.py:235-242): for |x| in [1, 2) two neighbouring bf16 numbers are
+        # 7.8e-3 apart and for |x| in [2, 4) 1.56e-2, so ANY two bf16 implementations whose fp32 sums differ in the last
+        # bit differ by more than 1e-2 on some elements (the reference does so against itself when only its CPU thread
+        # count changes).  What is asserted: max-abs within the 2-3 ulp bound above, at least 97 %
+        # of all logits within 1e-2, and a mean error an order of magnitude below it.
+        assert within >= 0.97 * elems, (name, "fraction of logits within 1e-2 of the reference", within / elems)
+        assert abs_sum / elems <= 2.5e-3, (name, "mean abs logit error vs the reference", abs_sum / elems)
 
 
 @pytest.mark.parametrize("name", [c for c in CASES if c.endswith("bf16")])
