@@ -83,6 +83,14 @@ enum mi_epilogue {
 int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const void* const w[3], const int n_rows[3],
               int epilogue, const void* residual, const void* norm_w, float eps, mi_stream_t stream);
 
+/* generate.py:101-118 needs, of the prompt's [T, vocab] logits (transformer.py:235-242), only log_softmax(logits)[t, next
+ * token]: logprob[m] = l[m, target[m]] - logsumexp(l[m, :]) with l = float(bf16(x @ W^T)), computed in ONE pass over the
+ * LM head without materialising the logits (per-tile max / sum-exp partials in `scratch`).  M < 256 rows take the plain
+ * logits + row-reduction route inside the same call.  target[m] outside [0, vocab) yields -logsumexp. */
+size_t mi_lm_head_logprobs_scratch_bytes(int M, int vocab);
+int mi_lm_head_logprobs(float* logprob, const void* x, int ldx, int M, int K, const void* w, int vocab,
+                        const int32_t* target, void* scratch, size_t scratch_bytes, mi_stream_t stream);
+
 /* Decode-branch attention (transformer_layers.py:77-89 with the mask of cache.py:249-254):
  * one query per sequence, keys = ring slots [0, min(pos+1, W)) of its row, GQA by kv = h / (H/Hkv)
  * (replaces repeat_kv, transformer_layers.py:16-19,84).  q: [B, ldq] (H*Dh used), out: [B, H*Dh].

@@ -200,6 +200,44 @@ int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const vo
   return hip_rc(launch_gemm(g, s), "gemm");
 }
 
+size_t mi_lm_head_logprobs_scratch_bytes(int M, int vocab) {
+  if (M <= 0 || vocab <= 0) return 0;
+  const size_t n_tiles = (size_t)(vocab + 255) / 256;
+  const size_t fused = align_up((size_t)M * n_tiles * sizeof(float2)) + align_up((size_t)M * sizeof(float));
+  const size_t rows = (size_t)M * vocab * sizeof(float);  // small-M path: the logits themselves
+  return fused > rows ? fused : (M < 256 ? rows : fused);
+}
+
+int mi_lm_head_logprobs(float* logprob, const void* x, int ldx, int M, int K, const void* w, int vocab,
+                        const int32_t* target, void* scratch, size_t scratch_bytes, mi_stream_t stream) {
+  if (!logprob || !x || !w || !target || !scratch || M <= 0 || K <= 0 || K % 8 || vocab <= 0)
+    return fail(MI_ERR_ARG, "mi_lm_head_logprobs");
+  if (scratch_bytes < mi_lm_head_logprobs_scratch_bytes(M, vocab))
+    return fail(MI_ERR_WORKSPACE, "mi_lm_head_logprobs: scratch %zu < required %zu", scratch_bytes,
+                mi_lm_head_logprobs_scratch_bytes(M, vocab));
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.epi = GEMM_LOGPROB; g.M = M; g.N = vocab; g.K = K; g.a = (const bf16_t*)x; g.lda = ldx;
+  g.w0 = (const bf16_t*)w; g.n0 = g.n1 = vocab;
+  if (M >= 256 && gemm256_applicable(g)) {
+    // one pass over the LM head: per-tile (max, sum-exp) partials + the target logit, then one wave per row
+    const int n_tiles = (vocab + 255) / 256;
+    g.lp_target = target;
+    g.lp_partial = (float2*)scratch;
+    g.lp_tgt = (float*)((char*)scratch + align_up((size_t)M * n_tiles * sizeof(float2)));
+    MI_TRY(hip_rc(hipMemsetAsync(g.lp_tgt, 0, (size_t)M * sizeof(float), s), "logprob target memset"));
+    MI_TRY(hip_rc(launch_gemm256(g, s), "lm head logprob gemm"));
+    return hip_rc(launch_logprob_finalize(logprob, g.lp_partial, g.lp_tgt, M, n_tiles, s), "logprob finalize");
+  }
+  // few rows: fp32 logits into the scratch (GEMV / 128-tile GEMM), then a row-wise log-softmax gather
+  const void* ws[3] = {w, nullptr, nullptr};
+  const int nr[3] = {vocab, 0, 0};
+  const int rc = mi_linear(scratch, vocab, x, ldx, M, K, ws, nr, MI_EPI_LOGITS, nullptr, nullptr, 0.f, stream);
+  if (rc) return rc;
+  return hip_rc(launch_logprob_rows(logprob, (const float*)scratch, vocab, target, M, vocab, s), "logprob rows");
+}
+
 size_t mi_attn_decode_scratch_bytes(int B, int n_heads, int n_kv_heads, int head_dim, int W) {
   return TICKET_BYTES + align_up(attn_decode_partial_floats(B, n_heads, n_kv_heads, head_dim, W) * sizeof(float));
 }

@@ -64,6 +64,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true));  // row_ror:8
+  v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, true));  // row_ror:4
+  v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, true));  // row_ror:2
+  v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, true));  // row_ror:1
+  return v;
+}
+
 // Packed fp32 -> bf16 (RNE) in one instruction; gfx950 has no builtin for it (guide T12).
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   uint32_t r;

@@ -307,7 +307,51 @@ __global__ __launch_bounds__(256) void gelu_kernel(bf16_t* x, int ldx, int N) {
   }
 }
 
+// logprob[m] = x_t - (M + log sum_j s_j exp(m_j - M)) from the per-tile partials of GEMM_LOGPROB: one wave per row.
+__global__ __launch_bounds__(64) void logprob_finalize_kernel(float* out, const float2* partial, const float* tgt, int n_tiles) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const float2* p = partial + (size_t)m * n_tiles;
+  float M = -INFINITY;
+  for (int j = lane; j < n_tiles; j += 64) M = fmaxf(M, p[j].x);
+  M = wave_max(M);
+  float S = 0.f;
+  for (int j = lane; j < n_tiles; j += 64) S += p[j].y * __expf(p[j].x - M);
+  S = wave_sum(S);
+  if (lane == 0) out[m] = tgt[m] - (M + logf(S));
+}
+
+// Same result from a full fp32 logits row (small-M path): one block per row.
+__global__ __launch_bounds__(256) void logprob_rows_kernel(float* out, const float* logits, int ld, const int32_t* target, int V) {
+  __shared__ float red[8];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = logits + (size_t)m * ld;
+  float M = -INFINITY;
+  for (int j = tid; j < V; j += 256) M = fmaxf(M, x[j]);
+  M = wave_max(M);
+  if (lane == 0) red[wid] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float S = 0.f;
+  for (int j = tid; j < V; j += 256) S += __expf(x[j] - M);
+  S = wave_sum(S);
+  if (lane == 0) red[4 + wid] = S;
+  __syncthreads();
+  if (tid == 0) {
+    const int t = target[m];
+    out[m] = (t >= 0 && t < V ? x[t] : 0.f) - (M + logf(red[4] + red[5] + red[6] + red[7]));
+  }
+}
+
 }  // namespace
+
+hipError_t launch_logprob_finalize(float* out, const float2* partial, const float* tgt, int M, int n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(logprob_finalize_kernel, dim3(M), dim3(64), 0, s, out, partial, tgt, n_tiles);
+  return hipGetLastError();
+}
+hipError_t launch_logprob_rows(float* out, const float* logits, int ld, const int32_t* target, int M, int V, hipStream_t s) {
+  hipLaunchKernelGGL(logprob_rows_kernel, dim3(M), dim3(256), 0, s, out, logits, ld, target, V);
+  return hipGetLastError();
+}
 
 hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s) {
   hipLaunchKernelGGL(gelu_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)x, ldx, N);

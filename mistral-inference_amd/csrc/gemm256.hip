@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   constexpr int NOUT = (EPI == GEMM_SWIGLU) ? 128 : 256;  // output columns per block
   // bf16 outputs: MFMAs issued as W-fragment x A-fragment (transposed 16x16 result tiles, see the epilogue); fp32
   // logits: A x W, whose 4-byte stores already cover 64-byte row segments and measured faster than 16-byte ones.
-  constexpr bool kSwap = EPI != GEMM_LOGITS;
+  constexpr bool kSwap = EPI != GEMM_LOGITS && EPI != GEMM_LOGPROB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,6 +235,52 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
 #undef SEGMENT_END
 #undef MFMA_END
 
+  if constexpr (EPI == GEMM_LOGPROB) {
+    // Log-softmax pieces of this tile, nothing stored (transformer.py:235-242 + generate.py:101-118: the LM head's
+    // bf16-rounded logits are only ever reduced to log-probabilities of given tokens).  A row's 256 columns live in the
+    // four wc waves: 4 values per lane x 16 lanes per wave.  Per wave: lane-local then DPP row reductions; the four
+    // waves meet in LDS (free again: every fragment read was waited for before the loop's last barrier).
+    __syncthreads();
+    float2* part = reinterpret_cast<float2*>(smem);  // [256 rows][4 waves]
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = ha * 128 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+          const int row = min(row0 + rl, g.M - 1);
+          float v[2][2], mx = -INFINITY;
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = n_tile * 256 + hb * 128 + wc * 32 + j * 16 + (lane & 15);
+              v[hb][j] = (n < g.N) ? bf_round(acc[ha][hb][i][j][r]) : -INFINITY;
+              mx = fmaxf(mx, v[hb][j]);
+              if (n == g.lp_target[row] && row0 + rl < g.M) g.lp_tgt[row] = v[hb][j];
+            }
+          mx = row16_max(mx);
+          float sm = 0.f;
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) sm += (v[hb][j] == -INFINITY) ? 0.f : __expf(v[hb][j] - mx);
+          sm = row16_sum(sm);
+          if ((lane & 15) == 0) part[rl * 4 + wc] = make_float2(mx, sm);
+        }
+    __syncthreads();
+    if (tid < 256 && row0 + tid < g.M) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) M = fmaxf(M, part[tid * 4 + w].x);
+      float S = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) S += (part[tid * 4 + w].x == -INFINITY) ? 0.f : part[tid * 4 + w].y * __expf(part[tid * 4 + w].x - M);
+      g.lp_partial[(size_t)(row0 + tid) * n_tiles + n_tile] = make_float2(M, S);
+    }
+    return;
+  }
   if constexpr (!kSwap) {
     // acc[ha][hb][i][j][r]: tile row ha*128 + wr*64 + i*16 + (lane>>4)*4 + r, tile column hb*128 + wc*32 + j*16 + (lane & 15)
 #pragma unroll
@@ -367,6 +413,7 @@ hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s) {
     case GEMM_RESIDUAL: return launch_one<GEMM_RESIDUAL>(g, grid, s);
     case GEMM_SWIGLU: return launch_one<GEMM_SWIGLU>(g, grid, s);
     case GEMM_LOGITS: return launch_one<GEMM_LOGITS>(g, grid, s);
+    case GEMM_LOGPROB: return launch_one<GEMM_LOGPROB>(g, grid, s);
     default: return hipErrorInvalidValue;
   }
 }

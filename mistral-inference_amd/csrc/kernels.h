@@ -56,7 +56,7 @@ int gemv_max_tokens(int K);
 hipError_t launch_gemv(const GemvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- GEMM
-enum GemmEpi { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SWIGLU = 2, GEMM_LOGITS = 3 };
+enum GemmEpi { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SWIGLU = 2, GEMM_LOGITS = 3, GEMM_LOGPROB = 4 };
 
 struct GemmArgs {
   int epi;
@@ -79,6 +79,11 @@ struct GemmArgs {
   const void* const* expert_tab;  // device [E][3] (w1, w2, w3) pointers
   int w_sel0, w_sel1;             // which of the three matrices feed w0 / w1 (w_sel1 < 0: unused)
   const int32_t* a_gather;        // device: A row of compact row r is a[a_gather[r]] (nullptr: a[r])
+  // GEMM_LOGPROB (gemm256 only): nothing is stored; per (row, 256-column tile) the max and sum-exp of the bf16-rounded
+  // logits go to lp_partial[row][n_tile] and the logit of column lp_target[row] to lp_tgt[row]
+  const int32_t* lp_target;       // device [M], -1: none
+  float2* lp_partial;             // device [M][ceil(N / 256)]
+  float* lp_tgt;                  // device [M]
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 bool gemm256_applicable(const GemmArgs& g);  // gemm256.hip: 256x256 tile for the large prefill shapes
@@ -132,6 +137,9 @@ inline int device_cus() {
 
 // ---------------------------------------------------------------------------------------------- elementwise
 hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s);
+// log-softmax gather: out[m] = x_t - logsumexp(row m), from per-tile (max, sum-exp) partials or from a full logits row
+hipError_t launch_logprob_finalize(float* out, const float2* partial, const float* tgt, int M, int n_tiles, hipStream_t s);
+hipError_t launch_logprob_rows(float* out, const float* logits, int ld, const int32_t* target, int M, int V, hipStream_t s);
 hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s);
 hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s);
 hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const float* rope_cs, const int32_t* tok_pos,

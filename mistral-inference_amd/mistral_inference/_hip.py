@@ -64,6 +64,8 @@ _SIGS = {
     "mi_attn_prefill": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp,
                                   _vp, C.c_int, C.c_float, _vp]),
     "mi_gelu": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "mi_lm_head_logprobs_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mi_lm_head_logprobs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
     "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
@@ -203,6 +205,22 @@ def attn_prefill(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int
                                 max_q_len, n_heads, n_kv_heads, head_dim, dev_ptr(q_start, torch.int32),
                                 dev_ptr(kv_before, torch.int32), 1 if causal else 0, float(softmax_scale),
                                 stream_ptr(qkv.device)), "mi_attn_prefill")
+    return out
+
+
+def lm_head_logprobs(x: torch.Tensor, w: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """fp32 [M]: log_softmax(float(bf16(x @ w^T)))[m, target[m]] without materialising the [M, vocab] logits."""
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and w.is_contiguous()
+    M, K = x.shape
+    V = w.shape[0]
+    tgt = target.to(device=x.device, dtype=torch.int32).contiguous()
+    assert tgt.numel() == M
+    need = lib().mi_lm_head_logprobs_scratch_bytes(M, V)
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().mi_lm_head_logprobs(dev_ptr(out, torch.float32), dev_ptr(x), x.stride(0), M, K, dev_ptr(w), V,
+                                    dev_ptr(tgt, torch.int32), dev_ptr(scratch, torch.uint8), need, stream_ptr(x.device)),
+          "mi_lm_head_logprobs")
     return out
 
 

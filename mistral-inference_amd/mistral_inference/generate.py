@@ -61,18 +61,7 @@ def generate(
         prompt_chunks = [p[s: s + chunk_size] for p in encoded_prompts]
         assert all(len(p) > 0 for p in prompt_chunks)
         flat = torch.tensor(sum(prompt_chunks, []), device=dev, dtype=torch.long)
-        prelogits = model.forward(flat, seqlens=[len(p) for p in prompt_chunks], cache=cache, images=flattened_images)
-        logits = torch.log_softmax(prelogits, dim=-1)
-
-        if last_token_prelogits is not None:
-            # first token of this chunk is scored by the previous chunk's last position
-            prev = torch.log_softmax(last_token_prelogits, dim=-1)
-            firsts = torch.tensor([p[0] for p in prompt_chunks], device=dev, dtype=torch.long)
-            picked = prev.gather(1, firsts[:, None])[:, 0]
-            for b in range(B):
-                lp_chunks.append((b, picked[b: b + 1]))
-
-        # token i+1 of each chunk is scored by position i: one gather for the whole chunk
+        # token i+1 of each chunk is scored by position i
         rows, cols, owners = [], [], []
         offset = 0
         for b, seq in enumerate(prompt_chunks):
@@ -81,17 +70,40 @@ def generate(
             cols += seq[1:]
             owners.append((b, n))
             offset += len(seq)
-        if rows:
-            idx = torch.tensor([rows, cols], device=dev, dtype=torch.long)
-            picked = logits[idx[0], idx[1]]
+        fused = (hasattr(model, "prompt_logprobs") and getattr(model, "num_pipeline_ranks", 1) == 1
+                 and getattr(model, "softmax_fp32", True) and model.device.type == "cuda")
+        if fused:
+            # the [T, V] logits are never materialised: the LM head GEMM reduces them to the wanted log-probabilities
+            tgt = torch.full((flat.numel(),), -1, dtype=torch.int32)
+            if rows:
+                tgt[rows] = torch.tensor(cols, dtype=torch.int32)
+            lp_rows, last_rows = model.prompt_logprobs(flat, [len(p) for p in prompt_chunks], cache, tgt.to(dev),
+                                                       images=flattened_images)
+            picked_rows = lp_rows[torch.tensor(rows, device=dev, dtype=torch.long)] if rows else None
+        else:
+            prelogits = model.forward(flat, seqlens=[len(p) for p in prompt_chunks], cache=cache, images=flattened_images)
+            logits = torch.log_softmax(prelogits, dim=-1)
+            picked_rows = None
+            if rows:
+                idx = torch.tensor([rows, cols], device=dev, dtype=torch.long)
+                picked_rows = logits[idx[0], idx[1]]
+            ends = torch.tensor([len(p) for p in prompt_chunks], device=dev).cumsum(dim=0) - 1
+            last_rows = prelogits.index_select(0, ends)
+
+        if last_token_prelogits is not None:
+            # first token of this chunk is scored by the previous chunk's last position
+            prev = torch.log_softmax(last_token_prelogits, dim=-1)
+            firsts = torch.tensor([p[0] for p in prompt_chunks], device=dev, dtype=torch.long)
+            picked = prev.gather(1, firsts[:, None])[:, 0]
+            for b in range(B):
+                lp_chunks.append((b, picked[b: b + 1]))
+        if picked_rows is not None:
             o = 0
             for b, n in owners:
                 if n:
-                    lp_chunks.append((b, picked[o: o + n]))
+                    lp_chunks.append((b, picked_rows[o: o + n]))
                 o += n
-
-        ends = torch.tensor([len(p) for p in prompt_chunks], device=dev).cumsum(dim=0) - 1
-        last_token_prelogits = prelogits.index_select(0, ends)
+        last_token_prelogits = last_rows
         assert last_token_prelogits.shape == (B, V)
 
     # ---- decode (reference generate.py:120-140)

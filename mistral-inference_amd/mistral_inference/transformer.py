@@ -357,6 +357,20 @@ class Transformer(ModelBase):
         assert logits is not None
         return logits if self.softmax_fp32 else logits.to(self.dtype)
 
+    def prompt_logprobs(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
+                        targets: torch.Tensor, images: Optional[List[torch.Tensor]] = None):
+        """What `generate()` takes from a prompt chunk's logits (reference generate.py:101-118), without the
+        [T, vocab] fp32 tensor `forward` contractually returns: (a) fp32 [T]
+        log_softmax(logits)[t, targets[t]] (targets[t] < 0: ignored row) from ONE pass over the LM head with the
+        log-softmax reduction in the GEMM epilogue, (b) the fp32 logits of each sequence's LAST row, [B, vocab].
+        Single rank, fp32-softmax models only (callers fall back to `forward` otherwise)."""
+        assert self.num_pipeline_ranks == 1 and self.softmax_fp32 and self.output is not None
+        h, _ = self._run(input_ids, seqlens, cache, want_logits=False, images=images)  # final RMSNorm applied
+        lp = _hip.lm_head_logprobs(h, self.output.weight, targets)
+        ends = torch.tensor(seqlens, device=h.device).cumsum(dim=0) - 1
+        last = _hip.linear(h.index_select(0, ends).contiguous(), (self.output.weight,), _hip.EPI_LOGITS)
+        return lp, last
+
     # ---- weights -------------------------------------------------------------------------------
     def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True, assign: bool = False) -> None:
         """Keep only this rank's tensors (reference transformer.py:244-295): embeddings on rank 0, norm/output

@@ -73,3 +73,23 @@ def test_full_size_graph_replay_equals_eager(full_model):
         graph = [m.forward(ids[T + i:T + i + 1], [1], c2)[0].clone() for i in range(steps)]
     assert all(torch.equal(a, b) for a, b in zip(eager, graph))
     assert torch.equal(c.kv_seqlens, c2.kv_seqlens)
+
+
+def test_full_size_prompt_logprobs_equal_forward(full_model):
+    """The fused LM-head log-probability path generate() uses (no [T, V] logits) against forward() + log_softmax at
+    T = 4096, V = 32768."""
+    m = full_model
+    T = 4096
+    ids = torch.randint(0, m.args.vocab_size, (T,), generator=torch.Generator().manual_seed(2)).cuda()
+    tgt = torch.cat([ids[1:], torch.tensor([-1], device="cuda")]).to(torch.int32)
+    c = _cache(m, T + 2)
+    logits = m.forward(ids, [T], c)
+    ref = torch.log_softmax(logits, dim=-1)[torch.arange(T - 1, device="cuda"), ids[1:]]
+    last_ref = logits[-1].clone()
+    del logits
+    c2 = _cache(m, T + 2)
+    lp, last = m.prompt_logprobs(ids, [T], c2, tgt)
+    assert float((lp[:-1] - ref).abs().max()) <= 1e-3
+    # the last row goes through the GEMV kernels instead of the GEMM: same bf16 values up to one ulp of summation order
+    d = (last[0] - last_ref).abs()
+    assert float((d / last_ref.abs().clamp(min=1e-2)).max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.2

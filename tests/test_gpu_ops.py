@@ -180,6 +180,24 @@ def test_linear_tail_round_split():
     assert bool((e3 <= 4 * r3.abs() * 2.0 ** -7 + 8e-3).all()), float(e3.max())
 
 
+@pytest.mark.parametrize("M", [3, 40, 300, 1030])
+@pytest.mark.parametrize("K,V", [(256, 1000), (512, 4096)])
+def test_lm_head_logprobs(M, K, V):
+    """log_softmax(logits)[m, target[m]] in one pass over the LM head (fused epilogue for M >= 256, logits + row kernel
+    below) against torch's log_softmax of the SAME bf16-rounded logits; ragged vocab tail, ignored rows."""
+    h = _hip()
+    x, w = rnd(M, K, seed=50), rnd(V, K, seed=51, scale=4 / math.sqrt(K))
+    tgt = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(52), dtype=torch.int32)
+    tgt[0] = V - 1
+    tgt[M // 2] = -1  # ignored row: returns -logsumexp
+    got = h.lm_head_logprobs(x.cuda(), w.cuda(), tgt.cuda()).cpu()
+    logits = h.linear(x.cuda(), (w.cuda(),), h.EPI_LOGITS).cpu()
+    lsm = torch.log_softmax(logits, dim=-1)
+    ref = torch.where(tgt >= 0, lsm.gather(1, tgt.clamp(min=0).long()[:, None])[:, 0], -torch.logsumexp(logits, dim=-1))
+    assert float((got - ref).abs().max()) <= 2e-4, float((got - ref).abs().max())
+    assert bf16_ulp_close(logits, F.linear(x, w).float(), ulps=1.0)[0]
+
+
 @pytest.mark.parametrize("M", [1, 4])
 def test_linear_fused_norm(M):
     h = _hip()
