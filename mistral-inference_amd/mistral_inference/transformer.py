@@ -363,12 +363,28 @@ class Transformer(ModelBase):
         [T, vocab] fp32 tensor `forward` contractually returns: (a) fp32 [T]
         log_softmax(logits)[t, targets[t]] (targets[t] < 0: ignored row) from ONE pass over the LM head with the
         log-softmax reduction in the GEMM epilogue, (b) the fp32 logits of each sequence's LAST row, [B, vocab].
-        Single rank, fp32-softmax models only (callers fall back to `forward` otherwise)."""
-        assert self.num_pipeline_ranks == 1 and self.softmax_fp32 and self.output is not None
-        h, _ = self._run(input_ids, seqlens, cache, want_logits=False, images=images)  # final RMSNorm applied
-        lp = _hip.lm_head_logprobs(h, self.output.weight, targets)
-        ends = torch.tensor(seqlens, device=h.device).cumsum(dim=0) - 1
-        last = _hip.linear(h.index_select(0, ends).contiguous(), (self.output.weight,), _hip.EPI_LOGITS)
+        fp32-softmax models only (callers fall back to `forward` otherwise).  Under pipeline parallelism the last
+        rank computes both and broadcasts T + B * vocab floats instead of the reference's [T, vocab] logits."""
+        assert self.softmax_fp32
+        h, _ = self._run(input_ids, seqlens, cache, want_logits=False, images=images)  # final RMSNorm on the last rank
+        T, B, dev = h.shape[0], len(seqlens), h.device
+        last_rank = self.pipeline_rank == self.num_pipeline_ranks - 1
+        targets = targets.to(device=dev, dtype=torch.int32)
+        if self.num_pipeline_ranks > 1:
+            # only rank 0 is guaranteed to hold the real prompt (the reference's other ranks get placeholders of the same
+            # length, main.py:147-160): its target ids travel to the rank that owns the LM head
+            torch.distributed.broadcast(targets, src=0)
+        if last_rank:
+            assert self.output is not None
+            lp = _hip.lm_head_logprobs(h, self.output.weight, targets)
+            ends = torch.tensor(seqlens, device=dev).cumsum(dim=0) - 1
+            last = _hip.linear(h.index_select(0, ends).contiguous(), (self.output.weight,), _hip.EPI_LOGITS)
+        else:
+            lp = torch.empty(T, dtype=torch.float32, device=dev)
+            last = torch.empty((B, self.vocab_size), dtype=torch.float32, device=dev)
+        if self.num_pipeline_ranks > 1:
+            torch.distributed.broadcast(lp, src=self.num_pipeline_ranks - 1)
+            torch.distributed.broadcast(last, src=self.num_pipeline_ranks - 1)
         return lp, last
 
     # ---- weights -------------------------------------------------------------------------------
