@@ -2,8 +2,8 @@
 //
 // mi_forward sequences, for every local layer, the launches that replace TransformerBlock.forward
 // (reference transformer_layers.py:158-169) and, around the stack, Transformer.forward_partial /
-// forward (transformer.py:163-242).  Per decode token and dense layer that is 5 launches:
-//   [RMSNorm + Wq|Wk|Wv GEMV + RoPE + ring write] [split-KV GQA attention] [Wo GEMV + residual]
+// forward (transformer.py:163-242).  Per decode token and dense layer that is 6 launches:
+//   [RMSNorm + Wq|Wk|Wv GEMV + RoPE + ring write] [split-KV GQA attention] [split combine] [Wo GEMV + residual]
 //   [RMSNorm + W1|W3 GEMV + SiLU*mul] [W2 GEMV + residual]
 // with no host synchronisation and no per-step host metadata (positions come from the device-resident
 // kv_seqlens), so a decode step can also be captured in a hipGraph by the caller.
