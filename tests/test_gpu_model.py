@@ -363,3 +363,25 @@ def test_mixtral_8x22b_dims_one_layer_vs_oracle():
         if clear.any():
             assert float((gl[clear] - rl[clear]).abs().max()) <= LOGIT_ATOL
     assert kept >= 0.8 * (T + steps)
+
+
+def test_nemo_12b_dims_one_layer_vs_oracle(tmp_path):
+    """BASELINE.json configs[2] shapes: dim 5120 with 32 heads of 128 (n_heads * head_dim = 4096 != dim), hidden 14336;
+    one layer, small vocabulary: 300-token prefill (the 256-tile GEMMs, whose 5120 output columns leave a partly filled
+    last round) and 3 decode steps against the bf16 oracle."""
+    args = mo.OracleArgs(dim=5120, n_layers=1, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                         vocab_size=1024, rope_theta=1e6)
+    w = mo.synth_weights(args, seed=31)
+    model = _load(tmp_path, args, w, max_batch_size=1)
+    from mistral_inference.cache import BufferCache
+    T, steps = 300, 3
+    ids = torch.randint(0, args.vocab_size, (T + steps,), generator=torch.Generator().manual_seed(32))
+    cache = BufferCache(1, 1, T + steps + 2, 8, 128, None, device="cuda", dtype=BF)
+    cache.reset()
+    got = [model.forward(ids[:T].cuda(), [T], cache).cpu()]
+    got += [model.forward(ids[T + i:T + i + 1].cuda(), [1], cache).cpu() for i in range(steps)]
+    om = mo.OracleModel(args, w)
+    oc = mo.OracleCache(1, 1, T + steps + 2, 8, 128, None, dtype=BF)
+    ref = [om.forward(ids[:T], [T], oc)] + [om.forward(ids[T + i:T + i + 1], [1], oc) for i in range(steps)]
+    for gl, rl in zip(got, ref):
+        assert float((gl - rl).abs().max()) <= LOGIT_ATOL
