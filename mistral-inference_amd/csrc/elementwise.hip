@@ -15,36 +15,37 @@ __global__ __launch_bounds__(256) void embedding_kernel(bf16_t* out, const bf16_
   for (int p = threadIdx.x; p < (D >> 3); p += 256) st16(dst + p * 8, ld16(src + p * 8));
 }
 
-// transformer_layers.py:115-120.  One block per row; the row is kept in registers between the passes.
-constexpr int NORM_MAX_PIECES = 8;  // D <= 256 * 8 * 8 = 16384
-__global__ __launch_bounds__(256) void rmsnorm_kernel(bf16_t* out, const bf16_t* x, const bf16_t* w, int D, float eps) {
-  __shared__ float red[4];
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+// transformer_layers.py:115-120.  One WAVE per row (4 rows per block): the row sits in registers between the two passes,
+// the sum of squares is a wave reduction - no LDS, no barrier - and every lane's NP 16-byte loads are issued
+// unconditionally from clamped addresses before anything waits (a `p < np ? load : 0` form costs a branch and a full
+// vmcnt drain per load, cdna_hip_programming.md ".s-level traps" (c)).
+template <int NP>  // 16-byte pieces per lane: D <= 64 * 8 * NP
+__global__ __launch_bounds__(256) void rmsnorm_kernel(bf16_t* out, const bf16_t* x, const bf16_t* w, int T, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (t >= T) return;
   const bf16_t* xr = x + (size_t)t * D;
   const int np = D >> 3;
-  u32x4 v[NORM_MAX_PIECES];
+  u32x4 v[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) v[j] = ld16(xr + min(lane + j * 64, np - 1) * 8);
   float ss = 0.f;
 #pragma unroll
-  for (int j = 0; j < NORM_MAX_PIECES; ++j) {
-    const int p = tid + j * 256;
-    v[j] = u32x4{0u, 0u, 0u, 0u};
-    if (p < np) {
-      v[j] = ld16(xr + p * 8);
+  for (int j = 0; j < NP; ++j) {
+    float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float a = bf_lo(v[j][i]), b = bf_hi(v[j][i]);
-        ss = fmaf(a, a, ss);
-        ss = fmaf(b, b, ss);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const float a = bf_lo(v[j][i]), b = bf_hi(v[j][i]);
+      s = fmaf(a, a, s);
+      s = fmaf(b, b, s);
     }
+    ss += (lane + j * 64 < np) ? s : 0.f;
   }
   ss = wave_sum(ss);
-  if (lane == 0) red[wid] = ss;
-  __syncthreads();
-  const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+  const float inv = 1.0f / sqrtf(ss / (float)D + eps);
 #pragma unroll
-  for (int j = 0; j < NORM_MAX_PIECES; ++j) {
-    const int p = tid + j * 256;
+  for (int j = 0; j < NP; ++j) {
+    const int p = lane + j * 64;
     if (p < np) {
       const u32x4 wv = ld16(w + p * 8);
       u32x4 o;
@@ -363,8 +364,14 @@ hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, in
   return hipGetLastError();
 }
 hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s) {
-  if (D > 256 * 8 * NORM_MAX_PIECES) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)x, (const bf16_t*)w, D, eps);
+  const dim3 grid((T + 3) / 4), block(256);
+  bf16_t* o = (bf16_t*)out;
+  const bf16_t *xx = (const bf16_t*)x, *ww = (const bf16_t*)w;
+  if (D % 8 || D > 16384) return hipErrorInvalidValue;
+  if (D <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<8>), grid, block, 0, s, o, xx, ww, T, D, eps);
+  else if (D <= 6144) hipLaunchKernelGGL((rmsnorm_kernel<12>), grid, block, 0, s, o, xx, ww, T, D, eps);
+  else if (D <= 8192) hipLaunchKernelGGL((rmsnorm_kernel<16>), grid, block, 0, s, o, xx, ww, T, D, eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<32>), grid, block, 0, s, o, xx, ww, T, D, eps);
   return hipGetLastError();
 }
 hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const float* rope_cs, const int32_t* tok_pos,
