@@ -70,7 +70,8 @@ def generate(
             cols += seq[1:]
             owners.append((b, n))
             offset += len(seq)
-        fused = hasattr(model, "prompt_logprobs") and getattr(model, "softmax_fp32", True) and model.device.type == "cuda"
+        fused = (getattr(model, "supports_prompt_logprobs", False) and getattr(model, "softmax_fp32", True)
+                 and model.device.type == "cuda")
         if fused:
             # the [T, V] logits are never materialised: the LM head GEMM reduces them to the wanted log-probabilities
             tgt = torch.full((flat.numel(),), -1, dtype=torch.int32)

@@ -22,16 +22,25 @@ class MoeLayer(nn.Module):
         self.args = moe_args
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
-        """inputs [T, D] (already ffn-normalised) -> sum_k w_k * expert_k(inputs) in the reference's bf16
-        accumulation order.  Built from the leaf operators: router kernel, then per expert (ascending id,
-        moe.py:29) the fused SwiGLU FFN on the tokens routed to it."""
+        """inputs [T, D] (already ffn-normalised) -> sum over the token's k experts of w * expert(inputs).
+
+        Router = one kernel (bf16 logits, top-k, fp32 softmax over the picks); the (token, slot) pairs are then grouped
+        by expert with one stable sort, each expert that received tokens runs its fused SwiGLU FFN on exactly those rows,
+        and the weighted outputs are added expert by expert in ascending id - the order in which the reference's loop
+        (moe.py:29-31) rounds its bf16 accumulator."""
         k = self.args.num_experts_per_tok
-        idx, w = _hip.moe_router(inputs, self.gate.weight, k)
-        results = torch.zeros_like(inputs)
-        for e, expert in enumerate(self.experts):
-            tok, slot = torch.where(idx == e)
-            if tok.numel() == 0:
-                continue
-            y = expert(inputs[tok].contiguous())
-            results[tok] += w[tok, slot, None].to(inputs.dtype) * y
-        return results
+        idx, w = _hip.moe_router(inputs, self.gate.weight, k)          # [T, k] int32 / fp32 (bf16-valued)
+        flat_e = idx.flatten().long()
+        order = torch.argsort(flat_e, stable=True)                      # pairs grouped by expert, token order kept
+        counts = torch.bincount(flat_e, minlength=len(self.experts)).tolist()
+        tok_of = torch.div(order, k, rounding_mode="floor")
+        gate_w = w.flatten()[order].to(inputs.dtype)
+        out = torch.zeros_like(inputs)
+        start = 0
+        for e, n in enumerate(counts):
+            if n:
+                rows = tok_of[start:start + n]
+                y = self.experts[e](inputs.index_select(0, rows))
+                out.index_add_(0, rows, gate_w[start:start + n, None] * y)  # a token meets an expert at most once
+                start += n
+        return out

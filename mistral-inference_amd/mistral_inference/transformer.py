@@ -148,6 +148,8 @@ class HipStackBackend:
 
 
 class Transformer(ModelBase):
+    supports_prompt_logprobs = True
+
     def __init__(self, args: TransformerArgs, pipeline_rank: int = 0, num_pipeline_ranks: int = 1,
                  softmax_fp32: bool = True, backend: Optional[Any] = None):
         super().__init__()

@@ -385,3 +385,28 @@ def test_nemo_12b_dims_one_layer_vs_oracle(tmp_path):
     ref = [om.forward(ids[:T], [T], oc)] + [om.forward(ids[T + i:T + i + 1], [1], oc) for i in range(steps)]
     for gl, rl in zip(got, ref):
         assert float((gl - rl).abs().max()) <= LOGIT_ATOL
+
+
+def test_module_level_moe_block_vs_oracle(tmp_path):
+    """TransformerBlock.forward with a MoeLayer driven module by module (router kernel + per-expert fused FFN + ordered
+    bf16 accumulation) against the oracle's first layer; tokens whose top-2 pick is a near-tie are excluded."""
+    from mistral_inference.transformer import Transformer
+    case = Case("moe_bf16")
+    folder = write_checkpoint(tmp_path / "c", case.args, case.weights())
+    m = Transformer.from_folder(folder, max_batch_size=4, device="cuda", dtype=BF)
+    ids = torch.tensor(sum(case.prompts, []), device="cuda")
+    lens = [len(p) for p in case.prompts]
+    pos = torch.cat([torch.arange(n) for n in lens]).cuda()
+    with torch.no_grad():
+        out = m.layers["0"](m.tok_embeddings.weight[ids], m.freqs_cis[pos]).float().cpu()
+    om = mo.OracleModel(case.args, case.weights())
+    col = []
+    mo.ROUTER_TRACE = []
+    om.forward_partial(ids.cpu(), lens, None, collect=col)
+    trace, mo.ROUTER_TRACE = mo.ROUTER_TRACE, None
+    srt = torch.sort(trace[0], dim=1, descending=True).values
+    k = case.args.num_experts_per_tok
+    clear = (srt[:, k - 1] - srt[:, k]) > 2 * srt[:, k - 1].abs().clamp(min=1e-3) * 2.0 ** -7
+    assert int(clear.sum()) >= 0.7 * len(ids)
+    ref = col[0].float()
+    assert float((out[clear] - ref[clear]).abs().max()) <= 4e-2 * max(1.0, float(ref.abs().max()))
