@@ -497,6 +497,8 @@ class Transformer(ModelBase):
             self._backend.invalidate()
         if self.vision_language_adapter is not None:
             self.vision_language_adapter.invalidate()
+        if self.vision_encoder is not None:
+            self.vision_encoder._conv_w = None
 
     def _check_foreign_key(self, k: str) -> None:
         """A key this rank does not own must still be a known kind (reference raises on anything else)."""

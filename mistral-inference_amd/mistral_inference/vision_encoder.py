@@ -84,6 +84,7 @@ class VisionTransformer(nn.Module):
         if head_dim not in (64, 128):
             raise NotImplementedError(f"vision head_dim {head_dim}: the attention kernels take 128 (or 64, zero-padded)")
         self._rope_cs: Optional[torch.Tensor] = None
+        self._conv_w: Optional[torch.Tensor] = None  # K-padded image of patch_conv.weight (rebuilt after a reload)
 
     @property
     def max_patches_per_side(self) -> int:
@@ -122,8 +123,14 @@ class VisionTransformer(nn.Module):
             C_, Hh, Ww = img.shape
             x = img.to(dev).unfold(1, P, P).unfold(2, P, P)
             rows.append(x.permute(1, 2, 0, 3, 4).reshape((Hh // P) * (Ww // P), C_ * P * P))
-        patches = torch.cat(rows).contiguous()
-        x = _hip.linear(patches, (self.patch_conv.weight.view(a.hidden_size, -1),), _hip.EPI_STORE)
+        patches = torch.cat(rows)
+        w_flat = self.patch_conv.weight.view(a.hidden_size, -1)
+        kpad = (-patches.shape[1]) % 8  # the GEMM's K granularity (C*P*P = 588 for 14-pixel patches): zero columns
+        if kpad:
+            if self._conv_w is None or self._conv_w.device != dev:
+                self._conv_w = torch.nn.functional.pad(w_flat, (0, kpad)).contiguous()
+            patches, w_flat = torch.nn.functional.pad(patches, (0, kpad)), self._conv_w
+        x = _hip.linear(patches.contiguous(), (w_flat,), _hip.EPI_STORE)
         x = _hip.rmsnorm(x, self.ln_pre.weight, 1e-5)
         T = x.shape[0]
         pos = position_meshgrid(grids)

@@ -88,3 +88,36 @@ def test_gelu_and_softmax_scale_ops():
     ref = (torch.softmax(q @ k.transpose(1, 2) * 64 ** -0.5, -1) @ v).transpose(0, 1)
     assert float((out[:, :, :64].float() - ref).abs().max()) <= 2.5e-2
     assert float(out[:, :, 64:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("merger", [False, True])
+def test_reference_selfconsistency_with_images(merger):
+    """The reference's own two Pixtral tests (tests/test_generate.py:72-171) on the HIP path: generate 7 tokens with
+    images, then re-score prompt + generation in ONE prefill; every logprob must agree (the reference asserts 5e-4 in
+    fp32 on its own kernels; here storage is bf16: 1 ulp at 1.0 is 7.8e-3).  Same tiny shapes as the reference,
+    including 2-pixel patches (C*P*P = 12: the patch GEMM's K is zero-padded to 16)."""
+    import numpy as np
+    from mistral_inference.args import TransformerArgs, VisionEncoderArgs
+    from mistral_inference.generate import generate
+    from mistral_inference.transformer import Transformer
+    torch.manual_seed(42)
+    gen = np.random.default_rng(seed=42)
+    side = 8 if merger else 4
+    seqs = [[1, 2, 2, 2, 2, 4, 5, 6, 7], [12, 13, 14], [2, 2, 2, 2, 7, 8, 9]]
+    images = [[gen.normal(size=(3, side, side))], [], [gen.normal(size=(3, side, side))]]
+    extra = dict(adapter_bias=False, spatial_merge_size=2, add_pre_mm_projector_layer_norm=True,
+                 mm_projector_id="patch_merge") if merger else {}
+    args = TransformerArgs(dim=512, n_layers=1, head_dim=128, hidden_dim=2048, n_heads=4, n_kv_heads=2, norm_eps=1e-5,
+                           vocab_size=32_000, max_batch_size=len(seqs),
+                           vision_encoder=VisionEncoderArgs(hidden_size=128, num_channels=3, image_size=side, patch_size=2,
+                                                            intermediate_size=256, num_hidden_layers=1,
+                                                            num_attention_heads=2, rope_theta=10000, image_token_id=2,
+                                                            **extra))
+    model = Transformer(args).to("cuda", dtype=BF)
+    toks, lp_old = generate(seqs, model, images=images, temperature=0.0, max_tokens=7)
+    enc2 = [e + t for e, t in zip(seqs, toks)]
+    generated, lp_new = generate(enc2, model, images=images, temperature=0.0, max_tokens=0)
+    assert generated == []
+    assert len(seqs) == len(lp_old) == len(lp_new)
+    worst = max(abs(x - y) for a, b in zip(lp_old, lp_new) for x, y in zip(a, b))
+    assert worst < 8e-2, worst
