@@ -111,8 +111,6 @@ int check_model(const mi_model_t* m) {
   if (!m || !m->layers) return fail(MI_ERR_ARG, "null model");
   if (m->head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim %d: kernels are built for 128", m->head_dim);
   if (m->n_heads % m->n_kv_heads) return fail(MI_ERR_SHAPE, "n_heads %% n_kv_heads != 0");
-  const int R = m->n_heads / m->n_kv_heads;
-  if (!(R == 1 || R == 2 || R == 4 || R == 6 || R == 8)) return fail(MI_ERR_SHAPE, "GQA ratio %d unsupported", R);
   if (m->dim % 8 || m->hidden_dim % 8) return fail(MI_ERR_SHAPE, "dim/hidden_dim must be multiples of 8");
   if (m->dim > 16384) return fail(MI_ERR_SHAPE, "dim > 16384");
   if (m->num_experts > 16 || m->top_k > 4 || (m->top_k == 3)) return fail(MI_ERR_SHAPE, "MoE: E <= 16, top_k in {1,2,4}");

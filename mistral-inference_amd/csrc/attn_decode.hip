@@ -84,9 +84,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     for (int i = 0; i < 8; ++i) st.acc[r][i] = 0.f;
   }
 
-  const size_t row_stride = (size_t)a.Hkv * DH;  // elements between consecutive slots
-  const bf16_t* kbase = a.cache_k + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
-  const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kvh * DH + dl * 8;
+  // `kvh` is a SCHEDULED kv head: when a GQA ratio is split into groups, kv_groups consecutive scheduled heads read the
+  // same real head's K/V (the repeat hits the XCD's L2) and own consecutive slices of its query heads.
+  const int kv_real = kvh / a.kv_groups;
+  const size_t row_stride = (size_t)(a.Hkv / a.kv_groups) * DH;  // elements between consecutive slots
+  const bf16_t* kbase = a.cache_k + ((size_t)b * a.W) * row_stride + (size_t)kv_real * DH + dl * 8;
+  const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kv_real * DH + dl * 8;
 
   // Each lane group walks slots s_begin + wid*4 + g + 16*j, UK slots (K and V rows = 2*UK loads) per step, two
   // steps in flight (ping-pong register sets A/B refilled in place, 16 KiB per wave outstanding): the kernel is pure
@@ -246,9 +249,19 @@ size_t attn_decode_partial_floats(int B, int H, int Hkv, int Dh, int W) {
   return (size_t)B * Hkv * attn_decode_splits(W) * R * (Dh + 2);
 }
 
-hipError_t launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
-  if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
-  const int R = a.H / a.Hkv;
+// Largest per-block query-head count in {8, 6, 4, 2, 1} that divides the GQA ratio: 12 (Mistral-Large) -> 2 groups of 6,
+// 16 -> 2 x 8, 3 -> 3 x 1.  Each group is scheduled as a kv head of its own.
+int attn_decode_group(int R) {
+  for (int g : {8, 6, 4, 2}) if (R % g == 0) return g;
+  return 1;
+}
+
+hipError_t launch_attn_decode(const AttnDecodeArgs& a_in, hipStream_t s) {
+  if (a_in.Dh != DH || a_in.H % a_in.Hkv != 0) return hipErrorInvalidValue;
+  AttnDecodeArgs a = a_in;
+  const int R = attn_decode_group(a.H / a.Hkv);
+  a.kv_groups = (a.H / a.Hkv) / R;
+  a.Hkv = a_in.Hkv * a.kv_groups;
   switch (R) {
     case 1: launch_r<1>(a, s); break;
     case 2: launch_r<2>(a, s); break;

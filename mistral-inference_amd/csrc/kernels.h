@@ -96,7 +96,8 @@ struct AttnDecodeArgs {
   int ldq;
   const bf16_t* cache_k;  // [maxB, W, Hkv*Dh]
   const bf16_t* cache_v;
-  int W, B, H, Hkv, Dh;
+  int W, B, H, Hkv, Dh;    // Hkv: kv heads AS SCHEDULED = real kv heads x kv_groups (launch_attn_decode sets both)
+  int kv_groups;           // query-head groups per real kv head (1 unless the GQA ratio is split, see launch_attn_decode)
   const int32_t* tok_pos;  // [B]
   float* partial;          // scratch
   int32_t* tickets;        // reserved: first 4 KiB of the scratch (arrival counters of a removed in-kernel combine)

@@ -225,7 +225,7 @@ def _ring_case(B, W, Hkv, Dh, lens, seed):
     return ck, cv, hist_k, hist_v
 
 
-@pytest.mark.parametrize("H,Hkv", [(4, 2), (32, 8), (8, 8), (12, 2), (16, 2)])
+@pytest.mark.parametrize("H,Hkv", [(4, 2), (32, 8), (8, 8), (12, 2), (16, 2), (24, 2), (6, 2), (10, 2), (32, 2)])
 @pytest.mark.parametrize("W,lens", [(16, [5, 16, 40]), (300, [1, 299, 300]), (4096, [4096, 17, 5000]), (9000, [9000, 5000])])
 def test_attn_decode(H, Hkv, W, lens):
     """lens[b] = tokens seen INCLUDING the new one (already in the ring)."""
