@@ -62,7 +62,7 @@ def _lin_ref(x, ws):
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 9, 64, 200])
-@pytest.mark.parametrize("K,N", [(256, 512), (4096, 1024), (1024, 4096), (14336, 512)])
+@pytest.mark.parametrize("K,N", [(256, 512), (4096, 1024), (1024, 4096), (14336, 512), (28672, 256)])
 def test_linear_store(M, K, N):
     h = _hip()
     x, w = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=1 / math.sqrt(K))
