@@ -71,7 +71,7 @@ def generate(
             owners.append((b, n))
             offset += len(seq)
         fused = (getattr(model, "supports_prompt_logprobs", False) and getattr(model, "softmax_fp32", True)
-                 and model.device.type == "cuda")
+                 and (model.device.type == "cuda" or getattr(model, "prompt_logprobs_any_device", False)))
         if fused:
             # the [T, V] logits are never materialised: the LM head GEMM reduces them to the wanted log-probabilities
             tgt = torch.full((flat.numel(),), -1, dtype=torch.int32)

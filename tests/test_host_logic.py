@@ -94,6 +94,41 @@ def test_generate_host_loop_matches_reference(name):
     assert gen == [] and [len(x) for x in lps0] == [len(p) - 1 for p in case.prompts]
 
 
+@pytest.mark.parametrize("name", ["dense_fp32", "swa_chunk_fp32"])
+def test_generate_fused_prompt_logprob_bookkeeping(name):
+    """generate()'s other prompt route - per-row target ids in, (logprob per row, last-row logits) out - with a CPU
+    stand-in for `prompt_logprobs`: targets, ignored rows, chunk seams and the logprob order must reproduce the
+    reference's outputs exactly like the [T, V] route does."""
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.generate import generate
+    from mistral_inference.transformer import Transformer
+
+    class CpuFused(Transformer):
+        prompt_logprobs_any_device = True
+        calls = 0
+
+        def prompt_logprobs(self, input_ids, seqlens, cache, targets, images=None):
+            CpuFused.calls += 1
+            logits = self.forward(input_ids, seqlens, cache)
+            lsm = torch.log_softmax(logits, dim=-1)
+            t = targets.long()
+            assert t.shape == (input_ids.numel(),) and int((t < 0).sum()) == len(seqlens)  # last row of every sequence
+            lp = lsm.gather(1, t.clamp(min=0)[:, None])[:, 0]
+            ends = torch.tensor(seqlens).cumsum(0) - 1
+            assert bool((t[ends] < 0).all())
+            return lp, logits.index_select(0, ends)
+
+    case = Case(name)
+    a = TransformerArgs.from_dict(case.params)
+    a.max_batch_size = case.max_batch_size
+    m = CpuFused(a, backend=OracleStackBackend())
+    m.load_state_dict(case.weights(), assign=True)
+    toks, lps = generate(case.prompts, m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size)
+    assert CpuFused.calls >= 1 and toks == case.tokens()
+    for x, y in zip(lps, case.logprobs()):
+        assert len(x) == len(y) and max(abs(p - q) for p, q in zip(x, y)) < 2e-5
+
+
 def test_generate_eos_and_sampling():
     from mistral_inference.generate import generate, sample_top_p
     case = Case("dense_fp32")
