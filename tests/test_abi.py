@@ -45,7 +45,7 @@ def test_no_oracle_import_in_product():
 
 
 def test_unsupported_shapes_fail_loudly_before_any_device_work():
-    """mi_forward validates the model description first: wrong head_dim / GQA ratio / MoE width come back as MI_ERR_SHAPE
+    """mi_forward validates the model description first: wrong head_dim / head counts / MoE width come back as MI_ERR_SHAPE
     with a message, never as a silent wrong answer (checked without a GPU: validation precedes every launch)."""
     import ctypes as C
     from mistral_inference import _hip
@@ -56,8 +56,10 @@ def test_unsupported_shapes_fail_loudly_before_any_device_work():
     m.layers = C.cast(layers, C.POINTER(_hip.MiLayer))
     bt = _hip.MiBatch()
     assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"head_dim" in L.mi_last_error_detail()
-    m.head_dim, m.n_heads, m.n_kv_heads = 128, 6, 2   # ratio 3: no kernel
-    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"GQA" in L.mi_last_error_detail()
+    m.head_dim, m.n_heads, m.n_kv_heads = 128, 7, 2   # 7 query heads over 2 kv heads: not a GQA layout
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"n_heads" in L.mi_last_error_detail()
+    m.n_heads = 6                                     # ratio 3 is fine (query heads are grouped 3 x 1)
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -1
     m.n_heads, m.num_experts, m.top_k = 4, 32, 2
     assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"MoE" in L.mi_last_error_detail()
     m.num_experts = m.top_k = 0
