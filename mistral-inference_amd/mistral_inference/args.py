@@ -49,38 +49,41 @@ class LoraArgs(_FromDict):
 
 @dataclass
 class VisionEncoderArgs(_FromDict):
-    hidden_size: int
-    num_channels: int
-    image_size: int
-    patch_size: int
-    intermediate_size: int
+    """`vision_encoder` block of params.json (Pixtral-12B, Mistral-Small-3.1)."""
+    hidden_size: int            # tower width; heads are hidden_size / num_attention_heads wide (64 in shipped models)
+    num_channels: int           # image channels (3)
+    image_size: int             # largest side in pixels -> image_size / patch_size rotary positions per axis
+    patch_size: int             # square patch = stride of the patch convolution (16 or 14)
+    intermediate_size: int      # SwiGLU width of the tower's blocks
     num_hidden_layers: int
     num_attention_heads: int
-    rope_theta: float = 1e4
-    image_token_id: int = 10
-    adapter_bias: bool = True
-    spatial_merge_size: int = 1
-    add_pre_mm_projector_layer_norm: bool = False
-    mm_projector_id: str = ""
+    rope_theta: float = 1e4     # base of the 2-D rotary table
+    image_token_id: int = 10    # placeholder id whose embedding rows are replaced by image features
+    adapter_bias: bool = True   # vision_language_adapter Linear layers carry a bias
+    spatial_merge_size: int = 1             # s: the patch merger folds s x s patches into one token
+    add_pre_mm_projector_layer_norm: bool = False  # RMSNorm between tower and merger/adapter
+    mm_projector_id: str = ""               # "patch_merge" enables the merger
 
 
 @dataclass
 class TransformerArgs(_FromDict):
-    dim: int
-    n_layers: int
+    """Top level of params.json.  The first eight fields are mandatory; the kernels additionally require head_dim == 128,
+    n_heads % n_kv_heads == 0 and dim, hidden_dim multiples of 8 (checked by libmistral_hip before any launch)."""
+    dim: int                    # residual stream width D
+    n_layers: int               # global layer count (a pipeline rank builds only its own contiguous range)
     head_dim: int
-    hidden_dim: int
-    n_heads: int
-    n_kv_heads: int
+    hidden_dim: int             # SwiGLU width F (per expert for MoE)
+    n_heads: int                # query heads H
+    n_kv_heads: int             # key/value heads Hkv (GQA ratio H / Hkv)
     norm_eps: float
     vocab_size: int
 
-    max_batch_size: int = 0
+    max_batch_size: int = 0     # set by from_folder; forward asserts len(seqlens) <= max_batch_size
     rope_theta: Optional[float] = None          # None -> 1e6 (reference transformer.py:115)
-    moe: Optional[MoeArgs] = None
-    lora: Optional[LoraArgs] = None
-    sliding_window: Union[None, int, List[Optional[int]]] = None
-    _sliding_window: Union[None, int, List[Optional[int]]] = None
+    moe: Optional[MoeArgs] = None               # sparse FFN: experts and experts per token
+    lora: Optional[LoraArgs] = None             # un-merged LoRA layers are rejected; load_lora() merges adapters
+    sliding_window: Union[None, int, List[Optional[int]]] = None   # one window, or one per layer (cycled)
+    _sliding_window: Union[None, int, List[Optional[int]]] = None  # legacy spelling of the same key
     model_type: str = "transformer"
     vision_encoder: Optional[VisionEncoderArgs] = None
 
