@@ -12,7 +12,14 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libmistral_hip.so"))
+def _default_lib() -> str:
+    """In-tree build (../lib, what build_native.py writes) first, then a copy shipped inside the package (wheel layout)."""
+    in_tree = os.path.join(os.path.dirname(_HERE), "lib", "libmistral_hip.so")
+    packaged = os.path.join(_HERE, "libmistral_hip.so")
+    return packaged if (not os.path.exists(in_tree) and os.path.exists(packaged)) else in_tree
+
+
+LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", _default_lib())
 
 MI_ABI_VERSION = 2
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
