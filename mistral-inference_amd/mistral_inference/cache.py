@@ -100,9 +100,26 @@ class CacheView:
         _hip.kv_write(self.cache_k, self.cache_v, xk.reshape(T, -1), xv.reshape(T, -1), b.tok_seq, b.tok_pos, b.q_start)
 
     def interleave_kv(self, xk: torch.Tensor, xv: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        raise NotImplementedError(
-            "interleave_kv (reference cache.py:94-117) has no equivalent here: the prefill attention kernel reads "
-            "cached keys from the ring and new keys from the activations directly, nothing is concatenated")
+        """Per sequence: [its cached tokens in position order ++ its new tokens], sequences concatenated (reference
+        cache.py:94-117).  The kernels never need this tensor (the prefill attention reads the ring and the activations
+        in place); it exists for callers that drive the layers themselves.  Pure data movement: one gather per tensor
+        from [ring rows ++ new rows] with an index list assembled on the host."""
+        assert xk.ndim == xv.ndim == 3 and xk.shape == xv.shape  # (sum of new tokens, H, D)
+        new = self.metadata.seqlens
+        seen = [int(s) for s in self.kv_seqlens.tolist()]
+        assert len(new) == len(seen), f"Batch size is {len(seen)}, got {len(new)}"
+        if all(s == 0 for s in seen):
+            return xk, xv  # nothing cached yet
+        B, W = self.cache_k.shape[0], self.cache_k.shape[1]
+        index: List[int] = []
+        row = 0
+        for b, (p, n) in enumerate(zip(seen, new)):
+            index += [b * W + q % W for q in range(p - min(p, W), p)]   # ring slots of the surviving cached positions
+            index += list(range(B * W + row, B * W + row + n))         # then this sequence's new rows
+            row += n
+        idx = torch.tensor(index, dtype=torch.long, device=xk.device)
+        flat = lambda c, x: torch.cat([c.reshape(B * W, *c.shape[2:]), x], dim=0).index_select(0, idx)  # noqa: E731
+        return flat(self.cache_k, xk), flat(self.cache_v, xv)
 
     @property
     def max_seq_len(self) -> int:

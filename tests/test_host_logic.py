@@ -145,3 +145,31 @@ def test_generate_eos_and_sampling():
     torch.manual_seed(1)
     toks, lps = generate(case.prompts, m, max_tokens=3, temperature=0.7)
     assert all(len(t) == 3 for t in toks) and all(x <= 0 for l in lps for x in l)
+
+
+def test_interleave_kv_and_unrotate_semantics():
+    """CacheView.interleave_kv (reference cache.py:94-117): per sequence its cached tokens in position order (ring
+    unrotated, at most W of them) followed by its new tokens; rings that have not wrapped, wrapped exactly, and wrapped
+    twice."""
+    from mistral_inference.cache import CacheInputMetadata, CacheView, unrotate
+    B, W, H, D = 4, 4, 2, 8
+    g = torch.Generator().manual_seed(0)
+    hist = [torch.randn(n, H, D, generator=g) for n in (0, 3, 8, 10)]   # everything each sequence has seen so far
+    ck, cv = torch.zeros(B, W, H, D), torch.zeros(B, W, H, D)
+    for b, hb in enumerate(hist):
+        for p in range(hb.shape[0]):
+            ck[b, p % W] = hb[p]
+            cv[b, p % W] = -hb[p]
+    new = [2, 1, 3, 2]
+    xk = torch.randn(sum(new), H, D, generator=g)
+    md = CacheInputMetadata(positions=None, to_cache_mask=None, cached_elements=None, cache_positions=None, prefill=True,
+                            mask=None, seqlens=new)
+    k, v = CacheView(ck, cv, md, torch.tensor([h.shape[0] for h in hist])).interleave_kv(xk, -xk)
+    want, o = [], 0
+    for hb, n in zip(hist, new):
+        want += [hb[max(0, hb.shape[0] - W):], xk[o:o + n]]
+        o += n
+    assert torch.equal(k, torch.cat(want)) and torch.equal(v, -torch.cat(want))
+    assert torch.equal(unrotate(ck[3], 10), hist[3][6:]) and torch.equal(unrotate(ck[1], 3), hist[1])
+    fresh = CacheView(ck, cv, md, torch.zeros(B, dtype=torch.long))
+    assert fresh.interleave_kv(xk, xk)[0] is xk   # nothing cached: the inputs come back (cache.py:101-103)
