@@ -198,12 +198,16 @@ int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const vo
   return hip_rc(launch_gemm(g, s), "gemm");
 }
 
+namespace {
+constexpr int LOGPROB_ROW_CHUNK = 128;  // rows per pass of the unfused route (bounds its scratch)
+}
+
 size_t mi_lm_head_logprobs_scratch_bytes(int M, int vocab) {
   if (M <= 0 || vocab <= 0) return 0;
   const size_t n_tiles = (size_t)(vocab + 255) / 256;
   const size_t fused = align_up((size_t)M * n_tiles * sizeof(float2)) + align_up((size_t)M * sizeof(float));
-  const size_t rows = (size_t)M * vocab * sizeof(float);  // small-M path: the logits themselves
-  return fused > rows ? fused : (M < 256 ? rows : fused);
+  const size_t rows = (size_t)(M < LOGPROB_ROW_CHUNK ? M : LOGPROB_ROW_CHUNK) * vocab * sizeof(float);
+  return fused > rows ? fused : rows;  // either route may be taken (the fused one needs M >= 256 and K % 64 == 0)
 }
 
 int mi_lm_head_logprobs(float* logprob, const void* x, int ldx, int M, int K, const void* w, int vocab,
@@ -228,12 +232,18 @@ int mi_lm_head_logprobs(float* logprob, const void* x, int ldx, int M, int K, co
     MI_TRY(hip_rc(launch_gemm256(g, s), "lm head logprob gemm"));
     return hip_rc(launch_logprob_finalize(logprob, g.lp_partial, g.lp_tgt, M, n_tiles, s), "logprob finalize");
   }
-  // few rows: fp32 logits into the scratch (GEMV / 128-tile GEMM), then a row-wise log-softmax gather
+  // few rows (or a K the 256-tile kernel does not take): fp32 logits of up to 128 rows at a time into the scratch
+  // (GEMV / 128-tile GEMM), then a row-wise log-softmax gather
   const void* ws[3] = {w, nullptr, nullptr};
   const int nr[3] = {vocab, 0, 0};
-  const int rc = mi_linear(scratch, vocab, x, ldx, M, K, ws, nr, MI_EPI_LOGITS, nullptr, nullptr, 0.f, stream);
-  if (rc) return rc;
-  return hip_rc(launch_logprob_rows(logprob, (const float*)scratch, vocab, target, M, vocab, s), "logprob rows");
+  for (int r0 = 0; r0 < M; r0 += LOGPROB_ROW_CHUNK) {
+    const int rows = (M - r0 < LOGPROB_ROW_CHUNK) ? M - r0 : LOGPROB_ROW_CHUNK;
+    const int rc = mi_linear(scratch, vocab, (const bf16_t*)x + (size_t)r0 * ldx, ldx, rows, K, ws, nr, MI_EPI_LOGITS, nullptr,
+                             nullptr, 0.f, stream);
+    if (rc) return rc;
+    MI_TRY(hip_rc(launch_logprob_rows(logprob + r0, (const float*)scratch, vocab, target + r0, rows, vocab, s), "logprob rows"));
+  }
+  return MI_OK;
 }
 
 size_t mi_attn_decode_scratch_bytes(int B, int n_heads, int n_kv_heads, int head_dim, int W) {
