@@ -268,6 +268,10 @@ class Transformer(ModelBase):
         (num_toks,) = input_ids.shape
         assert sum(seqlens) == num_toks, (sum(seqlens), num_toks)
         meta = cache.batch_metadata(seqlens) if cache is not None else self._nocache_metadata(seqlens)
+        # the kernels index the rotary table by position without a bound check (the reference's gather would raise)
+        top = max((p + s for p, s in zip(cache._seen, seqlens)), default=0) if cache is not None else max(seqlens)
+        if top > ROPE_TABLE_LEN:
+            raise IndexError(f"position {top - 1} is beyond the {ROPE_TABLE_LEN}-entry rotary table (reference transformer.py:116)")
         dev = self.device
         multimodal = self.pipeline_rank == 0 and self.vision_encoder is not None and bool(images)
         if multimodal:  # reference transformer.py:190-191
@@ -319,6 +323,8 @@ class Transformer(ModelBase):
             self._graphed = None
 
     def _graphed_step(self, input_ids: torch.Tensor, seqlens: List[int], cache: BufferCache, st: dict) -> torch.Tensor:
+        if max(cache._seen) + 1 > ROPE_TABLE_LEN:  # same bound as _run (a replayed step never passes through it)
+            raise IndexError(f"position {max(cache._seen)} is beyond the {ROPE_TABLE_LEN}-entry rotary table")
         if st["graph"] is None:
             if st["warm"] < 1:  # eager step: sizes the workspace and the cache's device metadata before capture
                 st["warm"] += 1

@@ -118,6 +118,9 @@ class VisionTransformer(nn.Module):
         dh = a.hidden_size // H
         dev = self.device
         grids = [(img.shape[1] // P, img.shape[2] // P) for img in images]
+        side = self.max_patches_per_side
+        assert all(gh <= side and gw <= side for gh, gw in grids), (
+            f"image larger than image_size={a.image_size}: the 2-D rotary table has {side} positions per axis")
         rows = []
         for img in images:  # im2col in nn.Conv2d's weight order (c, py, px), patches row-major over the grid
             C_, Hh, Ww = img.shape
