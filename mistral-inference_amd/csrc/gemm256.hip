@@ -4,6 +4,9 @@
 // picks this kernel when M >= 256 and K % 64 == 0, and for the token-grouped MoE form (moe.py:28-32, one launch for all
 // experts) when its tile table was built with 256-row m-tiles.
 //
+// Epilogues: store / residual add / SiLU*mul / fp32 logits as in gemm.hip, plus GEMM_LOGPROB (the LM head reduced to
+// log-softmax pieces without storing logits, generate.py:101-118).
+//
 // Why a second tile shape: the 128x128 kernel moves 32 KiB of operands through LDS per 128x128x64 MACs and is bound by
 // LDS bandwidth (DMA writes ~64-85 B/clk + fragment reads 256 B/clk against 16 clk per MFMA): ~37 % of the MFMA peak.
 // 256x256 halves the LDS bytes per flop.  Structure (cdna_hip_programming.md section 5, "256^2 8-phase template",
