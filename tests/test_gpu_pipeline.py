@@ -43,7 +43,7 @@ def test_two_stage_pipeline_on_hip(name, tmp_path):
     case = Case(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
+    port = 29600 + (os.getpid() % 500) + sum(map(ord, name)) % 97  # a fresh port per case (no TIME_WAIT reuse)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, str(tmp_path), q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -43,7 +43,7 @@ def test_two_stage_pipeline_matches_single_process(name):
     case = Case(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 1500) + sum(map(ord, name)) % 97  # a fresh port per case
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
     for p in procs:
         p.start()
