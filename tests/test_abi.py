@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -65,3 +67,26 @@ def test_unsupported_shapes_fail_loudly_before_any_device_work():
     m.num_experts = m.top_k = 0
     assert L.mi_forward(C.byref(m), C.byref(bt), None) == -1     # valid model, empty batch -> MI_ERR_ARG
     assert L.mi_attn_decode(1, 1, 128, 1, 1, 16, 1, 4, 2, 64, 1, 1, None) == -2   # head_dim 64
+
+
+def test_header_is_c99_and_a_c_program_can_drive_the_library(tmp_path):
+    """include/mistral_hip.h must be consumable from plain C (the boundary a cgo / JNI / ctypes shim binds): compile it
+    with gcc -std=c99 -pedantic, then build examples/abi_probe.c and run it against the in-tree library (argument
+    validation only - no device work)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mistral_hip.h"\nint main(void) { return MI_ABI_VERSION == 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                    str(src), "-o", str(tmp_path / "hdr.o")], check=True)
+    exe = tmp_path / "abi_probe"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "abi_probe.c"), "-ldl", "-o", str(exe)], check=True)
+    from mistral_inference import _hip
+    r = subprocess.run([str(exe), _hip.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "head_dim 96" in r.stdout and "workspace" in r.stdout
