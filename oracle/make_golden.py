@@ -54,7 +54,15 @@ CASES = {
     "moe_bf16": (dict(moe=dict(num_experts=8, num_experts_per_tok=2)), "bfloat16",
                  [[1, 5, 9, 200, 17, 3, 44], [7, 300, 2]], 5, None),
     "rope_theta_fp32": (dict(rope_theta=10000.0), "float32", [[4, 3, 2, 1, 0, 9, 8, 7, 6, 5, 4, 3]], 4, None),
+    # oracle-only pins (index flag `oracle_only`: not part of the GPU replay list): head layouts and option
+    # combinations the cases above do not reach
+    "mha_fp32": (dict(n_kv_heads=4), "float32", [[1, 5, 9, 200, 17, 3, 44], [7, 300, 2]], 5, None),
+    "gqa8_swa_fp32": (dict(n_heads=8, n_kv_heads=1, sliding_window=6), "float32",
+                      [[(11 * i + 5) % 512 for i in range(15)], [3, 1, 4, 1, 5, 9, 2, 6]], 9, None),
+    "moe_swa_chunk_fp32": (dict(moe=dict(num_experts=8, num_experts_per_tok=2), sliding_window=8), "float32",
+                           [[(3 * i + 1) % 512 for i in range(13)], [(7 * i + 2) % 512 for i in range(14)]], 5, 4),
 }
+ORACLE_ONLY = {"mha_fp32", "gqa8_swa_fp32", "moe_swa_chunk_fp32"}
 
 
 def build(over, dtype):
@@ -121,6 +129,8 @@ def main() -> None:
             "seed": 42, "max_batch_size": 4,
             "weights_checksum": float(sum(v.double().abs().sum().item() for v in w.values())),
         }
+        if name in ORACLE_ONLY:
+            meta["oracle_only"] = True
         save_file(tensors, os.path.join(OUT, f"{name}.safetensors"))
         index[name] = meta
         print(f"{name}: {len(tensors)} tensors, tokens={toks}")

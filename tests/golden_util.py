@@ -13,6 +13,8 @@ with open(os.path.join(GOLDEN, "index.json")) as f:
     INDEX = json.load(f)
 
 CASES = sorted(INDEX)
+# cases replayed on the GPU; `oracle_only` entries pin the CPU oracle to more reference outputs without being part of it
+GPU_CASES = [c for c in CASES if not INDEX[c].get("oracle_only")]
 
 
 class Case:

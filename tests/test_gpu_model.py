@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import mistral_oracle as mo
-from golden_util import CASES, Case
+from golden_util import GPU_CASES as CASES, Case
 from hip_util import bf16_ulp_close, write_checkpoint
 
 pytestmark = pytest.mark.gpu
