@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
@@ -190,8 +190,21 @@ typedef struct mi_batch {
 } mi_batch_t;
 
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);
-/* The first 4 KiB of the workspace hold split-KV arrival counters: zero them once after allocation. */
+/* The workspace must be ZERO-FILLED once after allocation (the first 4 KiB hold the control words of the persistent
+ * decode engine - step epoch, status - and the engine's hand-off granules carry tags that must never match garbage). */
 int mi_forward(const mi_model_t* model, const mi_batch_t* batch, mi_stream_t stream);
+
+/* Persistent decode engine (csrc/decode_engine.hip).  A DECODE-branch mi_forward with T == B == 1 on a dense model runs
+ * all local layers - TransformerBlock.forward (transformer_layers.py:158-169) x n_layers, the ring write (cache.py:83-92)
+ * and the LM head (transformer.py:235) - as ONE persistent launch when the shapes allow it (dim, hidden_dim and
+ * n_heads*128 multiples of 512, dim <= 8192, at most one attention work item per CU); bit-identical to the launch path.
+ * mi_set_decode_engine(0) forces the launch path (A/B measurements, tests); returns the previous setting.  Initial value:
+ * environment MI_DECODE_ENGINE (default 1). */
+int mi_set_decode_engine(int enabled);
+/* Copies the engine's control words out of a workspace and synchronises `stream` (a health check, NOT part of the hot
+ * path): status[0] = step epoch, status[1] = 0 or the code of the first bounded wait that ever timed out
+ * (0x100 loader / 0x200 ring / 0x300 consumer barrier / 0x400 hand-off sweep), status[2] = abort flag of the last step. */
+int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[4]);
 
 #ifdef __cplusplus
 }

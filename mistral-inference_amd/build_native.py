@@ -12,8 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
-SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "gemm256.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "gemm256.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip",
+           "decode_engine.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
+           os.path.join(CSRC, "attn_decode_core.cuh"),
            os.path.join(HERE, "..", "include", "mistral_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

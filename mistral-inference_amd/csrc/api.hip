@@ -11,6 +11,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/mistral_hip.h"
@@ -42,7 +43,18 @@ inline int hip_rc(hipError_t e, const char* what) {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-constexpr size_t TICKET_BYTES = 4096;
+constexpr size_t TICKET_BYTES = 4096;  // first words: control block of the persistent decode engine (epoch, status, abort)
+
+// 1 (default): batch-1 decode steps of dense models run on the persistent engine (decode_engine.hip) when the shapes
+// allow it; 0: always the launch path.  MI_DECODE_ENGINE sets the initial value, mi_set_decode_engine changes it.
+int g_engine_mode = -1;
+int engine_mode() {
+  if (g_engine_mode < 0) {
+    const char* e = getenv("MI_DECODE_ENGINE");
+    g_engine_mode = e ? (atoi(e) != 0) : 1;
+  }
+  return g_engine_mode;
+}
 
 struct Workspace {
   int32_t* tickets;
@@ -58,6 +70,8 @@ struct Workspace {
   int32_t* tile_tab; // grouped-GEMM m-tile table         [max_tiles][4]
   int32_t* n_tiles;
   bf16_t* moe_y;     // expert outputs, compact rows      [T * top_k, D]
+  void* gran;        // decode-engine granule regions (dense models)
+  size_t gran_bytes;
   int max_tiles;
   size_t total;
 };
@@ -73,6 +87,11 @@ Workspace carve(const mi_model_t* m, int T, int B, int maxW, char* base) {
   const int qkv_cols = (m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
   const int slots = m->top_k > 0 ? m->top_k : 1;
   w.tickets = (int32_t*)take(TICKET_BYTES);
+  // engine granules at a FIXED offset (independent of T): nothing else ever writes them, so a stale word can never
+  // look like a valid {value, tag} granule
+  w.gran_bytes = (m->num_experts == 0 && m->n_kv_heads > 0 && m->n_heads % m->n_kv_heads == 0)
+                     ? decode_engine_granule_bytes(m->dim, m->n_heads, m->n_kv_heads, m->hidden_dim, maxW) : 0;
+  w.gran = take(w.gran_bytes);
   w.xn = (bf16_t*)take((size_t)T * m->dim * 2);
   w.qkv = (bf16_t*)take((size_t)T * qkv_cols * 2);
   w.attn = (bf16_t*)take((size_t)T * m->n_heads * m->head_dim * 2);
@@ -293,6 +312,18 @@ int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T,
   return hip_rc(launch_moe_router(sel_idx, sel_w, x, ldx, T, D, gate, E, top_k, norm_w, eps, (hipStream_t)stream), "moe_router");
 }
 
+int mi_set_decode_engine(int enabled) {
+  const int prev = engine_mode();
+  g_engine_mode = enabled != 0;
+  return prev;
+}
+
+int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[4]) {
+  if (!workspace || !status) return fail(MI_ERR_ARG, "mi_decode_engine_status");
+  MI_TRY(hip_rc(hipMemcpyAsync(status, workspace, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "status copy"));
+  return hip_rc(hipStreamSynchronize((hipStream_t)stream), "status sync");
+}
+
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size) {
   if (!model || T <= 0 || B <= 0) return 0;
   return carve(model, T, B, max_cache_size > 0 ? max_cache_size : 1, nullptr).total;
@@ -325,14 +356,35 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
   // input_ids == NULL: h already holds this stage's input - received from the previous pipeline rank, or the multimodal
   // embeddings of transformer.py:190-191 (text rows from mi_embedding, image rows from the vision tower)
   const bool embed = m->tok_embeddings && bt->input_ids;
+  uint32_t* engine_ctrl = reinterpret_cast<uint32_t*>(ws.tickets);
   if (branch == MI_BRANCH_DECODE && embed) {
     MI_TRY(hip_rc(launch_decode_prep_embedding(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, h,
-                                               m->tok_embeddings, bt->input_ids, D, m->vocab_size, s), "decode_prep+embedding"));
+                                               m->tok_embeddings, bt->input_ids, D, m->vocab_size, engine_ctrl, s),
+                  "decode_prep+embedding"));
   } else {
     if (branch == MI_BRANCH_DECODE)
-      MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, s), "decode_prep"));
+      MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, engine_ctrl, s),
+                    "decode_prep"));
     if (embed)
       MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, s), "embedding"));
+  }
+
+  // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch
+  if (branch == MI_BRANCH_DECODE && T == 1 && B == 1 && m->num_experts == 0 && m->n_layers > 0 && engine_mode()) {
+    EngProblem pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.D = D; pr.H = H; pr.Hkv = Hkv; pr.F = F; pr.V = m->vocab_size; pr.n_layers = m->n_layers; pr.NB = device_cus();
+    pr.eps = m->norm_eps; pr.layers = m->layers; pr.cache_k = bt->cache_k; pr.cache_v = bt->cache_v; pr.W = bt->cache_sizes;
+    pr.h = h; pr.rope_cs = m->rope_cs; pr.tok_pos = bt->tok_pos; pr.tok_seq = bt->tok_seq;
+    pr.final_norm = m->final_norm; pr.output = m->output; pr.logits = bt->logits;
+    pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
+    bool dense_ok = true;
+    for (int l = 0; l < m->n_layers; ++l) dense_ok = dense_ok && m->layers[l].w1 && m->layers[l].w2 && m->layers[l].w3;
+    if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
+      MI_TRY(hip_rc(launch_decode_engine(pr, s), "decode engine"));
+      if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+      return MI_OK;
+    }
   }
 
   for (int l = 0; l < m->n_layers; ++l) {

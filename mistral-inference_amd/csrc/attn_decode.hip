@@ -14,42 +14,18 @@
 // agent-scope release/acquire ticket measured slower than that boundary and was dropped).
 #include <cstdlib>
 
-#include "common.cuh"
+#include "attn_decode_core.cuh"
 #include "kernels.h"
 
 namespace {
 
-constexpr int DH = 128;
-constexpr float LOG2E = 1.4426950408889634f;
-
-template <int R>
-struct State {
-  float m[R], l[R], acc[R][8];
-};
-
-template <int R>
-__device__ __forceinline__ void merge_from(State<R>& s, int off) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float mo = __shfl_xor(s.m[r], off, 64);
-    const float lo = __shfl_xor(s.l[r], off, 64);
-    const float M = fmaxf(s.m[r], mo);
-    const float a1 = exp2f(s.m[r] - M), a2 = exp2f(mo - M);
-    s.l[r] = s.l[r] * a1 + lo * a2;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float ao = __shfl_xor(s.acc[r][i], off, 64);
-      s.acc[r][i] = s.acc[r][i] * a1 + ao * a2;
-    }
-    s.m[r] = M;
-  }
-}
+using namespace attn_core;
 
 template <int R>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
-  __shared__ float sm_m[4][R];
-  __shared__ float sm_l[4][R];
-  __shared__ float sm_acc[4][R][DH];
+  __shared__ float sm_m[4 * R];
+  __shared__ float sm_l[4 * R];
+  __shared__ float sm_acc[4 * R * DH];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar control flow
@@ -59,30 +35,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   const int kvh = blockIdx.x % a.Hkv, split = blockIdx.x / a.Hkv, b = blockIdx.y;
   const int pos = a.tok_pos[b];
   const int kv_len = min(pos + 1, a.W);
-  int chunk = (a.W + a.n_splits - 1) / a.n_splits;
-  chunk = (chunk + 15) & ~15;
+  const int chunk = split_chunk(a.W, a.n_splits);
   const int s_begin = split * chunk;
   const int s_end = min(s_begin + chunk, kv_len);
-  const float sc = rsqrtf((float)DH) * LOG2E;
 
   float qf[R][8];
+  {
+    u32x4 qraw[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const u32x4 v = ld16(a.q + (size_t)b * a.ldq + (size_t)(kvh * R + r) * DH + dl * 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      qf[r][2 * i] = bf_lo(v[i]) * sc;
-      qf[r][2 * i + 1] = bf_hi(v[i]) * sc;
-    }
+    for (int r = 0; r < R; ++r) qraw[r] = ld16(a.q + (size_t)b * a.ldq + (size_t)(kvh * R + r) * DH + dl * 8);
+    load_q<R>(qf, qraw);
   }
   State<R> st;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    st.m[r] = -1e30f;
-    st.l[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st.acc[r][i] = 0.f;
-  }
+  init_state<R>(st);
 
   // `kvh` is a SCHEDULED kv head: when a GQA ratio is split into groups, kv_groups consecutive scheduled heads read the
   // same real head's K/V (the repeat hits the XCD's L2) and own consecutive slices of its query heads.
@@ -113,31 +78,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   auto reduce_step = [&](int it, const u32x4 (&kv)[2 * UK]) {
     const int s0 = s_first + it * 16 * UK;
 #pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      const bool valid = (s0 + 16 * u) < s_end;
-      float kf[8], vf[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kf[2 * i] = bf_lo(kv[u][i]);
-        kf[2 * i + 1] = bf_hi(kv[u][i]);
-        vf[2 * i] = bf_lo(kv[UK + u][i]);
-        vf[2 * i + 1] = bf_hi(kv[UK + u][i]);
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float d = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d = fmaf(qf[r][i], kf[i], d);
-        d = row16_sum(d);
-        const float mn = valid ? fmaxf(st.m[r], d) : st.m[r];
-        const float alpha = exp2f(st.m[r] - mn);
-        const float p = valid ? exp2f(d - mn) : 0.f;
-        st.m[r] = mn;
-        st.l[r] = st.l[r] * alpha + p;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i] * alpha);
-      }
-    }
+    for (int u = 0; u < UK; ++u) reduce_slot<R>(st, qf, kv[u], kv[UK + u], (s0 + 16 * u) < s_end);
   };
   // Two sets in flight.  Steps beyond n_steps reduce nothing (every slot is masked).
   load_step(0, setA);
@@ -149,20 +90,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     load_step(it + 3, setB);
   }
 
-  // 4 lane groups -> wave
-  merge_from<R>(st, 16);
-  merge_from<R>(st, 32);
-  if (g == 0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (dl == 0) {
-        sm_m[wid][r] = st.m[r];
-        sm_l[wid][r] = st.l[r];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sm_acc[wid][r][dl * 8 + i] = st.acc[r][i];
-    }
-  }
+  // 4 lane groups -> wave -> LDS
+  wave_state_to_lds<R>(st, wid, lane, sm_m, sm_l, sm_acc);
   __syncthreads();
 
   // 4 waves -> block partial in global scratch
@@ -170,19 +99,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   float* p_acc = a.partial + ((size_t)bh * a.n_splits + split) * R * DH;
   float* p_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + ((size_t)bh * a.n_splits + split) * R * 2;
   for (int idx = tid; idx < R * DH; idx += 256) {
-    const int r = idx / DH, d = idx % DH;
-    const float M = fmaxf(fmaxf(sm_m[0][r], sm_m[1][r]), fmaxf(sm_m[2][r], sm_m[3][r]));
-    float L = 0.f, A = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float e = exp2f(sm_m[w][r] - M);
-      L += sm_l[w][r] * e;
-      A += sm_acc[w][r][d] * e;
-    }
+    float A, M, L;
+    split_partial<R>(idx, sm_m, sm_l, sm_acc, A, M, L);
     p_acc[idx] = A;
-    if (d == 0) {
-      p_ml[r * 2] = M;
-      p_ml[r * 2 + 1] = L;
+    if (idx % DH == 0) {
+      p_ml[(idx / DH) * 2] = M;
+      p_ml[(idx / DH) * 2 + 1] = L;
     }
   }
 }
@@ -206,17 +128,8 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
     l[sp] = (sp < a.n_splits) ? ml.y : 0.f;
     v[sp] = all_acc[(size_t)s2 * R * DH];
   }
-  float M = -1e30f;
-#pragma unroll
-  for (int sp = 0; sp < NS; ++sp) M = fmaxf(M, m[sp]);
-  float L = 0.f, A = 0.f;
-#pragma unroll
-  for (int sp = 0; sp < NS; ++sp) {
-    const float e = exp2f(m[sp] - M);
-    L += l[sp] * e;
-    A += ((sp < a.n_splits) ? v[sp] : 0.f) * e;
-  }
-  reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)h * DH + d] = f_to_bf(A / L);
+  const float o = combine_splits<NS>(m, l, v, a.n_splits);
+  reinterpret_cast<bf16_t*>(a.out)[(size_t)b * a.H * DH + (size_t)h * DH + d] = f_to_bf(o);
 }
 
 template <int R>

@@ -1,0 +1,775 @@
+// Persistent decode engine: ONE launch runs every local layer of a batch-1 decode step (and the LM head).
+//
+// Replaces, for T = B = 1 on dense models, the 6 dependent launches per layer of the launch path (api.hip) - i.e. the
+// whole of TransformerBlock.forward (transformer_layers.py:158-169) for every layer, CacheView.update (cache.py:83-92),
+// the decode attention (transformer_layers.py:77-89) and the LM head (transformer.py:219,235).  Same arithmetic, same
+// summation orders: the results are BIT-IDENTICAL to the launch path (tests/test_gpu_engine.py).
+//
+// Why: a decode layer is ~436 MB of weights streamed through six all-to-all dependencies; as separate launches each
+// dependency costs a kernel boundary plus the ramp-up / drain of a 256-CU grid (~4.7 us).  Here
+// the HBM stream never stops at a dependency (cdna_hip_programming.md section 5.6, MI355X_MICROARCH.md rows
+// prefetch-credit / engine-vs-launches):
+//
+//   * grid = one workgroup per CU (5 waves): wave 4 is the LOADER, waves 0-3 are CONSUMERS.
+//   * The loader walks a fixed per-CU program - this CU's row slab of Wq|Wk|Wv, its K/V ring slice, its rows of Wo,
+//     W1|W3, W2 for every layer, then of the LM head - and copies it HBM -> LDS with `global_load_lds_dwordx4` (1 KiB
+//     "pieces", non-temporal) into a ring of 8 x 16 KiB "fills".  Weights and old K/V do not depend on activations, so
+//     the loader runs up to a full ring (~5 us of stream) ahead of the consumers across every dependency.
+//   * Consumers take whole rows out of the ring (fp32 FMA chain per lane in the launch path's order, butterfly sum) and
+//     run the epilogues (RMSNorm, RoPE, ring write, SwiGLU, residual).
+//   * Dependencies between CUs are 8-byte {value, tag} granules: ONE write-through (sc1) store publishes 2 bf16 (or 1
+//     fp32) together with its tag; consumers sweep the granule array with sc1 loads until every tag matches
+//     (Guideline 16 R2: the data is the flag - no fences, no barriers, placement-independent).  tag = (step epoch << 12)
+//     | (layer * 8 + edge + 1): unique per step and edge, so buffers are never re-initialised.  The epoch lives in
+//     device memory and is bumped by the step's first kernel (decode_prep), so hipGraph replays see fresh tags.
+//   * Every spin is bounded; on a timeout the block raises ctrl[1] (sticky) / ctrl[2] (per-step broadcast), all waits
+//     fall through and the launch drains.  mi_engine_status() reads the sticky word.
+//
+// Work split per layer (NB = CUs): q/k/v/Wo/W2/LM-head rows in contiguous slabs of row PAIRS per CU; W1|W3 in slabs of
+// unit pairs (rows w1[2j], w3[2j], w1[2j+1], w3[2j+1]); attention by (scheduled kv head, split) exactly as the
+// stand-alone kernel's grid; split merge by slabs of output pairs.
+#include <cstdlib>
+#include <cstring>
+
+#include "attn_decode_core.cuh"
+#include "kernels.h"
+
+namespace {
+
+using namespace attn_core;
+
+constexpr int NCONS = 4;
+constexpr int NTHREADS = (NCONS + 1) * 64;
+constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
+constexpr int FILL = 16;             // pieces per fill
+constexpr int RING_FILLS = 8;        // 128 KiB ring
+constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int CTL_BYTES = 256;
+constexpr int RES_BYTES = 1024;      // this CU's residual rows (bf16), <= 512 rows
+constexpr int XS_OFF = CTL_BYTES + RES_BYTES;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+// Every LDS access goes through an explicit address_space(3) pointer: a generic pointer makes hipcc emit FLAT loads,
+// which count in vmcnt (the loader's DMA bookkeeping) and are waited for with vmcnt(0).
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS char lchar;
+typedef LDS_AS uint32_t lu32;
+typedef LDS_AS volatile uint32_t lvu32;
+typedef LDS_AS float lf32;
+typedef LDS_AS volatile float lvf32;
+typedef LDS_AS u32x4 lu32x4;
+typedef LDS_AS bf16_t lbf16;
+
+// control words at the start of the LDS
+enum : int {
+  C_LANDED = 0,     // fills completely in LDS (loader -> consumers)
+  C_DONE = 1,       // [NCONS] first piece index each consumer wave may still read (consumers -> loader)
+  C_CBAR = 5,       // consumer-wave barrier counter
+  C_GATHERING = 6,  // consumers are sweeping granules: the loader keeps one fill outstanding
+  C_ABORT = 7,
+  C_RED = 8         // [4] fp32 wave totals of the RMSNorm
+};
+
+struct Shared {
+  lvu32* ctl;
+  lbf16* res;   // residual rows of this CU
+  lchar* xs;    // activation vector / attention scratch
+  lchar* ring;
+  uint32_t ring_mask;  // ring pieces - 1
+  gu32* ctrl;          // [0] epoch, [1] sticky status, [2] per-step abort broadcast
+};
+
+__device__ __forceinline__ void raise_abort(const Shared& sh, uint32_t code) {
+  sh.ctl[C_ABORT] = 1;
+  __hip_atomic_store(sh.ctrl + 2, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t expected = 0;
+  __hip_atomic_compare_exchange_strong(sh.ctrl + 1, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One iteration of a bounded spin.  Returns false when the wait must be abandoned.
+__device__ __forceinline__ bool spin_ok(const Shared& sh, uint32_t& spins, uint32_t code) {
+  __builtin_amdgcn_s_sleep(1);
+  if (sh.ctl[C_ABORT]) return false;
+  ++spins;
+  if ((spins & 1023u) == 0) {
+    if (__hip_atomic_load(sh.ctrl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      sh.ctl[C_ABORT] = 1;
+      return false;
+    }
+    if (spins >= SPIN_LIMIT) {
+      raise_abort(sh, code);
+      return false;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ u32x4 lds16(const LDS_AS void* p) { return *reinterpret_cast<const lu32x4*>(p); }
+__device__ __forceinline__ void lds_st16(LDS_AS void* p, u32x4 v) { *reinterpret_cast<lu32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------------ work split
+__device__ __forceinline__ void slab(int units, int c, int nb, int& u0, int& u1) {
+  u0 = (int)((long)units * c / nb);
+  u1 = (int)((long)units * (c + 1) / nb);
+}
+
+struct LayerPlan {  // this CU's share of one layer, in units and pieces
+  int q0, q1, k0, k1, v0, v1;  // row-pair slabs of Wq, Wk, Wv
+  int o0, o1;                  // row-pair slab of Wo and W2 (outputs of dim D)
+  int f0, f1;                  // unit-pair slab of W1|W3
+  int e0, e1;                  // output-pair slab of the split merge
+  int att;                     // 1: this CU owns an attention work item
+  int kvh, split, s_begin, s_end, n_att;  // scheduled kv head, split, slot range, K (= V) pieces
+  int cur_slot;
+};
+
+__device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, int c, int pos, LayerPlan& p) {
+  slab(a.H * DH / 2, c, a.NB, p.q0, p.q1);
+  slab(a.Hkv * DH / 2, c, a.NB, p.k0, p.k1);
+  p.v0 = p.k0;
+  p.v1 = p.k1;
+  slab(a.D / 2, c, a.NB, p.o0, p.o1);
+  slab(a.F / 2, c, a.NB, p.f0, p.f1);
+  slab(a.H * DH / 2, c, a.NB, p.e0, p.e1);
+  const int kv_len = min(pos + 1, L.W);
+  p.cur_slot = pos % L.W;
+  p.att = c < a.Hs * L.n_splits;
+  p.kvh = c % a.Hs;
+  p.split = c / a.Hs;
+  p.s_begin = p.split * L.chunk;
+  p.s_end = min(p.s_begin + L.chunk, kv_len);
+  p.n_att = (p.att && p.s_end > p.s_begin) ? (p.s_end - p.s_begin + 3) >> 2 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ loader wave
+struct Loader {
+  const Shared& sh;
+  int lane, ring_fills;
+  uint32_t g = 0;    // pieces issued
+  uint32_t pub = 0;  // fills published
+
+  __device__ __forceinline__ uint32_t min_done() const {
+    return min(min(sh.ctl[C_DONE + 0], sh.ctl[C_DONE + 1]), min(sh.ctl[C_DONE + 2], sh.ctl[C_DONE + 3]));
+  }
+  __device__ __forceinline__ void publish(uint32_t fills) {
+    if (fills > pub) {
+      pub = fills;
+      sh.ctl[C_LANDED] = fills;
+    }
+  }
+  __device__ __forceinline__ void piece(const void* src_lane) {
+    if ((g & (FILL - 1)) == 0) {
+      const uint32_t f = g / FILL;
+      if (f >= (uint32_t)ring_fills) {  // the slot's previous fill must have been consumed completely
+        const uint32_t need = (f - ring_fills + 1) * FILL;
+        if (min_done() < need) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          publish(f);  // everything issued has landed: consumers must not starve while we wait for them
+          uint32_t spins = 0;
+          while (min_done() < need)
+            if (!spin_ok(sh, spins, 0x100)) break;
+        }
+      }
+    }
+    lchar* dst = sh.ring + (uint32_t)__builtin_amdgcn_readfirstlane((int)(g & sh.ring_mask)) * PIECE;  // wave-uniform (M0)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, 0, 2 /* nt */);
+    ++g;
+    if ((g & (FILL - 1)) == 0) {
+      const uint32_t f = g / FILL;  // fills issued so far
+      if (sh.ctl[C_GATHERING]) {      // thin the stream while this CU's consumers sweep granules (gather-pass row)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        publish(f - 1);
+      } else {
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        if (f >= 2) publish(f - 2);
+      }
+    }
+  }
+  __device__ __forceinline__ void rows(const bf16_t* base, size_t row0, int nrows, int K) {  // contiguous row slab
+    const char* p = reinterpret_cast<const char*>(base + row0 * K) + lane * 16;
+    const int n = nrows * (K >> 9);
+    for (int i = 0; i < n; ++i) piece(p + (size_t)i * PIECE);
+  }
+  __device__ __forceinline__ void flush() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish((g + FILL - 1) / FILL);
+  }
+};
+
+__device__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
+  Loader ld{sh, lane, a.ring_fills};
+  const int PD = a.D >> 9;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const EngLayer& L = a.L[l];
+    LayerPlan p;
+    plan_layer(a, L, c, pos, p);
+    ld.rows(L.wq, 2 * (size_t)p.q0, 2 * (p.q1 - p.q0), a.D);
+    ld.rows(L.wk, 2 * (size_t)p.k0, 2 * (p.k1 - p.k0), a.D);
+    ld.rows(L.wv, 2 * (size_t)p.v0, 2 * (p.v1 - p.v0), a.D);
+    if (p.n_att) {  // K piece j, V piece j: 4 ring slots x 256 B each (slots past the ring end are clamped; masked later)
+      const int kv_real = p.kvh / a.kv_groups;
+      const size_t row_stride = (size_t)a.Hkv * DH;
+      const size_t base = ((size_t)seq * L.W) * row_stride + (size_t)kv_real * DH + (lane & 15) * 8;
+      for (int j = 0; j < p.n_att; ++j) {
+        const int slot = min(p.s_begin + 4 * j + (lane >> 4), L.W - 1);
+        ld.piece(L.ck + base + (size_t)slot * row_stride);
+        ld.piece(L.cv + base + (size_t)slot * row_stride);
+      }
+    }
+    ld.rows(L.wo, 2 * (size_t)p.o0, 2 * (p.o1 - p.o0), a.H * DH);
+    for (int j = p.f0; j < p.f1; ++j) {
+      ld.rows(L.w1, 2 * (size_t)j, 1, a.D);
+      ld.rows(L.w3, 2 * (size_t)j, 1, a.D);
+      ld.rows(L.w1, 2 * (size_t)j + 1, 1, a.D);
+      ld.rows(L.w3, 2 * (size_t)j + 1, 1, a.D);
+    }
+    ld.rows(L.w2, 2 * (size_t)p.o0, 2 * (p.o1 - p.o0), a.F);
+  }
+  if (a.head) {
+    int v0, v1;
+    slab(a.V / 2, c, a.NB, v0, v1);
+    ld.rows(a.output, 2 * (size_t)v0, 2 * (v1 - v0), a.D);
+  }
+  (void)PD;
+  ld.flush();
+}
+
+// ------------------------------------------------------------------------------------------------ consumer waves
+struct Cons {
+  const Shared& sh;
+  int w, lane;
+  uint32_t landed = 0;   // cached copy of ctl->landed
+  uint32_t cbar_target = 0;
+
+  __device__ __forceinline__ void need_fill(uint32_t piece_idx) {  // wait until the fill holding piece_idx has landed
+    const uint32_t need = piece_idx / FILL + 1;
+    if (landed >= need) return;
+    uint32_t spins = 0;
+    for (;;) {
+      landed = sh.ctl[C_LANDED];
+      if (landed >= need) return;
+      if (!spin_ok(sh, spins, 0x200)) return;
+    }
+  }
+  __device__ __forceinline__ void set_done(uint32_t piece_idx) { sh.ctl[C_DONE + w] = piece_idx; }
+
+  // barrier among the NCONS consumer waves (the loader never takes part)
+  __device__ __forceinline__ void cbar() {
+    cbar_target += NCONS;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_CBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t spins = 0;
+    while (sh.ctl[C_CBAR] < cbar_target)
+      if (!spin_ok(sh, spins, 0x300)) break;
+    asm volatile("" ::: "memory");
+  }
+
+  // fp32 dot of one streamed weight row (P pieces starting at piece g0) with the activation vector in LDS: lane owns
+  // elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p, accumulated in ascending p - the launch path's order.
+  __device__ __forceinline__ float row_dot(uint32_t g0, int P, const lbf16* xs) {
+    float acc = 0.f;
+    for (int p0 = 0; p0 < P; p0 += 4) {
+      const int n = min(4, P - p0);
+      need_fill(g0 + p0 + n - 1);
+      u32x4 wv[4], xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int jj = min(j, n - 1);
+        wv[j] = lds16(sh.ring + ((g0 + p0 + jj) & sh.ring_mask) * PIECE + lane * 16);
+        xv[j] = lds16(xs + ((p0 + jj) * 64 + lane) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < n) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc = fmaf(bf_lo(wv[j][i]), bf_lo(xv[j][i]), acc);
+            acc = fmaf(bf_hi(wv[j][i]), bf_hi(xv[j][i]), acc);
+          }
+        }
+      }
+    }
+    return wave_sum(acc);
+  }
+
+  __device__ __forceinline__ void publish(gu64* g, uint32_t tag, uint32_t value) {
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // All consumer waves: copy n granules (granule i lives at addr(i); its tag must match) into LDS words dst[0, n).
+  template <class AddrFn>
+  __device__ __forceinline__ void gather_fn(int n, uint32_t tag, lu32* dst, AddrFn addr) {
+    constexpr int NL = 8;
+    for (int k0 = 0; k0 * NCONS * 64 < n; k0 += NL) {
+      unsigned long long x[NL];
+      uint32_t spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int i = ((k0 + k) * NCONS + w) * 64 + lane;
+          x[k] = __hip_atomic_load(addr(min(i, n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int i = ((k0 + k) * NCONS + w) * 64 + lane;
+          ok &= (i >= n) || ((uint32_t)(x[k] >> 32) == tag);
+        }
+        if (__all(ok)) break;
+        if (!spin_ok(sh, spins, 0x400)) break;
+      }
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int i = ((k0 + k) * NCONS + w) * 64 + lane;
+        if (i < n) dst[i] = (uint32_t)x[k];
+      }
+    }
+  }
+  __device__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
+    gather_fn(n, tag, dst, [&](int i) { return src + i; });
+  }
+
+  // RMSNorm of the K-element bf16 vector in LDS, in place (transformer_layers.py:115-120), with the launch path's
+  // reduction tree: 256 "threads" own 16-byte pieces vt + i * 256, per-piece sums, wave butterfly, 4 wave totals.
+  __device__ void rmsnorm_inplace(lbf16* xs, int K, const bf16_t* norm_w, float eps) {
+    const int vt = w * 64 + lane, npieces = K >> 3;
+    u32x4 xr[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = vt + i * 256;
+      if (q < npieces) {
+        xr[i] = lds16(xs + q * 8);
+        float s = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float x0 = bf_lo(xr[i][cc]), x1 = bf_hi(xr[i][cc]);
+          s = fmaf(x0, x0, s);
+          s = fmaf(x1, x1, s);
+        }
+        ss += s;
+      }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) reinterpret_cast<lvf32*>(sh.ctl + C_RED)[w] = ss;
+    cbar();
+    lvf32* red = reinterpret_cast<lvf32*>(sh.ctl + C_RED);
+    const float s = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / sqrtf(s / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = vt + i * 256;
+      if (q < npieces) {
+        const u32x4 wv = ld16(norm_w + (size_t)q * 8);
+        u32x4 o;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          o[cc] = pack_bf2(bf_round(bf_lo(xr[i][cc]) * inv) * bf_lo(wv[cc]), bf_round(bf_hi(xr[i][cc]) * inv) * bf_hi(wv[cc]));
+        lds_st16(xs + q * 8, o);
+      }
+    }
+    cbar();
+  }
+};
+
+template <int R>
+__device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch) {
+  Cons cs{sh, w, lane};
+  lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
+  lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
+  gu64* G = (gu64*)a.gran;
+  const int PD = a.D >> 9, PA = (a.H * DH) >> 9, PF = a.F >> 9;
+  const int nq = a.H * DH, nkv = a.Hkv * DH;
+  uint32_t g = 0;  // first piece of the current segment
+  auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
+
+  // attention scratch inside the activation region (free between the q|k|v rows and the Wo gather)
+  lu32* q_lds = xs32;                                            // R * 64 words
+  lu32* kn_lds = xs32 + R * 64;                                  // 64 words
+  lu32* vn_lds = kn_lds + 64;                                    // 64 words
+  lf32* sm_m = reinterpret_cast<lf32*>(vn_lds + 64);             // 4 R
+  lf32* sm_l = sm_m + 4 * R;                                     // 4 R
+  lf32* sm_acc = sm_l + 4 * R;                                   // 4 R DH
+  lu32* cmb_lds = reinterpret_cast<lu32*>(sm_acc + 4 * R * DH);  // split merge staging: 3 * n_splits * ne words
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const EngLayer& L = a.L[l];
+    LayerPlan p;
+    plan_layer(a, L, c, pos, p);
+
+    // ================================================================ attention_norm + q|k|v + RoPE + ring write
+    if (l == 0 && a.first) {  // the step's input comes from global memory (embedding / previous stage / previous launch)
+      const int vt = w * 64 + lane;
+      for (int q = vt; q < (a.D >> 3); q += NCONS * 64) lds_st16(xs + q * 8, ld16(a.h + (size_t)q * 8));
+      for (int r = 2 * p.o0 + vt; r < 2 * p.o1; r += NCONS * 64) sh.res[r - 2 * p.o0] = a.h[r];
+      cs.cbar();
+    } else {
+      sh.ctl[C_GATHERING] = 1;
+      cs.gather(G + a.g_h, a.D / 2, tag_of(l - 1, 0), xs32);
+      cs.cbar();
+      sh.ctl[C_GATHERING] = 0;
+    }
+    cs.rmsnorm_inplace(xs, a.D, L.an, a.eps);
+    {
+      const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0, n_u = nq_u + 2 * nk_u;
+      for (int k = w; k < n_u; k += NCONS) {
+        const uint32_t ga = g + (uint32_t)(2 * k) * PD;
+        cs.set_done(ga);
+        const float v0 = cs.row_dot(ga, PD, xs), v1 = cs.row_dot(ga + PD, PD, xs);
+        if (lane == 0) {
+          float y0 = bf_round(v0), y1 = bf_round(v1);
+          int kind, u;  // 0 q, 1 k, 2 v; u = global row pair inside that matrix
+          if (k < nq_u) { kind = 0; u = p.q0 + k; }
+          else if (k < nq_u + nk_u) { kind = 1; u = p.k0 + (k - nq_u); }
+          else { kind = 2; u = p.v0 + (k - nq_u - nk_u); }
+          const int r0 = 2 * u;
+          if (kind < 2) {  // rope.py:13-23 on the adjacent pair
+            const int i = (r0 % DH) >> 1;
+            const float2 cs2 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + i) * 2);
+            const float re = __fsub_rn(__fmul_rn(y0, cs2.x), __fmul_rn(y1, cs2.y));
+            const float im = __fadd_rn(__fmul_rn(y0, cs2.y), __fmul_rn(y1, cs2.x));
+            y0 = re;
+            y1 = im;
+          }
+          const uint32_t packed = pack_bf2(y0, y1);
+          if (kind > 0) {  // cache.py:83-92
+            const size_t slot = (size_t)seq * L.W + p.cur_slot;
+            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + r0;
+            *reinterpret_cast<uint32_t*>(ring) = packed;
+          }
+          const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
+          cs.publish(G + a.g_qkv + gi, tag_of(l, 1), packed);
+        }
+      }
+      g += (uint32_t)(2 * n_u) * PD;
+      cs.set_done(g);
+    }
+
+    // ================================================================ attention: this CU's (kv head, split)
+    cs.cbar();  // every wave is done with the normalised activations: the region becomes attention scratch
+    if (p.att) {
+      const int kv_real = p.kvh / a.kv_groups;
+      const uint32_t tq = tag_of(l, 1);
+      sh.ctl[C_GATHERING] = 1;
+      cs.gather(G + a.g_qkv + (size_t)p.kvh * R * 64, R * 64, tq, q_lds);
+      cs.gather(G + a.g_qkv + nq / 2 + (size_t)kv_real * 64, 64, tq, kn_lds);
+      cs.gather(G + a.g_qkv + nq / 2 + nkv / 2 + (size_t)kv_real * 64, 64, tq, vn_lds);
+      cs.cbar();
+      sh.ctl[C_GATHERING] = 0;
+      const int gl = lane >> 4, dl = lane & 15;
+      float qf[R][8];
+      {
+        u32x4 qraw[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) qraw[r] = lds16(q_lds + r * 64 + dl * 4);
+        load_q<R>(qf, qraw);
+      }
+      State<R> st;
+      init_state<R>(st);
+      for (int j = w; j < p.n_att; j += NCONS) {  // virtual wave w of the stand-alone kernel
+        const uint32_t gk = g + 2 * j;
+        cs.set_done(gk);
+        cs.need_fill(gk + 1);
+        u32x4 kraw = lds16(sh.ring + (gk & sh.ring_mask) * PIECE + lane * 16);
+        u32x4 vraw = lds16(sh.ring + ((gk + 1) & sh.ring_mask) * PIECE + lane * 16);
+        const int slot = p.s_begin + 4 * j + gl;
+        if (slot == p.cur_slot) {  // this step's K/V row: taken from the granules, its ring write may still be in flight
+          kraw = lds16(kn_lds + dl * 4);
+          vraw = lds16(vn_lds + dl * 4);
+        }
+        const bool valid = slot < p.s_end;
+        if (!valid) {  // never-written ring slots may hold NaN bit patterns (torch.empty): 0 * NaN would poison the sums
+          kraw = u32x4{0u, 0u, 0u, 0u};
+          vraw = u32x4{0u, 0u, 0u, 0u};
+        }
+        reduce_slot<R>(st, qf, kraw, vraw, valid);
+      }
+      g += 2 * p.n_att;
+      cs.set_done(g);
+      wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
+      cs.cbar();
+      const uint32_t tp = tag_of(l, 2);
+      const size_t bh = p.kvh;  // batch 1
+      gu64* p_acc = G + a.g_part + (bh * L.n_splits + p.split) * R * DH;
+      gu64* p_ml = G + a.g_part + (size_t)a.Hs * L.n_splits * R * DH + (bh * L.n_splits + p.split) * R * 2;
+      for (int idx = w * 64 + lane; idx < R * DH; idx += NCONS * 64) {
+        float A, M, Lsum;
+        split_partial<R>(idx, sm_m, sm_l, sm_acc, A, M, Lsum);
+        cs.publish(p_acc + idx, tp, __float_as_uint(A));
+        if (idx % DH == 0) {
+          cs.publish(p_ml + (idx / DH) * 2, tp, __float_as_uint(M));
+          cs.publish(p_ml + (idx / DH) * 2 + 1, tp, __float_as_uint(Lsum));
+        }
+      }
+    }
+
+    // ================================================================ split merge: this CU's slab of output pairs
+    {
+      const int ne = 2 * (p.e1 - p.e0), ns = L.n_splits;  // output elements of this CU (<= 64), splits
+      if (ne > 0) {
+        const uint32_t tp = tag_of(l, 2);
+        // word t = (which * ns + sp) * ne + el: which = 0 acc, 1 m, 2 l of split sp for element 2 * e0 + el
+        const gu64* part = G + a.g_part;
+        const size_t ml_base = (size_t)a.Hs * ns * R * DH;
+        sh.ctl[C_GATHERING] = 1;
+        cs.gather_fn(3 * ns * ne, tp, cmb_lds, [&](int t) {
+          const int el = t % ne, sp = (t / ne) % ns, which = t / (ne * ns);
+          const int e = 2 * p.e0 + el, hh = e / DH, d = e % DH, kvh = hh / R, r = hh % R;
+          const size_t blk = (size_t)kvh * ns + sp;
+          return which == 0 ? part + blk * R * DH + (size_t)r * DH + d : part + ml_base + blk * R * 2 + r * 2 + (which - 1);
+        });
+        cs.cbar();
+        sh.ctl[C_GATHERING] = 0;
+        if (w == 0) {
+          const int el = min(lane, ne - 1);
+          const lf32* ca = reinterpret_cast<const lf32*>(cmb_lds) + el;
+          const lf32* cm = ca + ns * ne;
+          const lf32* cl = cm + ns * ne;
+          const float o = combine_stream(ns, [&](int sp) { return cm[sp * ne]; }, [&](int sp) { return cl[sp * ne]; },
+                                         [&](int sp) { return ca[sp * ne]; });
+          const float o_hi = __shfl_down(o, 1, 64);
+          if (lane < ne && !(lane & 1)) cs.publish(G + a.g_att + p.e0 + lane / 2, tag_of(l, 3), pack_bf2(o, o_hi));
+        }
+      }
+    }
+
+    // ================================================================ h1 = h + attn @ Wo^T
+    cs.cbar();  // the attention scratch is dead
+    sh.ctl[C_GATHERING] = 1;
+    cs.gather(G + a.g_att, nq / 2, tag_of(l, 3), xs32);
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 0;
+    {
+      const int n_u = p.o1 - p.o0;
+      for (int k = w; k < n_u; k += NCONS) {
+        const uint32_t ga = g + (uint32_t)(2 * k) * PA;
+        cs.set_done(ga);
+        const float v0 = cs.row_dot(ga, PA, xs), v1 = cs.row_dot(ga + PA, PA, xs);
+        if (lane == 0) {
+          const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
+          const uint32_t packed = pack_bf2(bf_lo(rs) + bf_round(v0), bf_hi(rs) + bf_round(v1));
+          *reinterpret_cast<lu32*>(sh.res + 2 * k) = packed;  // residual of the W2 epilogue
+          cs.publish(G + a.g_h1 + p.o0 + k, tag_of(l, 4), packed);
+        }
+      }
+      g += (uint32_t)(2 * n_u) * PA;
+      cs.set_done(g);
+    }
+
+    // ================================================================ hid = silu(W1 x) * (W3 x), x = ffn_norm(h1)
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 1;
+    cs.gather(G + a.g_h1, a.D / 2, tag_of(l, 4), xs32);
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 0;
+    cs.rmsnorm_inplace(xs, a.D, L.fn, a.eps);
+    {
+      const int n_u = p.f1 - p.f0;
+      for (int k = w; k < n_u; k += NCONS) {
+        const uint32_t ga = g + (uint32_t)(4 * k) * PD;
+        cs.set_done(ga);
+        const float a0 = cs.row_dot(ga, PD, xs), b0 = cs.row_dot(ga + PD, PD, xs);
+        const float a1 = cs.row_dot(ga + 2 * PD, PD, xs), b1 = cs.row_dot(ga + 3 * PD, PD, xs);
+        if (lane == 0) {
+          const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(a0, b0)) | ((uint32_t)f_to_bf(swiglu_bf(a1, b1)) << 16);
+          cs.publish(G + a.g_hid + p.f0 + k, tag_of(l, 5), packed);
+        }
+      }
+      g += (uint32_t)(4 * n_u) * PD;
+      cs.set_done(g);
+    }
+
+    // ================================================================ h = h1 + hid @ W2^T
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 1;
+    cs.gather(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 0;
+    {
+      const int n_u = p.o1 - p.o0;
+      const bool to_global = (l == a.n_layers - 1);
+      for (int k = w; k < n_u; k += NCONS) {
+        const uint32_t ga = g + (uint32_t)(2 * k) * PF;
+        cs.set_done(ga);
+        const float v0 = cs.row_dot(ga, PF, xs), v1 = cs.row_dot(ga + PF, PF, xs);
+        if (lane == 0) {
+          const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
+          const uint32_t packed = pack_bf2(bf_lo(rs) + bf_round(v0), bf_hi(rs) + bf_round(v1));
+          *reinterpret_cast<lu32*>(sh.res + 2 * k) = packed;  // residual of the next layer's Wo epilogue
+          cs.publish(G + a.g_h + p.o0 + k, tag_of(l, 0), packed);
+          if (to_global) *reinterpret_cast<uint32_t*>(a.h + 2 * (size_t)(p.o0 + k)) = packed;
+        }
+      }
+      g += (uint32_t)(2 * n_u) * PF;
+      cs.set_done(g);
+    }
+    cs.cbar();
+  }
+
+  // ================================================================ final norm + LM head (transformer.py:219,235,242)
+  if (a.head) {
+    sh.ctl[C_GATHERING] = 1;
+    cs.gather(G + a.g_h, a.D / 2, tag_of(a.n_layers - 1, 0), xs32);
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 0;
+    cs.rmsnorm_inplace(xs, a.D, a.final_norm, a.eps);
+    int v0, v1;
+    slab(a.V / 2, c, a.NB, v0, v1);
+    for (int k = w; k < v1 - v0; k += NCONS) {
+      const uint32_t ga = g + (uint32_t)(2 * k) * PD;
+      cs.set_done(ga);
+      const float y0 = cs.row_dot(ga, PD, xs), y1 = cs.row_dot(ga + PD, PD, xs);
+      if (lane == 0) {
+        float2 o = make_float2(bf_round(y0), bf_round(y1));
+        *reinterpret_cast<float2*>(a.logits + 2 * (size_t)(v0 + k)) = o;
+      }
+    }
+    g += (uint32_t)(2 * (v1 - v0)) * PD;
+  }
+  cs.set_done(0xffffffffu);
+}
+
+template <int R>
+__global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Shared sh;
+  lchar* lds = (lchar*)smem;
+  sh.ctl = reinterpret_cast<lvu32*>(lds);
+  sh.res = reinterpret_cast<lbf16*>(lds + CTL_BYTES);
+  sh.xs = lds + XS_OFF;
+  sh.ring = lds + (LDS_TOTAL - a.ring_fills * FILL * PIECE);
+  sh.ring_mask = a.ring_fills * FILL - 1;
+  sh.ctrl = (gu32*)a.ctrl;
+  if (threadIdx.x < CTL_BYTES / 4) sh.ctl[threadIdx.x] = 0;
+  __syncthreads();  // the only workgroup barrier: roles split below
+
+  const int pos = a.tok_pos[0];
+  const int seq = a.tok_seq ? a.tok_seq[0] : 0;
+  const uint32_t epoch = __hip_atomic_load(sh.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffffu;
+  if (w == NCONS) run_loader(a, sh, c, lane, pos, seq);
+  else run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace {
+struct GranLayout {
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, total;
+};
+GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
+  using attn_core::DH;
+  const int Rtot = H / Hkv, R = attn_decode_group(Rtot), Hs = Hkv * (Rtot / R);
+  GranLayout g;
+  uint32_t off = 0;
+  g.g_h = off;    off += D / 2;
+  g.g_qkv = off;  off += (H + 2 * Hkv) * DH / 2;
+  g.g_att = off;  off += H * DH / 2;
+  g.g_h1 = off;   off += D / 2;
+  g.g_hid = off;  off += F / 2;
+  g.g_part = off; off += (uint32_t)((size_t)Hs * max_splits * R * (DH + 2));
+  g.total = off;
+  return g;
+}
+}  // namespace
+
+size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW) {
+  if (Hkv <= 0 || H % Hkv) return 0;
+  (void)maxW;  // sized for the maximum of 32 splits so that the layout depends on the model only
+  return (size_t)gran_layout(D, H, Hkv, F, 32).total * 8;
+}
+
+bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
+  auto no = [&](const char* m) {
+    if (why) snprintf(why, why_len, "%s", m);
+    return false;
+  };
+  using attn_core::DH;
+  if (pr.D % 512 || pr.F % 512 || (pr.H * DH) % 512) return no("dim / hidden_dim / n_heads*128 not a multiple of 512");
+  if (pr.D > 8192) return no("dim > 8192 (fused RMSNorm holds 4 pieces per thread)");
+  if (pr.V % 2) return no("odd vocab");
+  const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
+  const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch
+  if ((size_t)kmax * 2 > region) return no("activation vector does not fit beside the 8-fill ring");
+  // a consumer wave holds its ring position while it reads one unit: the unit must fit the ring minus one fill
+  if (2 * (kmax >> 9) > RING_FILLS * FILL - FILL || 4 * (pr.D >> 9) > RING_FILLS * FILL - FILL) return no("unit longer than the ring");
+  const int NB = pr.NB;
+  if (NB < 8 || NB > 1024) return no("CU count");
+  if (((pr.D / 2 + NB - 1) / NB) * 2 * 2 > RES_BYTES) return no("residual slab");
+  if (pr.Hkv <= 0 || pr.H % pr.Hkv) return no("heads");
+  const int Rtot = pr.H / pr.Hkv;
+  const int R = attn_decode_group(Rtot);
+  if (R != 1 && R != 2 && R != 4 && R != 8) return no("GQA group size");
+  const int Hs = pr.Hkv * (Rtot / R);
+  const int ne_max = ((pr.H * DH / 2 + NB - 1) / NB) * 2;
+  if (ne_max > 64) return no("split-merge slab");
+  if ((size_t)R * (256 + 2 * DH * 16 + 32) + 512 + (size_t)3 * 32 * ne_max * 4 > region) return no("attention scratch");
+  for (int l = 0; l < pr.n_layers; ++l) {
+    const int ns = attn_decode_splits(pr.W[l]);
+    if (ns > 32 || Hs * ns > NB) return no("more attention work items than CUs");
+  }
+  return true;
+}
+
+hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
+  EngArgs a;
+  memset(&a, 0, sizeof(a));
+  a.D = pr.D; a.H = pr.H; a.Hkv = pr.Hkv; a.F = pr.F; a.V = pr.V; a.eps = pr.eps; a.NB = pr.NB;
+  const int Rtot = pr.H / pr.Hkv;
+  a.R = attn_decode_group(Rtot);
+  a.kv_groups = Rtot / a.R;
+  a.Hs = pr.Hkv * a.kv_groups;
+  a.ring_fills = RING_FILLS;
+  a.h = (bf16_t*)pr.h; a.rope_cs = pr.rope_cs; a.tok_pos = pr.tok_pos; a.tok_seq = pr.tok_seq;
+  a.final_norm = (const bf16_t*)pr.final_norm; a.output = (const bf16_t*)pr.output; a.logits = pr.logits;
+  a.gran = (uint64_t*)pr.granules; a.ctrl = pr.ctrl;
+  const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
+  a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
+  if ((size_t)gl.total * 8 > pr.granule_bytes) return hipErrorInvalidValue;
+
+  for (int l0 = 0; l0 < pr.n_layers; l0 += ENG_MAXL) {
+    const int nl = pr.n_layers - l0 < ENG_MAXL ? pr.n_layers - l0 : ENG_MAXL;
+    a.n_layers = nl;
+    a.seq_base = l0;
+    a.first = 1;  // every launch starts from the residual stream in global memory
+    a.head = (l0 + nl == pr.n_layers) && pr.logits != nullptr;
+    for (int l = 0; l < nl; ++l) {
+      const mi_layer_t& M = pr.layers[l0 + l];
+      EngLayer& L = a.L[l];
+      L.an = (const bf16_t*)M.attention_norm; L.wq = (const bf16_t*)M.wq; L.wk = (const bf16_t*)M.wk;
+      L.wv = (const bf16_t*)M.wv; L.wo = (const bf16_t*)M.wo; L.fn = (const bf16_t*)M.ffn_norm;
+      L.w1 = (const bf16_t*)M.w1; L.w2 = (const bf16_t*)M.w2; L.w3 = (const bf16_t*)M.w3;
+      L.ck = (bf16_t*)pr.cache_k[l0 + l]; L.cv = (bf16_t*)pr.cache_v[l0 + l];
+      L.W = pr.W[l0 + l];
+      L.n_splits = attn_decode_splits(L.W);
+      L.chunk = attn_core::split_chunk(L.W, L.n_splits);
+    }
+    const void* fn = nullptr;
+    switch (a.R) {
+      case 1: fn = (const void*)decode_engine_kernel<1>; break;
+      case 2: fn = (const void*)decode_engine_kernel<2>; break;
+      case 4: fn = (const void*)decode_engine_kernel<4>; break;
+      case 8: fn = (const void*)decode_engine_kernel<8>; break;
+      default: return hipErrorInvalidValue;
+    }
+    // 160 KiB of dynamic LDS is an opt-in per function AND per device
+    static bool attr_set[64][9] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev][a.R]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_set[dev][a.R] = true;
+    }
+    void* params[] = {(void*)&a};
+    hipError_t e = hipLaunchKernel(fn, dim3(pr.NB), dim3(NTHREADS), params, LDS_TOTAL, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}

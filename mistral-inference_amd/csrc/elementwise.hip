@@ -104,8 +104,12 @@ __global__ __launch_bounds__(256) void kv_write_kernel(bf16_t* ck, bf16_t* cv, i
 // Decode step metadata from the device-resident kv_seqlens (no host round trip), then
 // kv_seqlens += 1 (cache.py:193-195 update_seqlens for seqlens = [1]*B).
 __global__ void decode_prep_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
-                                   int32_t* tok_pos, int B) {
+                                   int32_t* tok_pos, int B, uint32_t* engine_ctrl) {
   const int b = threadIdx.x;
+  if (b == 0 && engine_ctrl) {
+    engine_ctrl[0] += 1;
+    engine_ctrl[2] = 0;
+  }
   if (b < B) {
     const int p = (int)kv_seqlens[b];
     kv_before[b] = p;
@@ -121,9 +125,14 @@ __global__ void decode_prep_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_
 // T == B at decode).  Saves a launch per token; the metadata words are consumed only by later launches.
 __global__ __launch_bounds__(256) void decode_prep_embedding_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before,
                                                                     int32_t* tok_seq, int32_t* tok_pos, int B, bf16_t* out,
-                                                                    const bf16_t* table, const int64_t* ids, int D, int vocab) {
+                                                                    const bf16_t* table, const int64_t* ids, int D, int vocab,
+                                                                    uint32_t* engine_ctrl) {
   const int t = blockIdx.x;
   if (threadIdx.x == 0) {
+    if (t == 0 && engine_ctrl) {
+      engine_ctrl[0] += 1;
+      engine_ctrl[2] = 0;
+    }
     const int p = (int)kv_seqlens[t];
     kv_before[t] = p;
     tok_pos[t] = p;
@@ -390,17 +399,17 @@ hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void*
   return hipGetLastError();
 }
 hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
-                              int32_t* tok_pos, int B, hipStream_t s) {
+                              int32_t* tok_pos, int B, uint32_t* engine_ctrl, hipStream_t s) {
   if (B > 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(decode_prep_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, s, kv_seqlens, q_start, kv_before,
-                     tok_seq, tok_pos, B);
+                     tok_seq, tok_pos, B, engine_ctrl);
   return hipGetLastError();
 }
 hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
                                         int32_t* tok_pos, int B, void* out, const void* table, const int64_t* ids, int D,
-                                        int vocab, hipStream_t s) {
+                                        int vocab, uint32_t* engine_ctrl, hipStream_t s) {
   hipLaunchKernelGGL(decode_prep_embedding_kernel, dim3(B), dim3(256), 0, s, kv_seqlens, q_start, kv_before, tok_seq, tok_pos, B,
-                     (bf16_t*)out, (const bf16_t*)table, ids, D, vocab);
+                     (bf16_t*)out, (const bf16_t*)table, ids, D, vocab, engine_ctrl);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s) {

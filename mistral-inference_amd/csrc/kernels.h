@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/mistral_hip.h"
+
 typedef uint16_t bf16_t;
 
 // ---------------------------------------------------------------------------------------------- GEMV
@@ -104,6 +106,7 @@ struct AttnDecodeArgs {
   int n_splits;
 };
 int attn_decode_splits(int W);
+int attn_decode_group(int R);  // query heads served per block: the largest of {8, 6, 4, 2, 1} dividing the GQA ratio
 size_t attn_decode_partial_floats(int B, int H, int Hkv, int Dh, int W);
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 
@@ -147,11 +150,13 @@ hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const f
                        hipStream_t s);
 hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
                            const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s);
+// engine_ctrl (nullable): control words of the persistent decode engine - [0] step epoch (incremented here), [2] the
+// per-step abort broadcast (cleared here)
 hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
-                              int32_t* tok_pos, int B, hipStream_t s);
+                              int32_t* tok_pos, int B, uint32_t* engine_ctrl, hipStream_t s);
 hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
                                         int32_t* tok_pos, int B, void* out, const void* table, const int64_t* ids, int D,
-                                        int vocab, hipStream_t s);
+                                        int vocab, uint32_t* engine_ctrl, hipStream_t s);
 hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- MoE
@@ -165,3 +170,56 @@ hipError_t launch_moe_lists(const int32_t* sel_idx, int T, int E, int top_k, int
 // bf16 from zero (moe.py:28-32 + transformer_layers.py:168)
 hipError_t launch_moe_combine(void* out, const void* h, const void* y, const int32_t* sel_idx, const float* sel_w,
                               const int32_t* row_of, int T, int D, int top_k, hipStream_t s);
+
+
+// ---------------------------------------------------------------------------------------------- persistent decode engine
+// decode_engine.hip: one launch per (up to ENG_MAXL) layers of a batch-1 decode step on a dense model.
+constexpr int ENG_MAXL = 32;  // layers per launch: bounded by the 4 KiB kernel-argument segment
+
+struct EngLayer {
+  const bf16_t *an, *wq, *wk, *wv, *wo, *fn, *w1, *w2, *w3;
+  bf16_t *ck, *cv;
+  int W, n_splits, chunk, pad;
+};
+
+struct EngArgs {
+  int n_layers, D, H, Hkv, F, V;
+  int R, kv_groups, Hs;   // query heads per scheduled kv head; groups per real kv head; scheduled kv heads
+  int NB, ring_fills;
+  int seq_base;           // global index of this launch's first layer (tag sequence)
+  int first, head;
+  float eps;
+  bf16_t* h;              // [D] residual stream, in (first layer) / out (last layer)
+  const float* rope_cs;
+  const int32_t* tok_pos;
+  const int32_t* tok_seq;
+  const bf16_t* final_norm;
+  const bf16_t* output;
+  float* logits;
+  uint64_t* gran;         // granule regions
+  uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part;
+  EngLayer L[ENG_MAXL];
+};
+
+struct EngProblem {
+  int D, H, Hkv, F, V, n_layers, NB;
+  float eps;
+  const mi_layer_t* layers;  // host
+  void* const* cache_k;      // host [n_layers]
+  void* const* cache_v;
+  const int32_t* W;          // host [n_layers]
+  void* h;
+  const float* rope_cs;
+  const int32_t* tok_pos;
+  const int32_t* tok_seq;
+  const void* final_norm;
+  const void* output;
+  float* logits;             // nullptr: no LM head
+  void* granules;
+  size_t granule_bytes;
+  uint32_t* ctrl;
+};
+size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW);
+bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len);
+hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s);

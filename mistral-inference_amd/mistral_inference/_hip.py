@@ -21,7 +21,7 @@ def _default_lib() -> str:
 
 LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", _default_lib())
 
-MI_ABI_VERSION = 2
+MI_ABI_VERSION = 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
 BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
 GEMV_MAX_T = 8
@@ -76,6 +76,8 @@ _SIGS = {
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
     "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
+    "mi_set_decode_engine": (C.c_int, [C.c_int]),
+    "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -246,6 +248,18 @@ def moe_router(x: torch.Tensor, gate: torch.Tensor, top_k: int, norm_w: Optional
     check(lib().mi_moe_router(dev_ptr(idx, torch.int32), dev_ptr(w, torch.float32), dev_ptr(x), x.stride(0), T, D,
                               dev_ptr(gate), E, top_k, dev_ptr(norm_w), float(eps), stream_ptr(x.device)), "mi_moe_router")
     return idx, w
+
+
+def set_decode_engine(enabled: bool) -> bool:
+    """Persistent decode engine on/off (default on; see include/mistral_hip.h).  Returns the previous setting."""
+    return bool(lib().mi_set_decode_engine(1 if enabled else 0))
+
+
+def decode_engine_status(workspace: torch.Tensor) -> dict:
+    """Control words of the persistent decode engine in `workspace` (synchronises the current stream)."""
+    st = (C.c_uint32 * 4)()
+    check(lib().mi_decode_engine_status(workspace.data_ptr(), stream_ptr(workspace.device), st), "mi_decode_engine_status")
+    return {"epoch": int(st[0]), "status": int(st[1]), "abort": int(st[2])}
 
 
 def ptr_array(ptrs: List[Optional[int]]):

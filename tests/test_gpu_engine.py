@@ -1,0 +1,143 @@
+"""Persistent decode engine (csrc/decode_engine.hip) against the launch path it replaces, stage by stage and end to end.
+
+The engine reproduces the launch path's arithmetic AND summation orders (csrc/attn_decode_core.cuh, gemv_core.cuh), so
+the contract is bit equality: logits, the residual stream and every K/V ring must be identical after every decode step.
+The launch path itself is compared with the oracle in test_gpu_model.py / test_gpu_depth.py; one oracle comparison of
+the engine is repeated here so that this file stands on its own.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+import mistral_oracle as mo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+
+
+def _model(args: mo.OracleArgs, seed: int):
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.transformer import Transformer
+    w = mo.synth_weights(args, seed=seed)
+    targs = TransformerArgs.from_dict(mo.params_json(args))
+    targs.max_batch_size = 1
+    with torch.device("meta"):
+        m = Transformer(targs)
+    m = m.to(BF).to_empty(device="cuda")
+    m.load_state_dict({k: v.cuda() for k, v in w.items()}, assign=True)
+    return m.eval(), w
+
+
+def _cache(m, n):
+    from mistral_inference.cache import BufferCache
+    a = m.args
+    c = BufferCache(m.n_local_layers, 1, n, a.n_kv_heads, a.head_dim, a.sliding_window, device="cuda", dtype=BF)
+    c.reset()
+    return c
+
+
+def _run(m, ids, prompt_len, steps, engine: bool, graph: bool = False):
+    """Prefill `prompt_len` tokens (always the launch path), then `steps` teacher-forced decode steps."""
+    from mistral_inference import _hip
+    prev = _hip.set_decode_engine(engine)
+    try:
+        c = _cache(m, prompt_len + steps + 2)
+        m.forward(ids[:prompt_len], [prompt_len], c)
+        outs = []
+        ctx = m.graphed_decode(c) if graph else _null()
+        with ctx:
+            for i in range(steps):
+                outs.append(m.forward(ids[prompt_len + i:prompt_len + i + 1], [1], c)[0].clone())
+        torch.cuda.synchronize()
+        st = _hip.decode_engine_status(m._backend._workspace)
+        rings = [(c.cache_k[l].clone(), c.cache_v[l].clone()) for l in range(m.n_local_layers)]
+        return outs, rings, st
+    finally:
+        _hip.set_decode_engine(prev)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+SHAPES = {
+    # dims are multiples of 512 (engine requirement); vocab deliberately not a multiple of 512
+    "gqa4_window_wraps": dict(dim=512, n_layers=3, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
+                              vocab_size=1000, sliding_window=48),
+    "mha_no_window": dict(dim=512, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=4, n_kv_heads=4, norm_eps=1e-5,
+                          vocab_size=514, sliding_window=None),
+    "gqa2_long_ring": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=8, n_kv_heads=4, norm_eps=1e-6,
+                           vocab_size=2048, sliding_window=1200),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_engine_bit_equal_launch_path(name):
+    p = SHAPES[name]
+    args = mo.OracleArgs(**p)
+    m, _ = _model(args, seed=11)
+    W = p["sliding_window"] or 10 ** 9
+    prompt_len = 40 if W < 100 else 300  # 40 + steps crosses the 48-slot ring; 300 leaves later splits empty in a 1200 ring
+    steps = 12
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(3)).cuda()
+    ref, ref_rings, st0 = _run(m, ids, prompt_len, steps, engine=False)
+    got, got_rings, st1 = _run(m, ids, prompt_len, steps, engine=True)
+    assert st1["status"] == 0 and st1["abort"] == 0, st1
+    assert st1["epoch"] >= steps  # the engine's step counter advanced: it really ran
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.isfinite(b).all(), i
+        assert torch.equal(a, b), (name, i, float((a - b).abs().max()))
+    for l, ((k0, v0), (k1, v1)) in enumerate(zip(ref_rings, got_rings)):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l)
+
+
+def test_engine_graph_replay_and_oracle():
+    """hipGraph replay of engine steps (the epoch lives in device memory, so replays see fresh tags) == eager engine
+    steps == launch path; and the whole thing against the CPU oracle."""
+    p = SHAPES["gqa4_window_wraps"]
+    args = mo.OracleArgs(**p)
+    m, w = _model(args, seed=5)
+    prompt_len, steps = 30, 24
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(9)).cuda()
+    ref, _, _ = _run(m, ids, prompt_len, steps, engine=False)
+    eager, _, st = _run(m, ids, prompt_len, steps, engine=True)
+    graph, _, st2 = _run(m, ids, prompt_len, steps, engine=True, graph=True)
+    assert st["status"] == 0 and st2["status"] == 0
+    assert all(torch.equal(a, b) for a, b in zip(ref, eager))
+    assert all(torch.equal(a, b) for a, b in zip(ref, graph))
+    om = mo.OracleModel(args, w)
+    oc = mo.OracleCache(args.n_layers, 1, prompt_len + steps + 2, args.n_kv_heads, args.head_dim, args.sliding_window, dtype=BF)
+    om.forward(ids[:prompt_len].cpu(), [prompt_len], oc)
+    for i in range(steps):
+        o = om.forward(ids[prompt_len + i:prompt_len + i + 1].cpu(), [1], oc)[0]
+        assert float((eager[i].cpu() - o).abs().max()) < 4e-2, i
+
+
+def test_engine_full_size_bit_equal():
+    """BASELINE configs[1] dims, 32 layers, 4096-token prompt, ring full and wrapping: engine == launch path bit for bit
+    (logits of 6 decode steps, all 64 rings), eager and replayed from a hipGraph."""
+    sys.path.insert(0, ROOT)
+    import bench
+    m = bench.build_model(dict(bench.MISTRAL_7B), 0, 1, "cuda")
+    T, steps = 4096, 6
+    ids = torch.randint(0, m.args.vocab_size, (T + steps,), generator=torch.Generator().manual_seed(0)).cuda()
+    ref, ref_rings, _ = _run(m, ids, T, steps, engine=False)
+    got, got_rings, st = _run(m, ids, T, steps, engine=True)
+    assert st["status"] == 0 and st["abort"] == 0, st
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    for l, ((k0, v0), (k1, v1)) in enumerate(zip(ref_rings, got_rings)):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1), l
+    del ref_rings, got_rings
+    graph, _, st2 = _run(m, ids, T, steps, engine=True, graph=True)
+    assert st2["status"] == 0
+    assert all(torch.equal(a, b) for a, b in zip(ref, graph))
+    del m
+    torch.cuda.empty_cache()
