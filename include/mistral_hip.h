@@ -205,6 +205,11 @@ int mi_set_decode_engine(int enabled);
  * path): status[0] = step epoch, status[1] = 0 or the code of the first bounded wait that ever timed out
  * (0x100 loader / 0x200 ring / 0x300 consumer barrier / 0x400 hand-off sweep), status[2] = abort flag of the last step. */
 int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[4]);
+/* Debug timeline of the engine (scripts/engine_trace.py): while a zero-filled device buffer of
+ * mi_debug_engine_trace_bytes() bytes is registered, consumer wave 0 and the loader wave of every workgroup stamp a
+ * 100 MHz clock at each phase boundary of each layer: trace[cu][layer (32)][event (26)] uint64.  NULL unregisters. */
+size_t mi_debug_engine_trace_bytes(void);
+int mi_debug_set_engine_trace(void* dev_buffer);
 
 #ifdef __cplusplus
 }

@@ -324,6 +324,12 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
   return hip_rc(hipStreamSynchronize((hipStream_t)stream), "status sync");
 }
 
+size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(device_cus()); }
+int mi_debug_set_engine_trace(void* dev_buffer) {
+  decode_engine_set_trace(dev_buffer);
+  return MI_OK;
+}
+
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size) {
   if (!model || T <= 0 || B <= 0) return 0;
   return carve(model, T, B, max_cache_size > 0 ? max_cache_size : 1, nullptr).total;

@@ -72,6 +72,12 @@ enum : int {
   C_RED = 8         // [4] fp32 wave totals of the RMSNorm
 };
 
+// Optional timeline (mi_debug_set_engine_trace): trace[c][layer][event] = 100 MHz wall clock.  Consumer wave 0 writes
+// events [0, TR_CONS), the loader events [TR_CONS, TR_EVENTS).  The buffer is reached through an explicit
+// global-address-space pointer held in `Shared`: a store through a generic pointer loaded from the by-value argument
+// struct makes hipcc spill the whole struct to scratch.
+constexpr int TR_CONS = 18, TR_EVENTS = 26;
+
 struct Shared {
   lvu32* ctl;
   lbf16* res;   // residual rows of this CU
@@ -79,7 +85,12 @@ struct Shared {
   lchar* ring;
   uint32_t ring_mask;  // ring pieces - 1
   gu32* ctrl;          // [0] epoch, [1] sticky status, [2] per-step abort broadcast
+  gu64* trace;         // optional timeline buffer
 };
+
+__device__ __forceinline__ void trace_ev(const Shared& sh, int c, int layer, int ev, bool who) {
+  if (sh.trace && who) sh.trace[((size_t)c * ENG_MAXL + layer) * TR_EVENTS + ev] = __builtin_amdgcn_s_memrealtime();
+}
 
 __device__ __forceinline__ void raise_abort(const Shared& sh, uint32_t code) {
   sh.ctl[C_ABORT] = 1;
@@ -150,6 +161,7 @@ struct Loader {
   int lane, ring_fills;
   uint32_t g = 0;    // pieces issued
   uint32_t pub = 0;  // fills published
+  uint32_t stalls = 0;  // fills that had to wait for a free ring slot (trace only)
 
   __device__ __forceinline__ uint32_t min_done() const {
     return min(min(sh.ctl[C_DONE + 0], sh.ctl[C_DONE + 1]), min(sh.ctl[C_DONE + 2], sh.ctl[C_DONE + 3]));
@@ -168,6 +180,7 @@ struct Loader {
         if (min_done() < need) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           publish(f);  // everything issued has landed: consumers must not starve while we wait for them
+          ++stalls;
           uint32_t spins = 0;
           while (min_done() < need)
             if (!spin_ok(sh, spins, 0x100)) break;
@@ -199,16 +212,19 @@ struct Loader {
   }
 };
 
-__device__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
+__device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
   Loader ld{sh, lane, a.ring_fills};
   const int PD = a.D >> 9;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
+    const bool tr = lane == 0;
+    trace_ev(sh, c, l, TR_CONS + 0, tr);
     ld.rows(L.wq, 2 * (size_t)p.q0, 2 * (p.q1 - p.q0), a.D);
     ld.rows(L.wk, 2 * (size_t)p.k0, 2 * (p.k1 - p.k0), a.D);
     ld.rows(L.wv, 2 * (size_t)p.v0, 2 * (p.v1 - p.v0), a.D);
+    trace_ev(sh, c, l, TR_CONS + 1, tr);
     if (p.n_att) {  // K piece j, V piece j: 4 ring slots x 256 B each (slots past the ring end are clamped; masked later)
       const int kv_real = p.kvh / a.kv_groups;
       const size_t row_stride = (size_t)a.Hkv * DH;
@@ -219,14 +235,19 @@ __device__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, 
         ld.piece(L.cv + base + (size_t)slot * row_stride);
       }
     }
+    trace_ev(sh, c, l, TR_CONS + 2, tr);
     ld.rows(L.wo, 2 * (size_t)p.o0, 2 * (p.o1 - p.o0), a.H * DH);
+    trace_ev(sh, c, l, TR_CONS + 3, tr);
     for (int j = p.f0; j < p.f1; ++j) {
       ld.rows(L.w1, 2 * (size_t)j, 1, a.D);
       ld.rows(L.w3, 2 * (size_t)j, 1, a.D);
       ld.rows(L.w1, 2 * (size_t)j + 1, 1, a.D);
       ld.rows(L.w3, 2 * (size_t)j + 1, 1, a.D);
     }
+    trace_ev(sh, c, l, TR_CONS + 4, tr);
     ld.rows(L.w2, 2 * (size_t)p.o0, 2 * (p.o1 - p.o0), a.F);
+    trace_ev(sh, c, l, TR_CONS + 5, tr);
+    if (sh.trace && tr) sh.trace[((size_t)c * ENG_MAXL + l) * TR_EVENTS + TR_CONS + 6] = ld.stalls;
   }
   if (a.head) {
     int v0, v1;
@@ -328,13 +349,13 @@ struct Cons {
       }
     }
   }
-  __device__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
+  __device__ __forceinline__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
     gather_fn(n, tag, dst, [&](int i) { return src + i; });
   }
 
   // RMSNorm of the K-element bf16 vector in LDS, in place (transformer_layers.py:115-120), with the launch path's
   // reduction tree: 256 "threads" own 16-byte pieces vt + i * 256, per-piece sums, wave butterfly, 4 wave totals.
-  __device__ void rmsnorm_inplace(lbf16* xs, int K, const bf16_t* norm_w, float eps) {
+  __device__ __forceinline__ void rmsnorm_inplace(lbf16* xs, int K, const bf16_t* norm_w, float eps) {
     const int vt = w * 64 + lane, npieces = K >> 3;
     u32x4 xr[4];
     float ss = 0.f;
@@ -376,7 +397,7 @@ struct Cons {
 };
 
 template <int R>
-__device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch) {
+__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch) {
   Cons cs{sh, w, lane};
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -399,6 +420,8 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
     const EngLayer& L = a.L[l];
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
+    const bool trc = (w == 0) && (lane == 0);
+    trace_ev(sh, c, l, 0, trc);
 
     // ================================================================ attention_norm + q|k|v + RoPE + ring write
     if (l == 0 && a.first) {  // the step's input comes from global memory (embedding / previous stage / previous launch)
@@ -412,7 +435,9 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       cs.cbar();
       sh.ctl[C_GATHERING] = 0;
     }
+    trace_ev(sh, c, l, 1, trc);
     cs.rmsnorm_inplace(xs, a.D, L.an, a.eps);
+    trace_ev(sh, c, l, 2, trc);
     {
       const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0, n_u = nq_u + 2 * nk_u;
       for (int k = w; k < n_u; k += NCONS) {
@@ -447,9 +472,11 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       g += (uint32_t)(2 * n_u) * PD;
       cs.set_done(g);
     }
+    trace_ev(sh, c, l, 3, trc);
 
     // ================================================================ attention: this CU's (kv head, split)
     cs.cbar();  // every wave is done with the normalised activations: the region becomes attention scratch
+    trace_ev(sh, c, l, 4, trc);
     if (p.att) {
       const int kv_real = p.kvh / a.kv_groups;
       const uint32_t tq = tag_of(l, 1);
@@ -459,6 +486,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       cs.gather(G + a.g_qkv + nq / 2 + nkv / 2 + (size_t)kv_real * 64, 64, tq, vn_lds);
       cs.cbar();
       sh.ctl[C_GATHERING] = 0;
+      trace_ev(sh, c, l, 5, trc);
       const int gl = lane >> 4, dl = lane & 15;
       float qf[R][8];
       {
@@ -489,6 +517,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       }
       g += 2 * p.n_att;
       cs.set_done(g);
+      trace_ev(sh, c, l, 6, trc);
       wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
       cs.cbar();
       const uint32_t tp = tag_of(l, 2);
@@ -505,6 +534,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
         }
       }
     }
+    trace_ev(sh, c, l, 7, trc);
 
     // ================================================================ split merge: this CU's slab of output pairs
     {
@@ -523,6 +553,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
         });
         cs.cbar();
         sh.ctl[C_GATHERING] = 0;
+        trace_ev(sh, c, l, 8, trc);
         if (w == 0) {
           const int el = min(lane, ne - 1);
           const lf32* ca = reinterpret_cast<const lf32*>(cmb_lds) + el;
@@ -537,11 +568,13 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
     }
 
     // ================================================================ h1 = h + attn @ Wo^T
+    trace_ev(sh, c, l, 9, trc);
     cs.cbar();  // the attention scratch is dead
     sh.ctl[C_GATHERING] = 1;
     cs.gather(G + a.g_att, nq / 2, tag_of(l, 3), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
+    trace_ev(sh, c, l, 10, trc);
     {
       const int n_u = p.o1 - p.o0;
       for (int k = w; k < n_u; k += NCONS) {
@@ -558,6 +591,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       g += (uint32_t)(2 * n_u) * PA;
       cs.set_done(g);
     }
+    trace_ev(sh, c, l, 11, trc);
 
     // ================================================================ hid = silu(W1 x) * (W3 x), x = ffn_norm(h1)
     cs.cbar();
@@ -565,7 +599,9 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
     cs.gather(G + a.g_h1, a.D / 2, tag_of(l, 4), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
+    trace_ev(sh, c, l, 12, trc);
     cs.rmsnorm_inplace(xs, a.D, L.fn, a.eps);
+    trace_ev(sh, c, l, 13, trc);
     {
       const int n_u = p.f1 - p.f0;
       for (int k = w; k < n_u; k += NCONS) {
@@ -581,6 +617,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       g += (uint32_t)(4 * n_u) * PD;
       cs.set_done(g);
     }
+    trace_ev(sh, c, l, 14, trc);
 
     // ================================================================ h = h1 + hid @ W2^T
     cs.cbar();
@@ -588,6 +625,7 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
     cs.gather(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
+    trace_ev(sh, c, l, 15, trc);
     {
       const int n_u = p.o1 - p.o0;
       const bool to_global = (l == a.n_layers - 1);
@@ -606,7 +644,9 @@ __device__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, i
       g += (uint32_t)(2 * n_u) * PF;
       cs.set_done(g);
     }
+    trace_ev(sh, c, l, 16, trc);
     cs.cbar();
+    trace_ev(sh, c, l, 17, trc);
   }
 
   // ================================================================ final norm + LM head (transformer.py:219,235,242)
@@ -646,6 +686,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   sh.ring = lds + (LDS_TOTAL - a.ring_fills * FILL * PIECE);
   sh.ring_mask = a.ring_fills * FILL - 1;
   sh.ctrl = (gu32*)a.ctrl;
+  sh.trace = (gu64*)a.trace;
   if (threadIdx.x < CTL_BYTES / 4) sh.ctl[threadIdx.x] = 0;
   __syncthreads();  // the only workgroup barrier: roles split below
 
@@ -717,9 +758,16 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   return true;
 }
 
+namespace {
+uint64_t* g_trace = nullptr;
+}
+void decode_engine_set_trace(void* dev_buffer) { g_trace = (uint64_t*)dev_buffer; }
+size_t decode_engine_trace_bytes(int NB) { return (size_t)NB * ENG_MAXL * TR_EVENTS * sizeof(uint64_t); }
+
 hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
   EngArgs a;
   memset(&a, 0, sizeof(a));
+  a.trace = (unsigned long long*)g_trace;
   a.D = pr.D; a.H = pr.H; a.Hkv = pr.Hkv; a.F = pr.F; a.V = pr.V; a.eps = pr.eps; a.NB = pr.NB;
   const int Rtot = pr.H / pr.Hkv;
   a.R = attn_decode_group(Rtot);

@@ -199,6 +199,7 @@ struct EngArgs {
   uint64_t* gran;         // granule regions
   uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
   uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part;
+  unsigned long long* trace;  // optional timeline buffer (debug)
   EngLayer L[ENG_MAXL];
 };
 
@@ -223,3 +224,5 @@ struct EngProblem {
 size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW);
 bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len);
 hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s);
+void decode_engine_set_trace(void* dev_buffer);  // debug: nullptr disables
+size_t decode_engine_trace_bytes(int NB);

@@ -78,6 +78,8 @@ _SIGS = {
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
+    "mi_debug_engine_trace_bytes": (C.c_size_t, []),
+    "mi_debug_set_engine_trace": (C.c_int, [_vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

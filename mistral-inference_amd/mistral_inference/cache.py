@@ -207,6 +207,13 @@ class BufferCache:
         seen = self._seen
         assert seen is not None
         dev = self.device
+        if batch.branch == _hip.BRANCH_DECODE:
+            # `batch_metadata` hands out views of the block the decode-prep kernel of `mi_forward` fills on the device.
+            # A caller that drives the layers itself never runs that kernel: give it the same arrays from the host mirror.
+            B = len(seqlens)
+            blob = torch.tensor(list(range(B + 1)) + list(seen) + list(range(B)) + list(seen), dtype=torch.int32).to(dev)
+            batch = BatchMetadata(_hip.BRANCH_DECODE, seqlens, 1, blob[: B + 1], blob[B + 1: 2 * B + 1],
+                                  blob[2 * B + 1: 3 * B + 1], blob[3 * B + 1:])
         out: List[CacheInputMetadata] = []
         tok_b = [b for b, s in enumerate(seqlens) for _ in range(s)]
         tok_i = [i for s in seqlens for i in range(s)]

@@ -33,6 +33,17 @@ def init_pipeline() -> int:
     return torch.distributed.get_world_size()
 
 
+def share_prompt_length(n_tokens: int) -> int:
+    """Rank 0's prompt length on every pipeline rank (reference main.py:161-170: only the LENGTH is shared, the other
+    ranks feed that many placeholder ids).  RCCL ("nccl") moves device memory only, so the one-element tensor lives
+    on the current device for the broadcast and its RECEIVED value is what is returned."""
+    buf = torch.tensor([n_tokens], dtype=torch.int)
+    if torch.distributed.get_backend() == "nccl":
+        buf = buf.cuda()
+    torch.distributed.broadcast(buf, src=0)
+    return int(buf.item())
+
+
 def _should_print() -> bool:
     return not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0
 
@@ -76,7 +87,6 @@ def interactive(model_path: str, max_tokens: int = 35, temperature: float = 0.7,
         model.load_lora(Path(lora_path))
     messages: List = []
     while True:
-        length = torch.zeros(1, dtype=torch.int)
         tokens: List[int] = []
         if should_print:
             user_input = input("Prompt: ")
@@ -87,12 +97,11 @@ def interactive(model_path: str, max_tokens: int = 35, temperature: float = 0.7,
                 tokens = mistral_tokenizer.encode_chat_completion(req.ChatCompletionRequest(messages=messages)).tokens
             else:
                 tokens = tokenizer.encode(user_input, bos=True, eos=False)
-            length = torch.tensor([len(tokens)], dtype=torch.int)
         if is_torchrun():
             # only the prompt LENGTH is shared; other ranks feed dummy ids (reference main.py:161-170)
-            torch.distributed.broadcast(length.cuda() if torch.distributed.get_backend() == "nccl" else length, src=0)
+            n = share_prompt_length(len(tokens))
             if not should_print:
-                tokens = int(length.item()) * [0]
+                tokens = n * [0]
         generated, _ = generate([tokens], model, max_tokens=max_tokens, temperature=temperature,
                                 eos_id=tokenizer.eos_id)
         answer = tokenizer.decode(generated[0])

@@ -78,10 +78,12 @@ def build(over, dtype):
     return p, oargs, w, model.to("cpu", dtype=dtype).eval()
 
 
-def main() -> None:
-    os.makedirs(OUT, exist_ok=True)
+def main(out_dir: str = OUT, only=None) -> None:
+    os.makedirs(out_dir, exist_ok=True)
     index = {}
     for name, (over, dt, prompts, max_tokens, chunk) in CASES.items():
+        if only is not None and name not in only:
+            continue
         dtype = getattr(torch, dt)
         params, oargs, w, model = build(over, dtype)
         fwd_out, layer_out = [], []
@@ -131,10 +133,10 @@ def main() -> None:
         }
         if name in ORACLE_ONLY:
             meta["oracle_only"] = True
-        save_file(tensors, os.path.join(OUT, f"{name}.safetensors"))
+        save_file(tensors, os.path.join(out_dir, f"{name}.safetensors"))
         index[name] = meta
         print(f"{name}: {len(tensors)} tensors, tokens={toks}")
-    with open(os.path.join(OUT, "index.json"), "w") as f:
+    with open(os.path.join(out_dir, "index.json"), "w") as f:
         json.dump(index, f, indent=1)
 
 

@@ -20,10 +20,19 @@ def memory_efficient_attention(query, key, value, attn_bias: Optional[AttentionB
     q = query.float().permute(0, 2, 1, 3)
     kk = key.float().permute(0, 2, 1, 3)
     v = value.float().permute(0, 2, 1, 3)
-    s = torch.matmul(q, kk.transpose(-1, -2)) * sc
+    bias = None
     if attn_bias is not None:
         bias = attn_bias.materialize((b, h, mq, mk), dtype=torch.float32, device=query.device)
-        s = s + bias
+        # xformers never READS a key no query of the call can see (the padded tail of every cache row under
+        # BlockDiagonalCausalWithOffsetPaddedKeysMask, reference cache.py:249-254).  Those rows of the reference's
+        # `torch.empty` cache (cache.py:163-167) hold arbitrary bits - NaN/Inf included - and `NaN + -inf` or `0 * NaN`
+        # would leak them into the result, so dead key columns are zeroed before they enter any arithmetic.
+        dead = torch.isneginf(bias).all(dim=-2)  # [b, h, mk]
+        kk = kk.masked_fill(dead.unsqueeze(-1), 0.0)
+        v = v.masked_fill(dead.unsqueeze(-1), 0.0)
+    s = torch.matmul(q, kk.transpose(-1, -2)) * sc
+    if bias is not None:
+        s = (s + bias).masked_fill(torch.isneginf(bias), float("-inf"))
     p_ = torch.softmax(s, dim=-1)
     o = torch.matmul(p_, v)
     return o.permute(0, 2, 1, 3).contiguous().to(query.dtype)

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Timeline of one decode step on the persistent decode engine (debug / tuning aid).
+
+Registers a trace buffer (mi_debug_set_engine_trace), runs one batch-1 decode step of the BASELINE configs[1] model at
+context 4096 and prints, per phase of a layer, when consumer wave 0 of every CU passed it (mean / min / max over CUs,
+averaged over the middle layers) and how long the loader took per weight segment.  Raw stamps: gpurun_out/engine_trace.npy
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "mistral-inference_amd"))
+import bench  # noqa: E402
+from mistral_inference import _hip  # noqa: E402
+from mistral_inference.cache import BufferCache  # noqa: E402
+
+CONS = ["start", "h gathered", "normed", "qkv rows", "cbar", "q gathered", "att pieces", "partial pub", "merge gathered",
+        "merge pub", "attn gathered", "wo rows", "h1 gathered", "normed2", "w13 rows", "hid gathered", "w2 rows", "end"]
+LOAD = ["L start", "L qkv", "L kv", "L wo", "L w13", "L w2"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--prefill", type=int, default=4096)
+    opt = ap.parse_args()
+    params = dict(bench.MISTRAL_7B)
+    params["n_layers"] = opt.layers
+    model = bench.build_model(params, 0, 1, "cuda")
+    a = model.args
+    cache = BufferCache(model.n_local_layers, 1, opt.prefill + 64, a.n_kv_heads, a.head_dim, a.sliding_window, device="cuda",
+                        dtype=torch.bfloat16)
+    cache.reset()
+    ids = torch.randint(0, a.vocab_size, (opt.prefill,), generator=torch.Generator().manual_seed(0)).cuda()
+    L = _hip.lib()
+    with torch.inference_mode():
+        nxt = torch.argmax(model.forward(ids, [opt.prefill], cache)[-1:], dim=-1)
+        for _ in range(4):
+            nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+        torch.cuda.synchronize()
+        nbytes = L.mi_debug_engine_trace_bytes()
+        buf = torch.zeros(nbytes // 8, dtype=torch.int64, device="cuda")
+        L.mi_debug_set_engine_trace(buf.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+        e1.record()
+        torch.cuda.synchronize()
+        L.mi_debug_set_engine_trace(None)
+    print("status", _hip.decode_engine_status(model._backend._workspace), "step ms (traced)", e0.elapsed_time(e1))
+    t = buf.cpu().numpy().reshape(-1, 32, 26).astype(np.float64)
+    nb = t.shape[0]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.save(os.path.join(ROOT, "gpurun_out", "engine_trace.npy"), t)
+    nl = opt.layers
+    us = 0.01  # 100 MHz ticks -> us
+    t0 = t[:, 0, 0].min()
+    print(f"CUs {nb}, layers {nl}; whole launch span (first start -> last end): "
+          f"{(t[:, nl - 1, 17].max() - t0) * us:.1f} us; per layer {(t[:, nl - 1, 17].max() - t0) * us / nl:.1f} us")
+    mid = range(2, max(3, nl - 2))
+    print("\nconsumer wave 0: time of each event relative to the layer's earliest start (us), averaged over middle layers")
+    print(f"{'event':16s} {'mean':>8s} {'min':>8s} {'max':>8s}   {'delta(mean)':>10s}")
+    prev = None
+    for ev, name in enumerate(CONS):
+        rel = np.stack([(t[:, l, ev] - t[:, l, 0].min()) * us for l in mid])  # [layers, cus]
+        valid = np.stack([t[:, l, ev] > 0 for l in mid])
+        m = rel[valid].mean() if valid.any() else float("nan")
+        lo = np.where(valid, rel, np.inf).min(axis=1).mean()
+        hi = np.where(valid, rel, -np.inf).max(axis=1).mean()
+        d = m - prev if prev is not None else 0.0
+        print(f"{name:16s} {m:8.2f} {lo:8.2f} {hi:8.2f}   {d:10.2f}")
+        prev = m
+    print("\nloader: time of each event relative to the same origin (us)")
+    for ev, name in enumerate(LOAD):
+        rel = np.stack([(t[:, l, 18 + ev] - t[:, l, 0].min()) * us for l in mid])
+        print(f"{name:16s} {rel.mean():8.2f} {rel.min(axis=1).mean():8.2f} {rel.max(axis=1).mean():8.2f}")
+    stalls = t[:, :nl, 24]
+    print("loader ring-full stalls per CU (cumulative at last layer): mean %.1f max %.0f" % (stalls[:, nl - 1].mean(), stalls[:, nl - 1].max()))
+    seg = (t[:, 2:nl - 2, 23] - t[:, 2:nl - 2, 18]) * us
+    print("loader time per layer: mean %.2f us, min %.2f, max %.2f  (1.70 MB per CU per layer -> %.1f GB/s per CU, %.2f TB/s chip)"
+          % (seg.mean(), seg.min(), seg.max(), 1.70e6 / seg.mean() / 1e3, 1.70e6 / seg.mean() / 1e3 * nb / 1e3))
+
+
+if __name__ == "__main__":
+    main()
