@@ -126,6 +126,34 @@ int mi_gelu(void* x, int ldx, int T, int N, mi_stream_t stream);
 int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate, int E,
                   int top_k, const void* norm_w, float eps, mi_stream_t stream);
 
+/* transformer_layers.py:66-70,165 + rope.py:13-23 + cache.py:83-92 for T <= 8 tokens (the decode step) in ONE launch:
+ * qkv[t] = [ rope(Wq xn) | rope(Wk xn) | Wv xn ] with xn = RMSNorm(x[t]; norm_w, eps) (norm_w == NULL: xn = x), every
+ * projection rounded to bf16 before the rotation; when cache_k/cache_v are given the new K/V rows are also stored into
+ * ring slot tok_pos[t] % W of row tok_seq[t] (tok_seq == NULL: row t) - CacheView.update at decode.
+ * qkv: [T, ldo] bf16, ldo >= (n_heads + 2 n_kv_heads) * head_dim.  T > 8: MI_ERR_UNSUPPORTED (the prefill path is
+ * mi_rmsnorm + mi_linear + mi_rope_inplace + mi_kv_write). */
+int mi_qkv_rope_kvwrite(void* qkv, int ldo, const void* x, int ldx, int T, int D, const void* wq, const void* wk,
+                        const void* wv, int n_heads, int n_kv_heads, int head_dim, const void* norm_w, float eps,
+                        const float* rope_cs, int rope_len, const int32_t* tok_pos, const int32_t* tok_seq, void* cache_k,
+                        void* cache_v, int W, mi_stream_t stream);
+
+/* moe.py:28-32 (+ the residual add of transformer_layers.py:168) for T <= 8 tokens, two launches, no host sync:
+ * out[t] = bf16(residual[t] + R_t), R_t = sum over the token's picked experts in ascending expert id of
+ * bf16(w * bf16(W2_e . bf16(silu(W1_e xn) * W3_e xn))), accumulated in bf16 from zero; xn = RMSNorm(x[t]) when norm_w is
+ * given.  expert_w_dev: DEVICE array [E][3] of (w1, w2, w3) pointers; sel_idx/sel_w: mi_moe_router's output [T, top_k];
+ * hidden_scratch: bf16 [T * top_k, F].  out may alias residual. */
+int mi_moe_experts_decode(void* out, const void* residual, const void* x, int ldx, int T, int D, int F,
+                          const void* const* expert_w_dev, const int32_t* sel_idx, const float* sel_w, int top_k,
+                          const void* norm_w, float eps, void* hidden_scratch, mi_stream_t stream);
+
+/* The same layer for any T (prefill): (token, slot) pairs sorted by expert ON THE DEVICE (the reference does one
+ * torch.where host sync per expert per layer, moe.py:30), ONE token-grouped MFMA GEMM launch per projection over all
+ * experts, then the ordered bf16 combine + residual.  x: dense [T, D] (already ffn-normalised), ldx == D. */
+size_t mi_moe_grouped_gemm_scratch_bytes(int T, int D, int F, int E, int top_k);
+int mi_moe_grouped_gemm(void* out, const void* residual, const void* x, int ldx, int T, int D, int F, int E, int top_k,
+                        const void* const* expert_w_dev, const int32_t* sel_idx, const float* sel_w, void* scratch,
+                        size_t scratch_bytes, mi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole local layer stack: Transformer.forward_partial (transformer.py:163-219) + the LM head of
  * Transformer.forward (transformer.py:229-242)
@@ -210,6 +238,10 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
  * 100 MHz clock at each phase boundary of each layer: trace[cu][layer (32)][event (26)] uint64.  NULL unregisters. */
 size_t mi_debug_engine_trace_bytes(void);
 int mi_debug_set_engine_trace(void* dev_buffer);
+/* Tuning knobs of the engine's loader wave (results never depend on them): thin = 1 keeps one 16 KiB fill outstanding
+ * while the workgroup's consumers sweep hand-off granules (0: never); depth = fills in flight otherwise (2 or 3).
+ * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults. */
+int mi_debug_set_engine_knobs(int thin, int depth);
 
 #ifdef __cplusplus
 }

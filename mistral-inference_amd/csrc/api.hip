@@ -312,6 +312,115 @@ int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T,
   return hip_rc(launch_moe_router(sel_idx, sel_w, x, ldx, T, D, gate, E, top_k, norm_w, eps, (hipStream_t)stream), "moe_router");
 }
 
+int mi_qkv_rope_kvwrite(void* qkv, int ldo, const void* x, int ldx, int T, int D, const void* wq, const void* wk,
+                        const void* wv, int n_heads, int n_kv_heads, int head_dim, const void* norm_w, float eps,
+                        const float* rope_cs, int rope_len, const int32_t* tok_pos, const int32_t* tok_seq, void* cache_k,
+                        void* cache_v, int W, mi_stream_t stream) {
+  if (!qkv || !x || !wq || !wk || !wv || !rope_cs || !tok_pos || T <= 0 || D <= 0 || D % 8 || rope_len <= 0)
+    return fail(MI_ERR_ARG, "mi_qkv_rope_kvwrite");
+  if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
+  if ((cache_k == nullptr) != (cache_v == nullptr) || (cache_k && W <= 0)) return fail(MI_ERR_ARG, "mi_qkv_rope_kvwrite: cache");
+  if (T > GEMV_MAX_T)
+    return fail(MI_ERR_UNSUPPORTED, "mi_qkv_rope_kvwrite: T = %d > %d (the prefill path is mi_rmsnorm + mi_linear + "
+                "mi_rope_inplace + mi_kv_write)", T, GEMV_MAX_T);
+  const int nq = n_heads * head_dim, nkv = n_kv_heads * head_dim;
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mode = GEMV_QKV_ROPE; a.K = D; a.N = nq + 2 * nkv; a.x = (const bf16_t*)x; a.ldx = ldx;
+  a.norm_w = (const bf16_t*)norm_w; a.eps = eps;
+  a.w0 = (const bf16_t*)wq; a.w1 = (const bf16_t*)wk; a.w2 = (const bf16_t*)wv; a.n0 = nq; a.n1 = nq + nkv;
+  a.out = qkv; a.ldo = ldo;
+  a.rope_cs = rope_cs; a.tok_pos = tok_pos; a.tok_seq = tok_seq; a.head_dim = head_dim;
+  a.write_kv = cache_k != nullptr; a.cache_k = cache_k; a.cache_v = cache_v; a.W = W;
+  return gemv_passes(a, T, (hipStream_t)stream, "qkv gemv");
+}
+
+int mi_moe_experts_decode(void* out, const void* residual, const void* x, int ldx, int T, int D, int F,
+                          const void* const* expert_w_dev, const int32_t* sel_idx, const float* sel_w, int top_k,
+                          const void* norm_w, float eps, void* hidden_scratch, mi_stream_t stream) {
+  if (!out || !residual || !x || !expert_w_dev || !sel_idx || !sel_w || !hidden_scratch || T <= 0 || D % 8 || F % 8)
+    return fail(MI_ERR_ARG, "mi_moe_experts_decode");
+  if (T > GEMV_MAX_T) return fail(MI_ERR_UNSUPPORTED, "mi_moe_experts_decode: T = %d > %d (use mi_moe_grouped_gemm)", T, GEMV_MAX_T);
+  if (!(top_k == 1 || top_k == 2 || top_k == 4)) return fail(MI_ERR_SHAPE, "MoE: top_k in {1,2,4}");
+  if ((size_t)top_k * F * 2 > 65536) return fail(MI_ERR_SHAPE, "MoE: top_k * hidden_dim too large for the decode combine kernel");
+  hipStream_t s = (hipStream_t)stream;
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mode = GEMV_MOE_W13; a.T = T; a.K = D; a.N = F; a.x = (const bf16_t*)x; a.ldx = ldx;
+  a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.out = hidden_scratch; a.ldo = F;
+  a.expert_tab = expert_w_dev; a.sel_idx = sel_idx; a.sel_w = sel_w; a.top_k = top_k;
+  MI_TRY(hip_rc(launch_gemv(a, s), "moe w13 gemv"));
+  memset(&a, 0, sizeof(a));
+  a.mode = GEMV_MOE_W2; a.T = T; a.K = F; a.N = D; a.x = (const bf16_t*)hidden_scratch; a.ldx = F; a.out = out; a.ldo = D;
+  a.residual = (const bf16_t*)residual;
+  a.expert_tab = expert_w_dev; a.sel_idx = sel_idx; a.sel_w = sel_w; a.top_k = top_k;
+  return hip_rc(launch_gemv(a, s), "moe w2 gemv");
+}
+
+namespace {
+struct MoeScratch {
+  bf16_t* hid;
+  bf16_t* y;
+  int32_t *tok_of, *row_of, *tile_tab, *n_tiles;
+  int max_tiles;
+  size_t total;
+};
+MoeScratch moe_carve(int T, int D, int F, int E, int top_k, char* base) {
+  MoeScratch w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  };
+  const size_t rows = (size_t)T * top_k;
+  w.hid = (bf16_t*)take(rows * F * 2);
+  w.y = (bf16_t*)take(rows * D * 2);
+  w.tok_of = (int32_t*)take(rows * 4);
+  w.row_of = (int32_t*)take(rows * 4);
+  w.max_tiles = (int)((rows + 127) / 128) + E;
+  w.tile_tab = (int32_t*)take((size_t)w.max_tiles * 16);
+  w.n_tiles = (int32_t*)take(256);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+size_t mi_moe_grouped_gemm_scratch_bytes(int T, int D, int F, int E, int top_k) {
+  if (T <= 0 || D <= 0 || F <= 0 || E <= 0 || top_k <= 0) return 0;
+  return moe_carve(T, D, F, E, top_k, nullptr).total;
+}
+
+int mi_moe_grouped_gemm(void* out, const void* residual, const void* x, int ldx, int T, int D, int F, int E, int top_k,
+                        const void* const* expert_w_dev, const int32_t* sel_idx, const float* sel_w, void* scratch,
+                        size_t scratch_bytes, mi_stream_t stream) {
+  if (!out || !residual || !x || !expert_w_dev || !sel_idx || !sel_w || !scratch || T <= 0 || D % 8 || F % 8 || ldx != D)
+    return fail(MI_ERR_ARG, "mi_moe_grouped_gemm (x must be dense [T, D])");
+  if (E > 16 || top_k > 4 || top_k > E || top_k < 1) return fail(MI_ERR_SHAPE, "MoE: E <= 16, top_k <= 4");
+  MoeScratch w = moe_carve(T, D, F, E, top_k, (char*)scratch);
+  if (w.total > scratch_bytes) return fail(MI_ERR_WORKSPACE, "mi_moe_grouped_gemm: scratch %zu < required %zu", scratch_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  const int k = top_k;
+  // 256-row m-tiles (gemm256.hip) once an expert averages a few of them, else 128-row tiles (gemm.hip)
+  const int tile_rows = ((long)T * k >= 512L * E && D % 64 == 0 && F % 64 == 0) ? 256 : 128;
+  const int max_m_tiles = (T * k + tile_rows - 1) / tile_rows + E;
+  MI_TRY(hip_rc(launch_moe_lists(sel_idx, T, E, k, w.tok_of, w.row_of, w.tile_tab, w.n_tiles, tile_rows, s), "moe_lists"));
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.epi = GEMM_SWIGLU; g.M = T * k; g.N = F; g.K = D; g.a = (const bf16_t*)x; g.lda = D; g.n0 = g.n1 = F;
+  g.out = w.hid; g.ldo = F;
+  g.tile_tab = w.tile_tab; g.n_tiles_ptr = w.n_tiles; g.max_m_tiles = max_m_tiles; g.tile_rows = tile_rows;
+  g.expert_tab = expert_w_dev; g.w_sel0 = 0; g.w_sel1 = 2; g.a_gather = w.tok_of;
+  MI_TRY(hip_rc(launch_gemm(g, s), "moe w13 grouped gemm"));
+  memset(&g, 0, sizeof(g));
+  g.epi = GEMM_STORE; g.M = T * k; g.N = D; g.K = F; g.a = w.hid; g.lda = F; g.n0 = g.n1 = D;
+  g.out = w.y; g.ldo = D;
+  g.tile_tab = w.tile_tab; g.n_tiles_ptr = w.n_tiles; g.max_m_tiles = max_m_tiles; g.tile_rows = tile_rows;
+  g.expert_tab = expert_w_dev; g.w_sel0 = 1; g.w_sel1 = -1;
+  MI_TRY(hip_rc(launch_gemm(g, s), "moe w2 grouped gemm"));
+  return hip_rc(launch_moe_combine(out, residual, w.y, sel_idx, sel_w, w.row_of, T, D, k, s), "moe combine");
+}
+
 int mi_set_decode_engine(int enabled) {
   const int prev = engine_mode();
   g_engine_mode = enabled != 0;
@@ -325,6 +434,10 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
 }
 
 size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(device_cus()); }
+int mi_debug_set_engine_knobs(int thin, int depth) {
+  decode_engine_set_knobs(thin, depth);
+  return MI_OK;
+}
 int mi_debug_set_engine_trace(void* dev_buffer) {
   decode_engine_set_trace(dev_buffer);
   return MI_OK;

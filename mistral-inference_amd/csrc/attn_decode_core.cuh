@@ -71,18 +71,33 @@ __device__ __forceinline__ void reduce_slot(State<R>& st, const float (&qf)[R][8
   }
 }
 
-template <int R>
-__device__ __forceinline__ void merge_from(State<R>& s, int off) {
+// Value of lane (lane ^ 16) / (lane ^ 32): gfx950 permlane swaps (VALU rate) instead of ds_bpermute round trips.
+// v_permlane16_swap(v, v) returns {rows (0,0,2,2), rows (1,1,3,3)}; v_permlane32_swap(v, v) {halves (lo,lo), (hi,hi)}.
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v, bool upper) {
+  static_assert(OFF == 16 || OFF == 32, "cross-row exchange");
+  const uint32_t u = __float_as_uint(v);
+  if (OFF == 16) {
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(upper ? a[0] : a[1]);
+  }
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(upper ? a[0] : a[1]);
+}
+
+template <int R, int OFF>
+__device__ __forceinline__ void merge_from(State<R>& s, int lane) {
+  const bool upper = (lane & OFF) != 0;  // this lane sits in the odd row / upper half: its partner is the other one
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const float mo = __shfl_xor(s.m[r], off, 64);
-    const float lo = __shfl_xor(s.l[r], off, 64);
+    const float mo = lane_xor<OFF>(s.m[r], upper);
+    const float lo = lane_xor<OFF>(s.l[r], upper);
     const float M = fmaxf(s.m[r], mo);
     const float a1 = exp2f(s.m[r] - M), a2 = exp2f(mo - M);
     s.l[r] = fmaf(s.l[r], a1, __fmul_rn(lo, a2));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float ao = __shfl_xor(s.acc[r][i], off, 64);
+      const float ao = lane_xor<OFF>(s.acc[r][i], upper);
       s.acc[r][i] = fmaf(s.acc[r][i], a1, __fmul_rn(ao, a2));
     }
     s.m[r] = M;
@@ -93,8 +108,8 @@ __device__ __forceinline__ void merge_from(State<R>& s, int off) {
 // (FP: float* into __shared__ arrays, or an explicit address_space(3) pointer)
 template <int R, class FP>
 __device__ __forceinline__ void wave_state_to_lds(State<R>& st, int vw, int lane, FP sm_m, FP sm_l, FP sm_acc) {
-  merge_from<R>(st, 16);
-  merge_from<R>(st, 32);
+  merge_from<R, 16>(st, lane);
+  merge_from<R, 32>(st, lane);
   const int g = lane >> 4, dl = lane & 15;
   if (g == 0) {
 #pragma unroll

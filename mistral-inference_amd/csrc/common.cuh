@@ -44,17 +44,6 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 // different places during development (long prologue between issue and wait; AGPR shuffling at 256 registers; the
 // R = 2 decode-attention instance on rings wider than ~5000 slots) - silent, timing-dependent corruption.
 
-// Sum over the 64 lanes of a wave; every lane gets the total.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 // Sum over each aligned group of 16 lanes (a DPP "row"); every lane of the row gets the total.
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);  // row_ror:8
@@ -63,13 +52,42 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, true);  // row_ror:1
   return v;
 }
-
+// Sum over the 64 lanes of a wave; every lane gets the SAME total (lane 0's association order, broadcast).
+// 4 DPP row rotations, then the two cross-row steps as gfx950 permlane swaps (v_permlane16_swap: rows 0|1 and 2|3,
+// v_permlane32_swap: halves) - 8 VALU-rate instructions instead of six dependent ds_bpermute round trips.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true));  // row_ror:8
   v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, true));  // row_ror:4
   v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, true));  // row_ror:2
   v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, true));  // row_ror:1
   return v;
+}
+
+// rope.py:13-23 on one (even, odd) pair: complex multiply with INDIVIDUALLY ROUNDED products.  HIP's __fmul_rn /
+// __fsub_rn are plain operators, so under the default -ffp-contract=fast the compiler may or may not fuse
+// `y0 * c - y1 * s` into an FMA depending on the surrounding code - two kernels then disagree in the last bit on
+// near-cancelling pairs.  contract(off) pins the four products and the two sums everywhere this helper is inlined.
+__device__ __forceinline__ void rope_pair(float y0, float y1, float c, float s, float& re, float& im) {
+#pragma clang fp contract(off)
+  const float a = y0 * c;
+  const float b = y1 * s;
+  const float d = y0 * s;
+  const float e = y1 * c;
+  re = a - b;
+  im = d + e;
 }
 
 // Packed fp32 -> bf16 (RNE) in one instruction; gfx950 has no builtin for it (guide T12).

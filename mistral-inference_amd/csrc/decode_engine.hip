@@ -158,7 +158,7 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
 // ------------------------------------------------------------------------------------------------ loader wave
 struct Loader {
   const Shared& sh;
-  int lane, ring_fills;
+  int lane, ring_fills, thin, depth;
   uint32_t g = 0;    // pieces issued
   uint32_t pub = 0;  // fills published
   uint32_t stalls = 0;  // fills that had to wait for a free ring slot (trace only)
@@ -172,39 +172,69 @@ struct Loader {
       sh.ctl[C_LANDED] = fills;
     }
   }
-  __device__ __forceinline__ void piece(const void* src_lane) {
-    if ((g & (FILL - 1)) == 0) {
-      const uint32_t f = g / FILL;
-      if (f >= (uint32_t)ring_fills) {  // the slot's previous fill must have been consumed completely
-        const uint32_t need = (f - ring_fills + 1) * FILL;
-        if (min_done() < need) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          publish(f);  // everything issued has landed: consumers must not starve while we wait for them
-          ++stalls;
-          uint32_t spins = 0;
-          while (min_done() < need)
-            if (!spin_ok(sh, spins, 0x100)) break;
-        }
-      }
-    }
-    lchar* dst = sh.ring + (uint32_t)__builtin_amdgcn_readfirstlane((int)(g & sh.ring_mask)) * PIECE;  // wave-uniform (M0)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, 0, 2 /* nt */);
-    ++g;
-    if ((g & (FILL - 1)) == 0) {
-      const uint32_t f = g / FILL;  // fills issued so far
-      if (sh.ctl[C_GATHERING]) {      // thin the stream while this CU's consumers sweep granules (gather-pass row)
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        publish(f - 1);
-      } else {
-        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        if (f >= 2) publish(f - 2);
+  // Before the first piece of a fill: its ring slot must have been consumed completely.
+  __device__ __forceinline__ void fill_begin() {
+    const uint32_t f = g / FILL;
+    if (f >= (uint32_t)ring_fills) {
+      const uint32_t need = (f - ring_fills + 1) * FILL;
+      if (min_done() < need) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(f);  // everything issued has landed: consumers must not starve while we wait for them
+        ++stalls;
+        uint32_t spins = 0;
+        while (min_done() < need)
+          if (!spin_ok(sh, spins, 0x100)) break;
       }
     }
   }
+  // After the last piece of a fill: retire older fills (DMA completes in order; 16 instructions per fill).
+  __device__ __forceinline__ void fill_end() {
+    const uint32_t f = g / FILL;  // fills issued so far
+    if (thin && sh.ctl[C_GATHERING]) {  // thin the stream while this CU's consumers sweep granules (gather-pass row)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      publish(f - 1);
+    } else if (depth >= 3) {
+      asm volatile("s_waitcnt vmcnt(47)" ::: "memory");  // <= 3 fills in flight (the counter saturates at 63)
+      if (f >= 3) publish(f - 3);
+    } else {
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      if (f >= 2) publish(f - 2);
+    }
+  }
+  template <int OFF>
+  __device__ __forceinline__ void dma(const void* src_lane, lchar* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, OFF, 2 /* nt */);
+  }
+  __device__ __forceinline__ lchar* slot_of(uint32_t piece_idx) {  // wave-uniform (becomes M0)
+    return sh.ring + (uint32_t)__builtin_amdgcn_readfirstlane((int)(piece_idx & sh.ring_mask)) * PIECE;
+  }
+  __device__ __forceinline__ void piece(const void* src_lane) {
+    if ((g & (FILL - 1)) == 0) fill_begin();
+    dma<0>(src_lane, slot_of(g));
+    ++g;
+    if ((g & (FILL - 1)) == 0) fill_end();
+  }
+  // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: g % 4 == 0): one address, immediate offsets
+  __device__ __forceinline__ void piece4(const void* src_lane) {
+    if ((g & (FILL - 1)) == 0) fill_begin();
+    lchar* dst = slot_of(g);
+    dma<0>(src_lane, dst);
+    dma<PIECE>(src_lane, dst);
+    dma<2 * PIECE>(src_lane, dst);
+    dma<3 * PIECE>(src_lane, dst);
+    g += 4;
+    if ((g & (FILL - 1)) == 0) fill_end();
+  }
   __device__ __forceinline__ void rows(const bf16_t* base, size_t row0, int nrows, int K) {  // contiguous row slab
     const char* p = reinterpret_cast<const char*>(base + row0 * K) + lane * 16;
-    const int n = nrows * (K >> 9);
-    for (int i = 0; i < n; ++i) piece(p + (size_t)i * PIECE);
+    int n = nrows * (K >> 9);
+    while (n > 0 && (g & 3)) {  // align the group path
+      piece(p);
+      p += PIECE;
+      --n;
+    }
+    for (; n >= 4; n -= 4, p += 4 * PIECE) piece4(p);
+    for (; n > 0; --n, p += PIECE) piece(p);
   }
   __device__ __forceinline__ void flush() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -213,7 +243,8 @@ struct Loader {
 };
 
 __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
-  Loader ld{sh, lane, a.ring_fills};
+  Loader ld{sh, lane, a.ring_fills, a.thin, a.depth};
+  __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
   const int PD = a.D >> 9;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
@@ -288,32 +319,55 @@ struct Cons {
     asm volatile("" ::: "memory");
   }
 
-  // fp32 dot of one streamed weight row (P pieces starting at piece g0) with the activation vector in LDS: lane owns
-  // elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p, accumulated in ascending p - the launch path's order.
-  __device__ __forceinline__ float row_dot(uint32_t g0, int P, const lbf16* xs) {
-    float acc = 0.f;
-    for (int p0 = 0; p0 < P; p0 += 4) {
-      const int n = min(4, P - p0);
-      need_fill(g0 + p0 + n - 1);
-      u32x4 wv[4], xv[4];
+  // fp32 dots of NR consecutive streamed weight rows (P pieces each, the first at piece g0) with the activation vector
+  // in LDS.  Lane owns elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p and accumulates in ascending p -
+  // the launch path's order per row.  The NR rows advance in lockstep: NR independent FMA chains and one unpack of the
+  // activation piece per p (a single chain is latency-bound: 28 GB/s per CU measured, below the HBM stream).
+  template <int NR>
+  __device__ __forceinline__ void unit_dot(uint32_t g0, int P, const lbf16* xs, float (&out)[NR]) {
+    float acc[NR];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int jj = min(j, n - 1);
-        wv[j] = lds16(sh.ring + ((g0 + p0 + jj) & sh.ring_mask) * PIECE + lane * 16);
-        xv[j] = lds16(xs + ((p0 + jj) * 64 + lane) * 8);
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+    need_fill(g0 + NR * P - 1);
+    const lchar* xl = reinterpret_cast<const lchar*>(xs) + lane * 16;
+    const lchar* wl = sh.ring + lane * 16;
+    auto step = [&](const u32x4& xv, const u32x4 (&wv)[NR]) {
+      float xf[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[2 * i] = bf_lo(xv[i]);
+        xf[2 * i + 1] = bf_hi(xv[i]);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < n) {
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc = fmaf(bf_lo(wv[j][i]), bf_lo(xv[j][i]), acc);
-            acc = fmaf(bf_hi(wv[j][i]), bf_hi(xv[j][i]), acc);
-          }
+        for (int i = 0; i < 4; ++i) {
+          acc[r] = fmaf(bf_lo(wv[r][i]), xf[2 * i], acc[r]);
+          acc[r] = fmaf(bf_hi(wv[r][i]), xf[2 * i + 1], acc[r]);
         }
+    };
+    constexpr int G = (NR <= 2) ? 4 : 2;  // pieces per group: all LDS reads of a group are issued before its math
+    int p = 0;
+    for (; p + G <= P; p += G) {
+      u32x4 xv[G], wv[G][NR];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        xv[j] = lds16(xl + (p + j) * PIECE);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) wv[j][r] = lds16(wl + ((g0 + r * P + p + j) & sh.ring_mask) * PIECE);
       }
+#pragma unroll
+      for (int j = 0; j < G; ++j) step(xv[j], wv[j]);
     }
-    return wave_sum(acc);
+    for (; p < P; ++p) {
+      u32x4 wv[NR];
+      const u32x4 xv = lds16(xl + p * PIECE);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) wv[r] = lds16(wl + ((g0 + r * P + p) & sh.ring_mask) * PIECE);
+      step(xv, wv);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) out[r] = wave_sum(acc[r]);
   }
 
   __device__ __forceinline__ void publish(gu64* g, uint32_t tag, uint32_t value) {
@@ -321,9 +375,8 @@ struct Cons {
   }
 
   // All consumer waves: copy n granules (granule i lives at addr(i); its tag must match) into LDS words dst[0, n).
-  template <class AddrFn>
+  template <int NL, class AddrFn>
   __device__ __forceinline__ void gather_fn(int n, uint32_t tag, lu32* dst, AddrFn addr) {
-    constexpr int NL = 8;
     for (int k0 = 0; k0 * NCONS * 64 < n; k0 += NL) {
       unsigned long long x[NL];
       uint32_t spins = 0;
@@ -349,13 +402,24 @@ struct Cons {
       }
     }
   }
+  template <int NL = 8>
   __device__ __forceinline__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
-    gather_fn(n, tag, dst, [&](int i) { return src + i; });
+    gather_fn<NL>(n, tag, dst, [&](int i) { return src + i; });
   }
 
   // RMSNorm of the K-element bf16 vector in LDS, in place (transformer_layers.py:115-120), with the launch path's
   // reduction tree: 256 "threads" own 16-byte pieces vt + i * 256, per-piece sums, wave butterfly, 4 wave totals.
-  __device__ __forceinline__ void rmsnorm_inplace(lbf16* xs, int K, const bf16_t* norm_w, float eps) {
+  // The norm weights do not depend on the activations: norm_prefetch issues their loads BEFORE the hand-off sweep so
+  // that the global round trip is over when the vector arrives.
+  struct NormW {
+    u32x4 w[4];
+  };
+  __device__ __forceinline__ void norm_prefetch(NormW& nw, int K, const bf16_t* norm_w) {
+    const int vt = w * 64 + lane, npieces = K >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nw.w[i] = ld16(norm_w + (size_t)min(vt + i * 256, npieces - 1) * 8);
+  }
+  __device__ __forceinline__ void rmsnorm_inplace(lbf16* xs, int K, const NormW& nw, float eps) {
     const int vt = w * 64 + lane, npieces = K >> 3;
     u32x4 xr[4];
     float ss = 0.f;
@@ -384,11 +448,10 @@ struct Cons {
     for (int i = 0; i < 4; ++i) {
       const int q = vt + i * 256;
       if (q < npieces) {
-        const u32x4 wv = ld16(norm_w + (size_t)q * 8);
         u32x4 o;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
-          o[cc] = pack_bf2(bf_round(bf_lo(xr[i][cc]) * inv) * bf_lo(wv[cc]), bf_round(bf_hi(xr[i][cc]) * inv) * bf_hi(wv[cc]));
+          o[cc] = pack_bf2(bf_round(bf_lo(xr[i][cc]) * inv) * bf_lo(nw.w[i][cc]), bf_round(bf_hi(xr[i][cc]) * inv) * bf_hi(nw.w[i][cc]));
         lds_st16(xs + q * 8, o);
       }
     }
@@ -424,6 +487,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 0, trc);
 
     // ================================================================ attention_norm + q|k|v + RoPE + ring write
+    typename Cons::NormW nw;
+    cs.norm_prefetch(nw, a.D, L.an);
     if (l == 0 && a.first) {  // the step's input comes from global memory (embedding / previous stage / previous launch)
       const int vt = w * 64 + lane;
       for (int q = vt; q < (a.D >> 3); q += NCONS * 64) lds_st16(xs + q * 8, ld16(a.h + (size_t)q * 8));
@@ -436,26 +501,27 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       sh.ctl[C_GATHERING] = 0;
     }
     trace_ev(sh, c, l, 1, trc);
-    cs.rmsnorm_inplace(xs, a.D, L.an, a.eps);
+    cs.rmsnorm_inplace(xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 2, trc);
     {
       const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0, n_u = nq_u + 2 * nk_u;
       for (int k = w; k < n_u; k += NCONS) {
         const uint32_t ga = g + (uint32_t)(2 * k) * PD;
         cs.set_done(ga);
-        const float v0 = cs.row_dot(ga, PD, xs), v1 = cs.row_dot(ga + PD, PD, xs);
+        int kind, u;  // 0 q, 1 k, 2 v; u = global row pair inside that matrix
+        if (k < nq_u) { kind = 0; u = p.q0 + k; }
+        else if (k < nq_u + nk_u) { kind = 1; u = p.k0 + (k - nq_u); }
+        else { kind = 2; u = p.v0 + (k - nq_u - nk_u); }
+        const int r0 = 2 * u;
+        // the rotary entry is fetched BEFORE the dot products (an L2 round trip otherwise sits in every unit's tail)
+        const float2 cs2 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + ((r0 % DH) >> 1)) * 2);
+        float v[2];
+        cs.template unit_dot<2>(ga, PD, xs, v);
         if (lane == 0) {
-          float y0 = bf_round(v0), y1 = bf_round(v1);
-          int kind, u;  // 0 q, 1 k, 2 v; u = global row pair inside that matrix
-          if (k < nq_u) { kind = 0; u = p.q0 + k; }
-          else if (k < nq_u + nk_u) { kind = 1; u = p.k0 + (k - nq_u); }
-          else { kind = 2; u = p.v0 + (k - nq_u - nk_u); }
-          const int r0 = 2 * u;
+          float y0 = bf_round(v[0]), y1 = bf_round(v[1]);
           if (kind < 2) {  // rope.py:13-23 on the adjacent pair
-            const int i = (r0 % DH) >> 1;
-            const float2 cs2 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + i) * 2);
-            const float re = __fsub_rn(__fmul_rn(y0, cs2.x), __fmul_rn(y1, cs2.y));
-            const float im = __fadd_rn(__fmul_rn(y0, cs2.y), __fmul_rn(y1, cs2.x));
+            float re, im;
+            rope_pair(y0, y1, cs2.x, cs2.y, re, im);
             y0 = re;
             y1 = im;
           }
@@ -545,7 +611,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         const gu64* part = G + a.g_part;
         const size_t ml_base = (size_t)a.Hs * ns * R * DH;
         sh.ctl[C_GATHERING] = 1;
-        cs.gather_fn(3 * ns * ne, tp, cmb_lds, [&](int t) {
+        cs.gather_fn<8>(3 * ns * ne, tp, cmb_lds, [&](int t) {
           const int el = t % ne, sp = (t / ne) % ns, which = t / (ne * ns);
           const int e = 2 * p.e0 + el, hh = e / DH, d = e % DH, kvh = hh / R, r = hh % R;
           const size_t blk = (size_t)kvh * ns + sp;
@@ -559,8 +625,15 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           const lf32* ca = reinterpret_cast<const lf32*>(cmb_lds) + el;
           const lf32* cm = ca + ns * ne;
           const lf32* cl = cm + ns * ne;
-          const float o = combine_stream(ns, [&](int sp) { return cm[sp * ne]; }, [&](int sp) { return cl[sp * ne]; },
-                                         [&](int sp) { return ca[sp * ne]; });
+          float mm[32], ll[32], vv[32];  // all reads independent: one LDS round trip instead of a chain of 64
+#pragma unroll
+          for (int sp = 0; sp < 32; ++sp) {
+            const int s2 = min(sp, ns - 1) * ne;
+            mm[sp] = cm[s2];
+            ll[sp] = cl[s2];
+            vv[sp] = ca[s2];
+          }
+          const float o = combine_splits<32>(mm, ll, vv, ns);
           const float o_hi = __shfl_down(o, 1, 64);
           if (lane < ne && !(lane & 1)) cs.publish(G + a.g_att + p.e0 + lane / 2, tag_of(l, 3), pack_bf2(o, o_hi));
         }
@@ -580,7 +653,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       for (int k = w; k < n_u; k += NCONS) {
         const uint32_t ga = g + (uint32_t)(2 * k) * PA;
         cs.set_done(ga);
-        const float v0 = cs.row_dot(ga, PA, xs), v1 = cs.row_dot(ga + PA, PA, xs);
+        float vv[2];
+        cs.template unit_dot<2>(ga, PA, xs, vv);
+        const float v0 = vv[0], v1 = vv[1];
         if (lane == 0) {
           const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
           const uint32_t packed = pack_bf2(bf_lo(rs) + bf_round(v0), bf_hi(rs) + bf_round(v1));
@@ -594,21 +669,23 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 11, trc);
 
     // ================================================================ hid = silu(W1 x) * (W3 x), x = ffn_norm(h1)
+    cs.norm_prefetch(nw, a.D, L.fn);
     cs.cbar();
     sh.ctl[C_GATHERING] = 1;
     cs.gather(G + a.g_h1, a.D / 2, tag_of(l, 4), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
     trace_ev(sh, c, l, 12, trc);
-    cs.rmsnorm_inplace(xs, a.D, L.fn, a.eps);
+    cs.rmsnorm_inplace(xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
     {
       const int n_u = p.f1 - p.f0;
       for (int k = w; k < n_u; k += NCONS) {
         const uint32_t ga = g + (uint32_t)(4 * k) * PD;
         cs.set_done(ga);
-        const float a0 = cs.row_dot(ga, PD, xs), b0 = cs.row_dot(ga + PD, PD, xs);
-        const float a1 = cs.row_dot(ga + 2 * PD, PD, xs), b1 = cs.row_dot(ga + 3 * PD, PD, xs);
+        float vv[4];
+        cs.template unit_dot<4>(ga, PD, xs, vv);
+        const float a0 = vv[0], b0 = vv[1], a1 = vv[2], b1 = vv[3];
         if (lane == 0) {
           const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(a0, b0)) | ((uint32_t)f_to_bf(swiglu_bf(a1, b1)) << 16);
           cs.publish(G + a.g_hid + p.f0 + k, tag_of(l, 5), packed);
@@ -622,7 +699,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     // ================================================================ h = h1 + hid @ W2^T
     cs.cbar();
     sh.ctl[C_GATHERING] = 1;
-    cs.gather(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
+    cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
     trace_ev(sh, c, l, 15, trc);
@@ -632,7 +709,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       for (int k = w; k < n_u; k += NCONS) {
         const uint32_t ga = g + (uint32_t)(2 * k) * PF;
         cs.set_done(ga);
-        const float v0 = cs.row_dot(ga, PF, xs), v1 = cs.row_dot(ga + PF, PF, xs);
+        float vv[2];
+        cs.template unit_dot<2>(ga, PF, xs, vv);
+        const float v0 = vv[0], v1 = vv[1];
         if (lane == 0) {
           const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
           const uint32_t packed = pack_bf2(bf_lo(rs) + bf_round(v0), bf_hi(rs) + bf_round(v1));
@@ -651,17 +730,21 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
   // ================================================================ final norm + LM head (transformer.py:219,235,242)
   if (a.head) {
+    typename Cons::NormW nw;
+    cs.norm_prefetch(nw, a.D, a.final_norm);
     sh.ctl[C_GATHERING] = 1;
     cs.gather(G + a.g_h, a.D / 2, tag_of(a.n_layers - 1, 0), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
-    cs.rmsnorm_inplace(xs, a.D, a.final_norm, a.eps);
+    cs.rmsnorm_inplace(xs, a.D, nw, a.eps);
     int v0, v1;
     slab(a.V / 2, c, a.NB, v0, v1);
     for (int k = w; k < v1 - v0; k += NCONS) {
       const uint32_t ga = g + (uint32_t)(2 * k) * PD;
       cs.set_done(ga);
-      const float y0 = cs.row_dot(ga, PD, xs), y1 = cs.row_dot(ga + PD, PD, xs);
+      float vv[2];
+      cs.template unit_dot<2>(ga, PD, xs, vv);
+      const float y0 = vv[0], y1 = vv[1];
       if (lane == 0) {
         float2 o = make_float2(bf_round(y0), bf_round(y1));
         *reinterpret_cast<float2*>(a.logits + 2 * (size_t)(v0 + k)) = o;
@@ -760,6 +843,11 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
 
 namespace {
 uint64_t* g_trace = nullptr;
+int g_thin = -1, g_depth = -1;
+}
+void decode_engine_set_knobs(int thin, int depth) {
+  g_thin = thin;
+  g_depth = depth;
 }
 void decode_engine_set_trace(void* dev_buffer) { g_trace = (uint64_t*)dev_buffer; }
 size_t decode_engine_trace_bytes(int NB) { return (size_t)NB * ENG_MAXL * TR_EVENTS * sizeof(uint64_t); }
@@ -768,6 +856,16 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
   EngArgs a;
   memset(&a, 0, sizeof(a));
   a.trace = (unsigned long long*)g_trace;
+  if (g_thin < 0) {
+    const char* e = getenv("MI_ENGINE_THIN");
+    g_thin = e ? atoi(e) : 1;
+  }
+  if (g_depth < 0) {
+    const char* e = getenv("MI_ENGINE_DEPTH");
+    g_depth = e ? atoi(e) : 3;
+  }
+  a.thin = g_thin;
+  a.depth = g_depth;
   a.D = pr.D; a.H = pr.H; a.Hkv = pr.Hkv; a.F = pr.F; a.V = pr.V; a.eps = pr.eps; a.NB = pr.NB;
   const int Rtot = pr.H / pr.Hkv;
   a.R = attn_decode_group(Rtot);

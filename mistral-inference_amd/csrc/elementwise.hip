@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qkv, int ld, int T, i
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = bf_lo(v[i]), b = bf_hi(v[i]);
-    const float re = __fsub_rn(__fmul_rn(a, cc[i]), __fmul_rn(b, sn[i]));
-    const float im = __fadd_rn(__fmul_rn(a, sn[i]), __fmul_rn(b, cc[i]));
+    float re, im;
+    rope_pair(a, b, cc[i], sn[i], re, im);
     o[i] = pack_bf2(re, im);
   }
   st16(ptr, o);

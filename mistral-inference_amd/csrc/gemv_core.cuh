@@ -350,8 +350,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
             const int pos = ep_pos;
             if (r0 < a.n1) {  // q or k rows: rotate the adjacent pair (rope.py:13-23)
               const float2 cs = ep_cs;
-              const float re = __fsub_rn(__fmul_rn(y0, cs.x), __fmul_rn(y1, cs.y));
-              const float im = __fadd_rn(__fmul_rn(y0, cs.y), __fmul_rn(y1, cs.x));
+              float re, im;
+              rope_pair(y0, y1, cs.x, cs.y, re, im);
               y0 = re;
               y1 = im;
             }

@@ -188,6 +188,7 @@ struct EngArgs {
   int NB, ring_fills;
   int seq_base;           // global index of this launch's first layer (tag sequence)
   int first, head;
+  int thin, depth;        // loader knobs (A/B): thin the stream during hand-off sweeps; fills in flight (2 or 3)
   float eps;
   bf16_t* h;              // [D] residual stream, in (first layer) / out (last layer)
   const float* rope_cs;
@@ -225,4 +226,5 @@ size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW);
 bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len);
 hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s);
 void decode_engine_set_trace(void* dev_buffer);  // debug: nullptr disables
+void decode_engine_set_knobs(int thin, int depth);  // debug / tuning
 size_t decode_engine_trace_bytes(int NB);

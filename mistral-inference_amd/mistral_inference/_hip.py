@@ -74,12 +74,20 @@ _SIGS = {
     "mi_lm_head_logprobs_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mi_lm_head_logprobs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
+    "mi_qkv_rope_kvwrite": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp,
+                                      C.c_float, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "mi_moe_experts_decode": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_float,
+                                        _vp, _vp]),
+    "mi_moe_grouped_gemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_moe_grouped_gemm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                      C.c_size_t, _vp]),
     "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "mi_debug_engine_trace_bytes": (C.c_size_t, []),
     "mi_debug_set_engine_trace": (C.c_int, [_vp]),
+    "mi_debug_set_engine_knobs": (C.c_int, [C.c_int, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -250,6 +258,54 @@ def moe_router(x: torch.Tensor, gate: torch.Tensor, top_k: int, norm_w: Optional
     check(lib().mi_moe_router(dev_ptr(idx, torch.int32), dev_ptr(w, torch.float32), dev_ptr(x), x.stride(0), T, D,
                               dev_ptr(gate), E, top_k, dev_ptr(norm_w), float(eps), stream_ptr(x.device)), "mi_moe_router")
     return idx, w
+
+
+def qkv_rope_kvwrite(x: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, head_dim: int, rope_cs: torch.Tensor,
+                     tok_pos: torch.Tensor, norm_w: Optional[torch.Tensor] = None, eps: float = 0.0,
+                     cache_k: Optional[torch.Tensor] = None, cache_v: Optional[torch.Tensor] = None,
+                     tok_seq: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode-sized (T <= 8) fused [RMSNorm] + q|k|v projection + RoPE [+ ring write at tok_pos % W of row tok_seq]:
+    returns qkv [T, (H + 2 Hkv) * head_dim] (post-RoPE)."""
+    T, D = x.shape
+    nq, nkv = wq.shape[0], wk.shape[0]
+    assert wv.shape[0] == nkv and rope_cs.dtype == torch.float32 and rope_cs.is_contiguous() and tok_pos.dtype == torch.int32
+    out = torch.empty((T, nq + 2 * nkv), dtype=x.dtype, device=x.device)
+    W = cache_k.shape[1] if cache_k is not None else 0
+    check(lib().mi_qkv_rope_kvwrite(dev_ptr(out), out.stride(0), dev_ptr(x), x.stride(0), T, D, dev_ptr(wq), dev_ptr(wk),
+                                    dev_ptr(wv), nq // head_dim, nkv // head_dim, head_dim, dev_ptr(norm_w), float(eps),
+                                    dev_ptr(rope_cs, torch.float32), rope_cs.shape[0], dev_ptr(tok_pos, torch.int32),
+                                    dev_ptr(tok_seq, torch.int32), dev_ptr(cache_k), dev_ptr(cache_v), W,
+                                    stream_ptr(x.device)), "mi_qkv_rope_kvwrite")
+    return out
+
+
+def moe_experts(x: torch.Tensor, expert_tab: torch.Tensor, n_experts: int, hidden_dim: int, sel_idx: torch.Tensor,
+                sel_w: torch.Tensor, residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+                eps: float = 0.0) -> torch.Tensor:
+    """bf16(residual + sum over each token's picked experts (ascending id) of bf16(w * expert(x))) (reference moe.py:28-32 +
+    transformer_layers.py:168).  expert_tab: int64 device tensor [E, 3] of (w1, w2, w3) pointers; sel_idx/sel_w: the
+    router's output.  T <= 8 runs the two weight-streaming launches (mi_moe_experts_decode), larger T the token-grouped
+    MFMA GEMMs (mi_moe_grouped_gemm).  residual None: zeros (the bare MoeLayer.forward value)."""
+    T, D = x.shape
+    k = sel_idx.shape[1]
+    if residual is None:
+        residual = torch.zeros_like(x)
+    out = torch.empty_like(x)
+    L, st = lib(), stream_ptr(x.device)
+    if T <= GEMV_MAX_T:
+        hid = torch.empty((T * k, hidden_dim), dtype=x.dtype, device=x.device)
+        check(L.mi_moe_experts_decode(dev_ptr(out), dev_ptr(residual), dev_ptr(x), x.stride(0), T, D, hidden_dim,
+                                      expert_tab.data_ptr(), dev_ptr(sel_idx, torch.int32), dev_ptr(sel_w, torch.float32), k,
+                                      dev_ptr(norm_w), float(eps), dev_ptr(hid), st), "mi_moe_experts_decode")
+        return out
+    assert norm_w is None, "the grouped path takes already-normalised rows"
+    xc = x if x.is_contiguous() else x.contiguous()
+    need = L.mi_moe_grouped_gemm_scratch_bytes(T, D, hidden_dim, n_experts, k)
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    check(L.mi_moe_grouped_gemm(dev_ptr(out), dev_ptr(residual), dev_ptr(xc), D, T, D, hidden_dim, n_experts, k,
+                                expert_tab.data_ptr(), dev_ptr(sel_idx, torch.int32), dev_ptr(sel_w, torch.float32),
+                                scratch.data_ptr(), need, st), "mi_moe_grouped_gemm")
+    return out
 
 
 def set_decode_engine(enabled: bool) -> bool:

@@ -2,8 +2,9 @@
 
 Module-level forward (used when a block is driven layer by layer); `Transformer.forward_partial` runs the
 same kernels from the native layer-stack runner.  At decode sizes (<= 8 tokens) the router, the selected
-experts' gate/up GEMVs and the down-projection + weighted bf16 combine are three launches with no host
-sync; the reference needs `num_experts` `torch.where` syncs per layer (moe.py:30)."""
+experts' gate/up GEMVs and the down-projection + weighted bf16 combine are three launches; larger batches
+take the device-side expert sort + token-grouped GEMMs.  No torch compute and no host sync either way; the
+reference needs `num_experts` `torch.where` syncs per layer (moe.py:30)."""
 from typing import List
 
 import torch
@@ -21,26 +22,22 @@ class MoeLayer(nn.Module):
         self.gate = gate
         self.args = moe_args
 
-    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
-        """inputs [T, D] (already ffn-normalised) -> sum over the token's k experts of w * expert(inputs).
+    def _expert_table(self) -> torch.Tensor:
+        """int64 device tensor [E, 3] of the experts' (w1, w2, w3) weight pointers, rebuilt when a weight moved."""
+        ptrs = [p for ex in self.experts for p in (ex.w1.weight.data_ptr(), ex.w2.weight.data_ptr(), ex.w3.weight.data_ptr())]
+        if getattr(self, "_tab_ptrs", None) != ptrs:
+            self._tab_ptrs = ptrs
+            self._tab = torch.tensor(ptrs, dtype=torch.int64, device=self.gate.weight.device).view(-1, 3)
+        return self._tab
 
-        Router = one kernel (bf16 logits, top-k, fp32 softmax over the picks); the (token, slot) pairs are then grouped
-        by expert with one stable sort, each expert that received tokens runs its fused SwiGLU FFN on exactly those rows,
-        and the weighted outputs are added expert by expert in ascending id - the order in which the reference's loop
-        (moe.py:29-31) rounds its bf16 accumulator."""
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """inputs [T, D] (already ffn-normalised) -> sum over the token's k experts of w * expert(inputs), accumulated in
+        bf16 in ascending expert id (the order in which the reference's loop rounds, moe.py:29-31).
+
+        All device work is libmistral_hip: the router kernel (bf16 logits, top-k, fp32 softmax over the picks), then for
+        T <= 8 the selected experts' fused gate/up GEMV + the down-projection/combine kernel (`mi_moe_experts_decode`),
+        for larger T the on-device expert sort + ONE token-grouped MFMA GEMM launch per projection + ordered combine
+        (`mi_moe_grouped_gemm`).  No host synchronisation (the reference does one `torch.where` sync per expert)."""
         k = self.args.num_experts_per_tok
         idx, w = _hip.moe_router(inputs, self.gate.weight, k)          # [T, k] int32 / fp32 (bf16-valued)
-        flat_e = idx.flatten().long()
-        order = torch.argsort(flat_e, stable=True)                      # pairs grouped by expert, token order kept
-        counts = torch.bincount(flat_e, minlength=len(self.experts)).tolist()
-        tok_of = torch.div(order, k, rounding_mode="floor")
-        gate_w = w.flatten()[order].to(inputs.dtype)
-        out = torch.zeros_like(inputs)
-        start = 0
-        for e, n in enumerate(counts):
-            if n:
-                rows = tok_of[start:start + n]
-                y = self.experts[e](inputs.index_select(0, rows))
-                out.index_add_(0, rows, gate_w[start:start + n, None] * y)  # a token meets an expert at most once
-                start += n
-        return out
+        return _hip.moe_experts(inputs, self._expert_table(), len(self.experts), self.experts[0].w1.weight.shape[0], idx, w)

@@ -72,9 +72,13 @@ class Attention(nn.Module):
         T = x.shape[0]
         H, Hkv, Dh = self.n_heads, self.n_kv_heads, self.head_dim
         nq, nkv = H * Dh, Hkv * Dh
-        qkv = _hip.linear(x, (self.wq.weight, self.wk.weight, self.wv.weight), _hip.EPI_STORE)
         cs = torch.view_as_real(freqs_cis).contiguous()  # rows already gathered by position (transformer.py:199)
-        _hip.rope_inplace(qkv, H, Hkv, Dh, cs, torch.arange(T, dtype=torch.int32, device=x.device))
+        rows = torch.arange(T, dtype=torch.int32, device=x.device)
+        if T <= _hip.GEMV_MAX_T:  # decode-sized: projection + RoPE in the one weight-streaming launch
+            qkv = _hip.qkv_rope_kvwrite(x, self.wq.weight, self.wk.weight, self.wv.weight, Dh, cs, rows)
+        else:
+            qkv = _hip.linear(x, (self.wq.weight, self.wk.weight, self.wv.weight), _hip.EPI_STORE)
+            _hip.rope_inplace(qkv, H, Hkv, Dh, cs, rows)
         if cache is None:
             # reference quirk: the block never forwards `mask` (transformer_layers.py:165) -> unmasked
             out = _hip.attn_prefill(qkv, H, Hkv, Dh, None, None, T, None, None, 1, T, causal=False)

@@ -109,6 +109,41 @@ def test_engine_bit_equal_launch_path(name):
         assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
 
 
+def test_engine_summation_order_fingerprint():
+    """fp32 summation ORDER of the engine's row dots == the launch path's, made visible: with W[:, D/2:] = -W[:, :D/2]
+    and an input whose two halves are equal, every q/k/v output of layer 0 is mathematically zero - what is computed is
+    the rounding residue of the particular association order, a fingerprint of it that survives the bf16 rounding."""
+    p = dict(dim=4096, n_layers=1, head_dim=128, hidden_dim=1024, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+             vocab_size=512, sliding_window=64)
+    args = mo.OracleArgs(**p)
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.transformer import Transformer
+    w = mo.synth_weights(args, seed=21)
+    half = p["dim"] // 2
+    w["tok_embeddings.weight"][:, half:] = w["tok_embeddings.weight"][:, :half]
+    w["layers.0.attention_norm.weight"][half:] = w["layers.0.attention_norm.weight"][:half]
+    for n in ("wq", "wk", "wv"):
+        t = w[f"layers.0.attention.{n}.weight"]
+        t[:, half:] = -t[:, :half]
+    targs = TransformerArgs.from_dict(mo.params_json(args))
+    targs.max_batch_size = 1
+    with torch.device("meta"):
+        m = Transformer(targs)
+    m = m.to(BF).to_empty(device="cuda")
+    m.load_state_dict({k: v.cuda() for k, v in w.items()}, assign=True)
+    m.eval()
+    prompt_len, steps = 5, 6
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(4)).cuda()
+    _, ref_rings, _ = _run(m, ids, prompt_len, steps, engine=False)
+    _, got_rings, st = _run(m, ids, prompt_len, steps, engine=True)
+    assert st["status"] == 0
+    (k0, v0), (k1, v1) = ref_rings[0], got_rings[0]
+    dec_k, dec_v = k0[:, prompt_len:], v0[:, prompt_len:]           # rows written by the decode steps
+    assert float(dec_k.float().abs().max()) < 1e-3 and float(dec_v.float().abs().max()) < 1e-3   # residues, not signal
+    assert float((dec_v != 0).float().mean()) > 0.5                # ... and not trivially zero: the fingerprint is real
+    assert torch.equal(k0, k1) and torch.equal(v0, v1), (_where(k0, k1), _where(v0, v1))
+
+
 def test_engine_graph_replay_and_oracle():
     """hipGraph replay of engine steps (the epoch lives in device memory, so replays see fresh tags) == eager engine
     steps == launch path; and the whole thing against the CPU oracle."""

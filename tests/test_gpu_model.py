@@ -410,3 +410,36 @@ def test_module_level_moe_block_vs_oracle(tmp_path):
     assert int(clear.sum()) >= 0.7 * len(ids)
     ref = col[0].float()
     assert float((out[clear] - ref[clear]).abs().max()) <= 4e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["dense_bf16", "swa_bf16"])
+def test_module_level_decode_with_cache(name, tmp_path):
+    """The PUBLIC layer-by-layer route at decode (reference transformer.py:196-211 written out by a caller):
+    cache.get_input_metadata -> cache.get_view -> TransformerBlock.forward(h, freqs_cis[positions], view) -> norm ->
+    output, after a prefill through the runner.  Decode metadata comes from the cache's host mirror (the runner's
+    decode-prep kernel never ran for these views); rings, positions and logits must match the reference's stored decode
+    logits like the runner's do."""
+    from mistral_inference.cache import BufferCache
+    case = Case(name)
+    w = {k: v.to(BF) for k, v in mo.synth_weights(case.args, seed=case.meta["seed"], dtype=BF).items()}
+    m = _load(tmp_path, case.args, w)
+    a = m.args
+    lens = [len(p) for p in case.prompts]
+    B = len(lens)
+    cache = BufferCache(m.n_local_layers, a.max_batch_size, max(lens) + case.max_tokens, a.n_kv_heads, a.head_dim,
+                        a.sliding_window, device="cuda", dtype=BF)
+    cache.reset()
+    m.forward(torch.tensor(sum(case.prompts, []), device="cuda"), lens, cache)
+    toks = case.tokens()
+    for step in range(3):
+        nxt = torch.tensor([t[step] for t in toks], device="cuda")
+        md = cache.get_input_metadata([1] * B)
+        assert not md[0].prefill and md[0].positions.tolist() == [n + step for n in lens]
+        h = m.tok_embeddings.weight[nxt]
+        for li, blk in enumerate(m.layers.values()):
+            h = blk(h, m.freqs_cis[md[li].positions], cache.get_view(li, md[li]))
+        cache.update_seqlens([1] * B)
+        logits = torch.nn.functional.linear(m.norm(h), m.output.weight).float().cpu()
+        ref = case.t[f"decode_logits.{step}"]
+        assert float((logits - ref).abs().max()) <= LOGIT_ATOL, (step, float((logits - ref).abs().max()))
+    assert cache.kv_seqlens.tolist() == [n + 3 for n in lens]

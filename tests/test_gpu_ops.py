@@ -357,3 +357,98 @@ def test_moe_router(T):
             # accumulation-order noise may flip a bf16 rounding of a logit; require the same VALUES picked
             assert torch.allclose(got_logits, ref_logits, atol=2e-2), (t, idx[t], ti[t])
         assert torch.allclose(w[t], tw[t], atol=8e-3), (t, w[t], tw[t])
+
+
+# ------------------------------------------------------------------------------------------------
+# leaf entry points of the fused decode operators (SURVEY.md section 8b minimum export set)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T", [1, 3, 8])
+@pytest.mark.parametrize("H,Hkv,D", [(4, 2, 512), (32, 8, 4096), (8, 8, 1024)])
+def test_qkv_rope_kvwrite_leaf(T, H, Hkv, D):
+    """mi_qkv_rope_kvwrite = RMSNorm + q|k|v GEMV + RoPE + ring write vs the oracle's pieces (transformer_layers.py:66-70,
+    rope.py:13-23, cache.py:83-92).  Projections are compared to 1 bf16 ulp of the pre-rotation value (summation order),
+    the ring rows must be exactly the k/v columns of the returned activations."""
+    h = _hip()
+    Dh, W, B = 128, 24, T
+    x = rnd(T, D, seed=40, scale=2.0)
+    nw = (1 + 0.1 * torch.randn(D, generator=torch.Generator().manual_seed(41))).to(BF)
+    wq, wk, wv = (rnd(n, D, seed=42 + i, scale=D ** -0.5) for i, n in enumerate((H * Dh, Hkv * Dh, Hkv * Dh)))
+    cs = mo.rope_angles(Dh, 4000, 1e6)
+    pos = torch.randint(0, 4000, (T,), generator=torch.Generator().manual_seed(45), dtype=torch.int32)
+    seq = torch.arange(T, dtype=torch.int32).flip(0).contiguous()  # rows deliberately not in token order
+    ck = torch.zeros(B, W, Hkv, Dh, dtype=BF).cuda()
+    cv = torch.zeros_like(ck)
+    got = h.qkv_rope_kvwrite(x.cuda(), wq.cuda(), wk.cuda(), wv.cuda(), Dh, cs.cuda(), pos.cuda(), norm_w=nw.cuda(), eps=1e-5,
+                             cache_k=ck, cache_v=cv, tok_seq=seq.cuda()).cpu()
+    xn = mo.rms_norm(x, nw, 1e-5)
+    q = mo.apply_rope(F.linear(xn, wq).reshape(T, H, Dh), cs[pos.long()]).reshape(T, -1)
+    k = mo.apply_rope(F.linear(xn, wk).reshape(T, Hkv, Dh), cs[pos.long()]).reshape(T, -1)
+    v = F.linear(xn, wv)
+    ref = torch.cat([q, k, v], dim=1)
+    # a rotated pair mixes two projections: bound the error by 1.5 ulp of the larger member of the pair
+    mag = ref.float().abs().reshape(T, -1, 2).amax(-1, keepdim=True).expand(-1, -1, 2).reshape(T, -1)
+    err = (got.float() - ref.float()).abs()
+    assert bool((err <= 1.5 * torch.clamp(mag, min=1e-2) * 2.0 ** -7 + 1e-6).all()), float(err.max())
+    assert float((err > 0).float().mean()) < 0.2
+    for t in range(T):
+        slot = int(pos[t]) % W
+        assert torch.equal(ck[int(seq[t]), slot].cpu().reshape(-1), got[t, H * Dh:(H + Hkv) * Dh])
+        assert torch.equal(cv[int(seq[t]), slot].cpu().reshape(-1), got[t, (H + Hkv) * Dh:])
+    # without a cache and without the fused norm the same call is projection + RoPE only
+    got2 = h.qkv_rope_kvwrite(xn.cuda(), wq.cuda(), wk.cuda(), wv.cuda(), Dh, cs.cuda(), pos.cuda()).cpu()
+    assert float((got2.float() - ref.float()).abs().max()) <= float(err.max()) + 4e-2
+
+
+def _moe_case(T, D, Fh, E, k, seed):
+    x = rnd(T, D, seed=seed, scale=1.0)
+    gate = rnd(E, D, seed=seed + 1, scale=0.05)
+    experts = [(rnd(Fh, D, seed=seed + 10 + 3 * e, scale=D ** -0.5), rnd(D, Fh, seed=seed + 11 + 3 * e, scale=Fh ** -0.5),
+                rnd(Fh, D, seed=seed + 12 + 3 * e, scale=D ** -0.5)) for e in range(E)]
+    return x, gate, experts
+
+
+@pytest.mark.parametrize("T", [1, 2, 8, 9, 300])
+def test_moe_expert_leaves_vs_oracle(T):
+    """mi_moe_experts_decode (T <= 8) and mi_moe_grouped_gemm (T > 8) behind `_hip.moe_experts`, with and without a
+    residual, against oracle moe_ffn (moe.py:24-32).  Tokens whose k-th/(k+1)-th router logits tie within 2 ulp are
+    excluded (torch.topk's tie order is unspecified)."""
+    h = _hip()
+    D, Fh, E, k = 512, 1024, 8, 2
+    x, gate, experts = _moe_case(T, D, Fh, E, k, seed=60)
+    mo.ROUTER_TRACE = []
+    ref = mo.moe_ffn(x, gate, experts, k)
+    logits, mo.ROUTER_TRACE = mo.ROUTER_TRACE[0], None
+    srt = torch.sort(logits, dim=1, descending=True).values
+    clear = (srt[:, k - 1] - srt[:, k]) > 2 * srt[:, k - 1].abs().clamp(min=1e-3) * 2.0 ** -7
+    assert int(clear.sum()) >= max(1, int(0.7 * T))
+    dev = [tuple(w.cuda() for w in ex) for ex in experts]
+    tab = torch.tensor([[w.data_ptr() for w in ex] for ex in dev], dtype=torch.int64, device="cuda")
+    idx, w = h.moe_router(x.cuda(), gate.cuda(), k)
+    got = h.moe_experts(x.cuda(), tab, E, Fh, idx, w).cpu()
+    tol = 3e-2 * max(1.0, float(ref.float().abs().max()))
+    assert float((got.float() - ref.float())[clear].abs().max()) <= tol
+    res = rnd(T, D, seed=99, scale=2.0)
+    got_r = h.moe_experts(x.cuda(), tab, E, Fh, idx, w, residual=res.cuda()).cpu()
+    assert torch.equal(got_r[clear], (res + got)[clear])  # bf16(h + R): the block's residual add (transformer_layers.py:168)
+
+
+def test_moe_layer_module_uses_the_native_kernels():
+    """MoeLayer.forward holds no torch compute: its result equals the leaf call on the same router output."""
+    h = _hip()
+    from torch import nn
+    from mistral_inference.args import MoeArgs
+    from mistral_inference.moe import MoeLayer
+    from mistral_inference.transformer_layers import FeedForward
+    D, Fh, E, k = 512, 1024, 4, 2
+    x, gate, experts = _moe_case(5, D, Fh, E, k, seed=80)
+    layer = MoeLayer([FeedForward(D, Fh) for _ in range(E)], nn.Linear(D, E, bias=False), MoeArgs(num_experts=E, num_experts_per_tok=k))
+    layer = layer.to(BF).cuda()
+    with torch.no_grad():
+        layer.gate.weight.copy_(gate)
+        for ex, (w1, w2, w3) in zip(layer.experts, experts):
+            ex.w1.weight.copy_(w1)
+            ex.w2.weight.copy_(w2)
+            ex.w3.weight.copy_(w3)
+        out = layer(x.cuda()).cpu()
+    ref = mo.moe_ffn(x, gate, experts, k)
+    assert float((out.float() - ref.float()).abs().max()) <= 3e-2 * max(1.0, float(ref.float().abs().max()))
