@@ -28,6 +28,14 @@ __device__ __forceinline__ bf16_t f_to_bf(float f) { return (bf16_t)f_to_bf_bits
 __device__ __forceinline__ float bf_round(float f) { return __uint_as_float(f_to_bf_bits(f) << 16); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return f_to_bf_bits(lo) | (f_to_bf_bits(hi) << 16); }
 
+// acc + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs, fp32 accumulate: ONE v_dot2c_f32_bf16 instead of four unpacks and
+// two FMAs.  Every weight-streaming dot product (GEMV kernels and the persistent decode engine) goes through this helper
+// in the same element order, which is what keeps the two paths bit-identical.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+
 // 16-byte loads.  `nt` marks streamed-once data (weights at decode): MI355X_MICROARCH "nt-weights".
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) {

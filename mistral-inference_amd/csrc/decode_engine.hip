@@ -320,9 +320,9 @@ struct Cons {
   }
 
   // fp32 dots of NR consecutive streamed weight rows (P pieces each, the first at piece g0) with the activation vector
-  // in LDS.  Lane owns elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p and accumulates in ascending p -
-  // the launch path's order per row.  The NR rows advance in lockstep: NR independent FMA chains and one unpack of the
-  // activation piece per p (a single chain is latency-bound: 28 GB/s per CU measured, below the HBM stream).
+  // in LDS.  Lane owns elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p and accumulates them pairwise
+  // (dot2_bf16) in ascending order - the launch path's order per row.  The NR rows advance in lockstep: NR independent
+  // accumulation chains (a single chain is latency-bound: 28 GB/s per CU measured, below the HBM stream).
   template <int NR>
   __device__ __forceinline__ void unit_dot(uint32_t g0, int P, const lbf16* xs, float (&out)[NR]) {
     float acc[NR];
@@ -332,19 +332,10 @@ struct Cons {
     const lchar* xl = reinterpret_cast<const lchar*>(xs) + lane * 16;
     const lchar* wl = sh.ring + lane * 16;
     auto step = [&](const u32x4& xv, const u32x4 (&wv)[NR]) {
-      float xf[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xf[2 * i] = bf_lo(xv[i]);
-        xf[2 * i + 1] = bf_hi(xv[i]);
-      }
 #pragma unroll
       for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[r] = fmaf(bf_lo(wv[r][i]), xf[2 * i], acc[r]);
-          acc[r] = fmaf(bf_hi(wv[r][i]), xf[2 * i + 1], acc[r]);
-        }
+        for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(wv[r][i], xv[i], acc[r]);
     };
     constexpr int G = (NR <= 2) ? 4 : 2;  // pieces per group: all LDS reads of a group are issued before its math
     int p = 0;
@@ -547,9 +538,13 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       const int kv_real = p.kvh / a.kv_groups;
       const uint32_t tq = tag_of(l, 1);
       sh.ctl[C_GATHERING] = 1;
-      cs.gather(G + a.g_qkv + (size_t)p.kvh * R * 64, R * 64, tq, q_lds);
-      cs.gather(G + a.g_qkv + nq / 2 + (size_t)kv_real * 64, 64, tq, kn_lds);
-      cs.gather(G + a.g_qkv + nq / 2 + nkv / 2 + (size_t)kv_real * 64, 64, tq, vn_lds);
+      {  // q of the R query heads | this step's k row | v row of the kv head: ONE sweep (q_lds, kn_lds, vn_lds are contiguous)
+        const gu64* qg = G + a.g_qkv + (size_t)p.kvh * R * 64;
+        const gu64* kg = G + a.g_qkv + nq / 2 + (size_t)kv_real * 64;
+        const gu64* vg = kg + nkv / 2;
+        cs.template gather_fn<2>(R * 64 + 128, tq, q_lds,
+                                 [&](int i) { return i < R * 64 ? qg + i : (i < R * 64 + 64 ? kg + (i - R * 64) : vg + (i - R * 64 - 64)); });
+      }
       cs.cbar();
       sh.ctl[C_GATHERING] = 0;
       trace_ev(sh, c, l, 5, trc);

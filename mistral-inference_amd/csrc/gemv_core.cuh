@@ -41,28 +41,13 @@ __device__ __forceinline__ void fma_batch(const u32x4 (&buf)[BATCH], int c0, con
   for (int u = 0; u < U; ++u) {
     const int e = ((c0 + u) * 64 + lane) * 8;
     if (e < K) {
-      float a[8], b[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[2 * i] = bf_lo(buf[u][i]);
-        a[2 * i + 1] = bf_hi(buf[u][i]);
-        if (ROWS == 2) {
-          b[2 * i] = bf_lo(buf[U + u][i]);
-          b[2 * i + 1] = bf_hi(buf[U + u][i]);
-        }
-      }
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + e);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float x0 = bf_lo(xv[i]), x1 = bf_hi(xv[i]);
-          acc.v[0][t] = fmaf(a[2 * i], x0, acc.v[0][t]);
-          acc.v[0][t] = fmaf(a[2 * i + 1], x1, acc.v[0][t]);
-          if (ROWS == 2) {
-            acc.v[1][t] = fmaf(b[2 * i], x0, acc.v[1][t]);
-            acc.v[1][t] = fmaf(b[2 * i + 1], x1, acc.v[1][t]);
-          }
+          acc.v[0][t] = dot2_bf16(buf[u][i], xv[i], acc.v[0][t]);
+          if (ROWS == 2) acc.v[1][t] = dot2_bf16(buf[U + u][i], xv[i], acc.v[1][t]);
         }
       }
     }
