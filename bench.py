@@ -135,10 +135,37 @@ def dominant_kernel_roofline(model, iters: int) -> dict:
             "launches_timed": n}
 
 
+def reference_baseline(params: dict, ctx: int, steps: int = 6):
+    """The UNMODIFIED reference timed on this box's host cores (oracle/time_reference.py in a subprocess: the reference
+    shares the product's package name).  None where the reference source is absent (the GPU box)."""
+    import subprocess
+    ref = os.environ.get("MISTRAL_REFERENCE_SRC", "/root/reference/src")
+    if not os.path.isdir(os.path.join(ref, "mistral_inference")):
+        return None
+    p = {k: v for k, v in params.items()}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--params", json.dumps(p),
+                            "--ctx", str(ctx), "--steps", str(steps)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MISTRAL_REFERENCE_SRC=ref))
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:  # noqa: BLE001  (a baseline that cannot be taken is reported as absent, never as a number)
+        return None
+
+
 def cpu_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
-    """The oracle (CPU restatement of the reference, oracle/mistral_oracle.py) timed on this box's host cores on
-    a bounded sample: the same decode step at the same context but with 2 of the 32 layers (+ LM head), scaled
-    linearly in the layer count."""
+    """CPU baseline on this box's host cores, bounded sample (the same decode step at the same context with 2 of the
+    layers + LM head, scaled linearly in the layer count): the unmodified reference where its source is present
+    (`kind: "reference"`, with the oracle port's number alongside), else the oracle port (`kind: "port"`)."""
+    ref = reference_baseline(params, ctx, steps)
+    port = port_baseline(params, ctx, steps)
+    if ref is not None:
+        ref["port_value"] = port["value"]
+        return ref
+    return port
+
+
+def port_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
+    """The oracle (CPU restatement of the reference, oracle/mistral_oracle.py) timed the same way."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.nn.functional as F
     import mistral_oracle as mo
@@ -262,6 +289,15 @@ def main() -> None:
         dt, prefill_s = tmax.tolist()
 
 
+    from mistral_inference import _hip
+    engine = _hip.decode_engine_status(model._backend._workspace)
+    assert engine["status"] == 0 and engine["bad_id"] == 0, f"device-side error flags: {engine}"
+
+    def decode_launch_label() -> str:
+        # the engine counts its own launches in the workspace: that is how we know which path was timed
+        kind = "persistent decode engine (1 launch per token)" if engine["engine_launches"] > 0 else "6 launches per layer"
+        return kind + (", eager" if (opt.no_graph or world > 1) else ", hipGraph replay")
+
     def report() -> dict:
         ctx_len = T0 + Wm + K // 2
         step_bytes = decode_bytes_per_token(params, ctx_len)
@@ -274,8 +310,9 @@ def main() -> None:
             "config": {"workload": f"{model_name} dims, {params['n_layers']} layers, random-init bf16, "
                                    f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
                        "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
-                       "decode_launch": "eager" if (opt.no_graph or world > 1) else "hipGraph replay",
-                       "parallelism": "single GPU" if world == 1 else f"pp{world} (layer ranges, RCCL send/recv + logits broadcast)"},
+                       "decode_launch": decode_launch_label(),
+                       "parallelism": "single GPU" if world == 1 else
+                       f"pp{world} (layer ranges, {torch.distributed.get_backend()} send/recv + logits broadcast)"},
             "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                                   "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
             "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),

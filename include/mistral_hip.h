@@ -45,7 +45,9 @@ const char* mi_last_error_detail(void);
  * Leaf operators (each replaces one group of torch/xformers launches of the reference)
  * ---------------------------------------------------------------------------------------------- */
 
-/* transformer.py:193  h = tok_embeddings(input_ids).  out[T,D] = table[ids[t], :] */
+/* transformer.py:193  h = tok_embeddings(input_ids).  out[T,D] = table[ids[t], :].  ids must lie in [0, vocab): the
+ * reference raises IndexError otherwise, which a kernel cannot - this leaf reads row 0 / vocab-1 for such an id (callers
+ * validate; mi_forward additionally records the offending token index in the workspace, see mi_decode_engine_status). */
 int mi_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, mi_stream_t stream);
 
 /* transformer_layers.py:115-120 RMSNorm.forward: out = bf16(bf16(x_f32 * rsqrt(mean(x^2)+eps)) * w).
@@ -231,8 +233,12 @@ int mi_forward(const mi_model_t* model, const mi_batch_t* batch, mi_stream_t str
 int mi_set_decode_engine(int enabled);
 /* Copies the engine's control words out of a workspace and synchronises `stream` (a health check, NOT part of the hot
  * path): status[0] = step epoch, status[1] = 0 or the code of the first bounded wait that ever timed out
- * (0x100 loader / 0x200 ring / 0x300 consumer barrier / 0x400 hand-off sweep), status[2] = abort flag of the last step. */
-int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[4]);
+ * (0x100 loader / 0x200 ring / 0x300 consumer barrier / 0x400 hand-off sweep), status[2] = abort flag of the last step,
+ * status[3] = 0 or 1 + the index of a token whose id was outside [0, vocab) in some mi_forward call (sticky until the
+ * caller zeroes the word: the host raises the reference's IndexError from it), status[4] = launches completed by the
+ * engine since the workspace was zeroed (one per <= 32 layers of a decode step; unchanged when the launch path ran),
+ * status[5..7] reserved. */
+int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[8]);
 /* Debug timeline of the engine (scripts/engine_trace.py): while a zero-filled device buffer of
  * mi_debug_engine_trace_bytes() bytes is registered, consumer wave 0 and the loader wave of every workgroup stamp a
  * 100 MHz clock at each phase boundary of each layer: trace[cu][layer (32)][event (26)] uint64.  NULL unregisters. */

@@ -159,7 +159,7 @@ const char* mi_error_string(int code) {
 
 int mi_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, mi_stream_t stream) {
   if (!out || !table || !ids || T <= 0 || D <= 0 || D % 8) return fail(MI_ERR_ARG, "mi_embedding");
-  return hip_rc(launch_embedding(out, table, ids, T, D, vocab, (hipStream_t)stream), "embedding");
+  return hip_rc(launch_embedding(out, table, ids, T, D, vocab, nullptr, (hipStream_t)stream), "embedding");
 }
 
 int mi_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, mi_stream_t stream) {
@@ -427,9 +427,9 @@ int mi_set_decode_engine(int enabled) {
   return prev;
 }
 
-int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[4]) {
+int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[8]) {
   if (!workspace || !status) return fail(MI_ERR_ARG, "mi_decode_engine_status");
-  MI_TRY(hip_rc(hipMemcpyAsync(status, workspace, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "status copy"));
+  MI_TRY(hip_rc(hipMemcpyAsync(status, workspace, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "status copy"));
   return hip_rc(hipStreamSynchronize((hipStream_t)stream), "status sync");
 }
 
@@ -485,7 +485,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, engine_ctrl, s),
                     "decode_prep"));
     if (embed)
-      MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, s), "embedding"));
+      MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, engine_ctrl + 3, s), "embedding"));
   }
 
   // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch

@@ -13,6 +13,15 @@ namespace attn_core {
 
 constexpr int DH = 128;
 constexpr float LOG2E = 1.4426950408889634f;
+// Online softmax with a LAGGING reference maximum (cdna_hip_programming.md T13): a lane group rescales its sums only
+// when a score exceeds the reference by more than 2^RESCALE_T, so the common step has no rescale multiplies; the
+// triple (m, l, acc) stays self-consistent (p <= 2^RESCALE_T, far inside fp32 range) and every merge works on it as on
+// an exact maximum.
+constexpr float RESCALE_T = 8.0f;
+
+// 2^x as ONE v_exp_f32 (arguments are <= RESCALE_T; results below the normal range flush to zero, which is what a softmax
+// weight of 2^-127 is anyway).  The library routine spends ~5 more instructions on denormal range fix-ups.
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int R>
 struct State {
@@ -61,13 +70,19 @@ __device__ __forceinline__ void reduce_slot(State<R>& st, const float (&qf)[R][8
 #pragma unroll
     for (int i = 0; i < 8; ++i) d = fmaf(qf[r][i], kf[i], d);
     d = row16_sum(d);
-    const float mn = valid ? fmaxf(st.m[r], d) : st.m[r];
-    const float alpha = exp2f(st.m[r] - mn);
-    const float p = valid ? exp2f(d - mn) : 0.f;
-    st.m[r] = mn;
-    st.l[r] = fmaf(st.l[r], alpha, p);
+    const bool grow = valid && (d > st.m[r] + RESCALE_T);
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform branch: rare after a lane group's first slots
+      const float mn = grow ? d : st.m[r];
+      const float alpha = ex2(st.m[r] - mn);        // 1 for the lanes that keep their reference
+      st.l[r] *= alpha;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], __fmul_rn(st.acc[r][i], alpha));
+      for (int i = 0; i < 8; ++i) st.acc[r][i] *= alpha;
+      st.m[r] = mn;
+    }
+    const float p = valid ? ex2(d - st.m[r]) : 0.f;
+    st.l[r] += p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i]);
   }
 }
 
@@ -93,7 +108,7 @@ __device__ __forceinline__ void merge_from(State<R>& s, int lane) {
     const float mo = lane_xor<OFF>(s.m[r], upper);
     const float lo = lane_xor<OFF>(s.l[r], upper);
     const float M = fmaxf(s.m[r], mo);
-    const float a1 = exp2f(s.m[r] - M), a2 = exp2f(mo - M);
+    const float a1 = ex2(s.m[r] - M), a2 = ex2(mo - M);
     s.l[r] = fmaf(s.l[r], a1, __fmul_rn(lo, a2));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -133,7 +148,7 @@ __device__ __forceinline__ void split_partial(int idx, FP sm_m, FP sm_l, FP sm_a
   A = 0.f;
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    const float e = exp2f(sm_m[w * R + r] - M);
+    const float e = ex2(sm_m[w * R + r] - M);
     L = fmaf(sm_l[w * R + r], e, L);
     A = fmaf(sm_acc[(w * R + r) * DH + d], e, A);
   }
@@ -148,7 +163,7 @@ __device__ __forceinline__ float combine_splits(const float (&m)[NS], const floa
   float L = 0.f, A = 0.f;
 #pragma unroll
   for (int sp = 0; sp < NS; ++sp) {
-    const float e = exp2f(((sp < n) ? m[sp] : -1e30f) - M);
+    const float e = ex2(((sp < n) ? m[sp] : -1e30f) - M);
     L = fmaf((sp < n) ? l[sp] : 0.f, e, L);
     A = fmaf((sp < n) ? v[sp] : 0.f, e, A);
   }
@@ -163,7 +178,7 @@ __device__ __forceinline__ float combine_stream(int n, FM m, FL l, FV v) {
   for (int sp = 0; sp < n; ++sp) M = fmaxf(M, m(sp));
   float L = 0.f, A = 0.f;
   for (int sp = 0; sp < n; ++sp) {
-    const float e = exp2f(m(sp) - M);
+    const float e = ex2(m(sp) - M);
     L = fmaf(l(sp), e, L);
     A = fmaf(v(sp), e, A);
   }

@@ -314,12 +314,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
 
 template <int NW>
 static hipError_t launch_nw(const AttnPrefillArgs& a, hipStream_t s) {
-  static bool attr_set = false;  // 2 x 33 KiB of dynamic LDS: above the 64 KiB default limit
-  if (!attr_set) {
+  // 2 x 33 KiB of dynamic LDS: above the 64 KiB default limit.  The opt-in is per function AND per device.
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   constexpr int QB = NW * 32;
   dim3 grid(((a.max_q_len + QB - 1) / QB) * a.H, a.causal ? a.B : 1), block(NW * 64);

@@ -84,7 +84,7 @@ struct Shared {
   lchar* xs;    // activation vector / attention scratch
   lchar* ring;
   uint32_t ring_mask;  // ring pieces - 1
-  gu32* ctrl;          // [0] epoch, [1] sticky status, [2] per-step abort broadcast
+  gu32* ctrl;          // [0] epoch, [1] sticky status, [2] per-step abort broadcast, [3] bad token id, [4] engine launches
   gu64* trace;         // optional timeline buffer
 };
 
@@ -694,7 +694,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     // ================================================================ h = h1 + hid @ W2^T
     cs.cbar();
     sh.ctl[C_GATHERING] = 1;
-    cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
+    cs.gather<28>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
     trace_ev(sh, c, l, 15, trc);
@@ -773,6 +773,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const uint32_t epoch = __hip_atomic_load(sh.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffffu;
   if (w == NCONS) run_loader(a, sh, c, lane, pos, seq);
   else run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch);
+  // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
+  if (c == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(sh.ctrl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace

@@ -5,11 +5,21 @@
 namespace {
 
 // transformer.py:193
+// An id outside [0, vocab) makes nn.Embedding raise (reference transformer.py:193).  A kernel cannot raise: it records
+// 1 + the token index in *bad_id (when given), reads row 0 / vocab-1 instead of faulting, and the host turns the flag
+// into the IndexError at its next synchronisation point (ids that live on the host are checked before the launch).
+__device__ __forceinline__ long checked_id(long id, int vocab, int t, uint32_t* bad_id) {
+  if (id < 0 || id >= vocab) {
+    if (bad_id && threadIdx.x == 0) atomicMax(bad_id, (uint32_t)t + 1u);
+    id = id < 0 ? 0 : vocab - 1;
+  }
+  return id;
+}
+
 __global__ __launch_bounds__(256) void embedding_kernel(bf16_t* out, const bf16_t* table, const int64_t* ids, int D,
-                                                        int vocab) {
+                                                        int vocab, uint32_t* bad_id) {
   const int t = blockIdx.x;
-  long id = ids[t];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // torch would raise; clamp instead of faulting
+  const long id = checked_id(ids[t], vocab, t, bad_id);
   const bf16_t* src = table + (size_t)id * D;
   bf16_t* dst = out + (size_t)t * D;
   for (int p = threadIdx.x; p < (D >> 3); p += 256) st16(dst + p * 8, ld16(src + p * 8));
@@ -141,8 +151,7 @@ __global__ __launch_bounds__(256) void decode_prep_embedding_kernel(int64_t* kv_
     kv_seqlens[t] = p + 1;
     if (t == 0) q_start[B] = B;
   }
-  long id = ids[t];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const long id = checked_id(ids[t], vocab, t, engine_ctrl ? engine_ctrl + 3 : nullptr);
   const bf16_t* src = table + (size_t)id * D;
   bf16_t* dst = out + (size_t)t * D;
   for (int p = threadIdx.x; p < (D >> 3); p += 256) st16(dst + p * 8, ld16(src + p * 8));
@@ -368,8 +377,9 @@ hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s) {
-  hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)table, ids, D, vocab);
+hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, uint32_t* bad_id,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)table, ids, D, vocab, bad_id);
   return hipGetLastError();
 }
 hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s) {

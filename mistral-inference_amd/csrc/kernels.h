@@ -144,14 +144,16 @@ hipError_t launch_gelu(void* x, int ldx, int T, int N, hipStream_t s);
 // log-softmax gather: out[m] = x_t - logsumexp(row m), from per-tile (max, sum-exp) partials or from a full logits row
 hipError_t launch_logprob_finalize(float* out, const float2* partial, const float* tgt, int M, int n_tiles, hipStream_t s);
 hipError_t launch_logprob_rows(float* out, const float* logits, int ld, const int32_t* target, int M, int V, hipStream_t s);
-hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, hipStream_t s);
+// bad_id (nullable): receives 1 + the index of an out-of-range token id (atomic max); such ids read row 0 / vocab-1
+hipError_t launch_embedding(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, uint32_t* bad_id,
+                            hipStream_t s);
 hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s);
 hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const float* rope_cs, const int32_t* tok_pos,
                        hipStream_t s);
 hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
                            const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s);
-// engine_ctrl (nullable): control words of the persistent decode engine - [0] step epoch (incremented here), [2] the
-// per-step abort broadcast (cleared here)
+// engine_ctrl (nullable): control words of the workspace - [0] step epoch of the persistent decode engine (incremented
+// here), [2] its per-step abort broadcast (cleared here), [3] out-of-range token id flag (launch_embedding)
 hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
                               int32_t* tok_pos, int B, uint32_t* engine_ctrl, hipStream_t s);
 hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,

@@ -138,8 +138,15 @@ def dev_ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = torch.bflo
 # ------------------------------------------------------------------------------------------------
 # leaf operator wrappers (torch tensors in, torch tensors out; all work done by the library)
 # ------------------------------------------------------------------------------------------------
+def check_ids_on_host(ids: torch.Tensor, vocab: int) -> None:
+    """nn.Embedding's IndexError for ids the host can see without a device synchronisation."""
+    if ids.device.type == "cpu" and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= vocab):
+        raise IndexError("index out of range in self")
+
+
 def embedding(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     T, (V, D) = ids.numel(), table.shape
+    check_ids_on_host(ids, V)
     out = torch.empty((T, D), dtype=table.dtype, device=table.device)
     ids = ids.to(device=table.device, dtype=torch.long).contiguous()
     check(lib().mi_embedding(dev_ptr(out), dev_ptr(table), dev_ptr(ids, torch.long), T, D, V, stream_ptr(table.device)),
@@ -315,9 +322,9 @@ def set_decode_engine(enabled: bool) -> bool:
 
 def decode_engine_status(workspace: torch.Tensor) -> dict:
     """Control words of the persistent decode engine in `workspace` (synchronises the current stream)."""
-    st = (C.c_uint32 * 4)()
+    st = (C.c_uint32 * 8)()
     check(lib().mi_decode_engine_status(workspace.data_ptr(), stream_ptr(workspace.device), st), "mi_decode_engine_status")
-    return {"epoch": int(st[0]), "status": int(st[1]), "abort": int(st[2])}
+    return {"epoch": int(st[0]), "status": int(st[1]), "abort": int(st[2]), "bad_id": int(st[3]), "engine_launches": int(st[4])}
 
 
 def ptr_array(ptrs: List[Optional[int]]):

@@ -144,6 +144,11 @@ def generate(
             logprobs[b].extend(lp[b])
     else:
         generated_tokens = []
+    # the copies above synchronised the stream: the place to turn device-side flags (an out-of-range token id seen by the
+    # embedding kernel, a timed-out wait of the decode engine) into the exceptions the reference would have raised
+    backend = getattr(model, "_backend", None)
+    if hasattr(backend, "raise_if_flagged"):
+        backend.raise_if_flagged()
     return generated_tokens, logprobs
 
 

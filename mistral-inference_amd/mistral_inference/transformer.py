@@ -113,6 +113,19 @@ class HipStackBackend:
         self._plan = None
         self._workspace = None
 
+    def raise_if_flagged(self) -> None:
+        """Health check at a point where the caller synchronises anyway (end of generate()): an out-of-range token id
+        seen by the embedding kernel becomes the reference's IndexError, a timed-out wait of the decode engine a
+        RuntimeError."""
+        if self._workspace is None:
+            return
+        st = _hip.decode_engine_status(self._workspace)
+        if st["bad_id"]:
+            self._workspace[12:16].zero_()
+            raise IndexError(f"index out of range in self (token {st['bad_id'] - 1} of a forward call)")
+        if st["status"]:
+            raise RuntimeError(f"persistent decode engine: bounded wait 0x{st['status']:x} timed out (workspace poisoned)")
+
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
         need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
         ws = self._workspace
@@ -267,6 +280,8 @@ class Transformer(ModelBase):
             f"Max batch size is {self.args.max_batch_size}, got batch size of {len(seqlens)}")
         (num_toks,) = input_ids.shape
         assert sum(seqlens) == num_toks, (sum(seqlens), num_toks)
+        if self.pipeline_rank == 0:
+            _hip.check_ids_on_host(input_ids, self.vocab_size)  # device-resident ids: flagged by the embedding kernel
         meta = cache.batch_metadata(seqlens) if cache is not None else self._nocache_metadata(seqlens)
         # the kernels index the rotary table by position without a bound check (the reference's gather would raise)
         top = max((p + s for p, s in zip(cache._seen, seqlens)), default=0) if cache is not None else max(seqlens)
