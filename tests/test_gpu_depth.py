@@ -1,0 +1,183 @@
+"""Parity AT DEPTH: the full 32-layer BASELINE configs[1] model (Mistral-7B-v0.3 dims, random init) against the CPU oracle
+in bf16 AND against an fp32 run of the oracle on the same (bf16-representable) weights.
+
+SURVEY.md section 7 asks for three numbers, because a max-abs tolerance between two bf16 implementations means nothing
+without knowing how far bf16 itself sits from the fp32 answer:
+
+    e_hip = max |HIP - oracle_fp32|      e_o16 = max |oracle_bf16 - oracle_fp32|      d = max |HIP - oracle_bf16|
+
+The assertion is relative: the HIP path may not be further from the fp32 truth than the reference's own bf16 arithmetic
+is (x 1.25 on the maximum, x 1.1 on the mean), at 32 layers, on a 256-token prompt plus 8 teacher-forced decode steps
+(the batch-1 decode steps run on the persistent decode engine), once with the BASELINE window (4096) and once with
+sliding_window = 128 so that the ring wraps inside the prompt and keeps wrapping during decode.
+
+The oracle runs LAYER-MAJOR (a 32-stage pipeline of one-layer OracleModels, the reference's own pipeline contract,
+transformer.py:94-98): weights are generated per layer on the host, copied into the HIP model, used by the four oracle
+passes (2 windows x 2 dtypes) and dropped - 7.2 G parameters never sit in host memory at once.
+"""
+import math
+import time
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mistral_oracle as mo
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+P7B = dict(dim=4096, n_layers=32, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+           vocab_size=32768, rope_theta=1e6)
+PROMPT, STEPS = 256, 8
+
+
+def _lin(o, i, g):
+    return ((torch.rand(o, i, generator=g) * 2 - 1) / math.sqrt(i)).to(BF)
+
+
+def _layer_weights(l, p, g):
+    D, Fh, nq, nkv = p["dim"], p["hidden_dim"], p["n_heads"] * p["head_dim"], p["n_kv_heads"] * p["head_dim"]
+    pre = f"layers.{l}."
+    return {
+        pre + "attention.wq.weight": _lin(nq, D, g), pre + "attention.wk.weight": _lin(nkv, D, g),
+        pre + "attention.wv.weight": _lin(nkv, D, g), pre + "attention.wo.weight": _lin(D, nq, g),
+        pre + "attention_norm.weight": (1 + 0.1 * torch.randn(D, generator=g)).to(BF),
+        pre + "ffn_norm.weight": (1 + 0.1 * torch.randn(D, generator=g)).to(BF),
+        pre + "feed_forward.w1.weight": _lin(Fh, D, g), pre + "feed_forward.w2.weight": _lin(D, Fh, g),
+        pre + "feed_forward.w3.weight": _lin(Fh, D, g),
+    }
+
+
+def test_32_layers_vs_bf16_and_fp32_oracle():
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    p = dict(P7B)
+    L, V, D = p["n_layers"], p["vocab_size"], p["dim"]
+    oargs = mo.OracleArgs.from_params(p)
+    ta = TransformerArgs.from_dict(p)
+    ta.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(ta)
+    model = model.to(BF).to_empty(device="cuda").eval()
+    sd = dict(model.named_parameters())
+    g = torch.Generator().manual_seed(1234)
+    emb = torch.randn(V, D, generator=g).to(BF)
+    final_norm = (1 + 0.1 * torch.randn(D, generator=g)).to(BF)
+    out_w = _lin(V, D, g)
+    with torch.no_grad():
+        sd["tok_embeddings.weight"].copy_(emb)
+        sd["norm.weight"].copy_(final_norm)
+        sd["output.weight"].copy_(out_w)
+    ids = torch.randint(0, V, (PROMPT + STEPS,), generator=torch.Generator().manual_seed(5))
+    windows = {"w4096": None, "w128": 128}
+    dtypes = {"bf16": BF, "fp32": torch.float32}
+    # activations flowing between the one-layer pipeline stages: [variant][dtype] -> (prefill h, [decode h])
+    acts = {v: {d: (None, [None] * STEPS) for d in dtypes} for v in windows}
+    t0 = time.time()
+    for l in range(L):
+        w = _layer_weights(l, p, g)
+        with torch.no_grad():
+            for k, t in w.items():
+                sd[k].copy_(t)
+        extra = {}
+        if l == 0:
+            extra["tok_embeddings.weight"] = emb
+        if l == L - 1:
+            extra["norm.weight"] = final_norm
+        for dn, dt in dtypes.items():
+            wl = {k: t.to(dt) for k, t in {**w, **extra}.items()}
+            om = mo.OracleModel(oargs, wl, pipeline_rank=l, num_pipeline_ranks=L)
+            for vn, win in windows.items():
+                oc = mo.OracleCache(1, 1, PROMPT + STEPS + 2, p["n_kv_heads"], p["head_dim"], win, dtype=dt)
+                h_pre, h_dec = acts[vn][dn]
+                h_pre = om.forward_partial(ids[:PROMPT], [PROMPT], oc, h_in=h_pre)
+                h_dec = [om.forward_partial(ids[PROMPT + s:PROMPT + s + 1], [1], oc, h_in=h_dec[s]) for s in range(STEPS)]
+                acts[vn][dn] = (h_pre, h_dec)
+        del w
+    oracle_s = time.time() - t0
+    model._weights_changed()
+
+    report = {}
+    for vn, win in windows.items():
+        cache = BufferCache(L, 1, PROMPT + STEPS + 2, p["n_kv_heads"], p["head_dim"], win, device="cuda", dtype=BF)
+        cache.reset()
+        with torch.inference_mode():
+            hip = [model.forward(ids[:PROMPT].cuda(), [PROMPT], cache).cpu()]
+            hip += [model.forward(ids[PROMPT + s:PROMPT + s + 1].cuda(), [1], cache).cpu() for s in range(STEPS)]
+        hip = torch.cat(hip)                                              # [PROMPT + STEPS, V] fp32
+        ref = {}
+        for dn, dt in dtypes.items():
+            h_pre, h_dec = acts[vn][dn]                                   # already RMS-normalised by the last stage
+            ref[dn] = F.linear(torch.cat([h_pre] + h_dec), out_w.to(dt)).float()
+        e_hip = (hip - ref["fp32"]).abs()
+        e_o16 = (ref["bf16"] - ref["fp32"]).abs()
+        d = (hip - ref["bf16"]).abs()
+        report[vn] = dict(e_hip_max=float(e_hip.max()), e_o16_max=float(e_o16.max()), d_max=float(d.max()),
+                          e_hip_mean=float(e_hip.mean()), e_o16_mean=float(e_o16.mean()), d_mean=float(d.mean()),
+                          logit_absmax=float(ref["fp32"].abs().max()),
+                          argmax_agree_hip=float((hip.argmax(1) == ref["fp32"].argmax(1)).float().mean()),
+                          argmax_agree_o16=float((ref["bf16"].argmax(1) == ref["fp32"].argmax(1)).float().mean()))
+    print(f"\n32-layer parity (oracle passes took {oracle_s:.0f} s on the host):")
+    for vn, r in report.items():
+        print(f"  {vn}: max|HIP-fp32| {r['e_hip_max']:.4f}  max|oracle_bf16-fp32| {r['e_o16_max']:.4f}  max|HIP-oracle_bf16| "
+              f"{r['d_max']:.4f}   means {r['e_hip_mean']:.5f} / {r['e_o16_mean']:.5f} / {r['d_mean']:.5f}   |logit|max "
+              f"{r['logit_absmax']:.2f}   argmax agreement with fp32: HIP {r['argmax_agree_hip']:.3f}, oracle_bf16 {r['argmax_agree_o16']:.3f}")
+    from mistral_inference import _hip
+    st = _hip.decode_engine_status(model._backend._workspace)
+    assert st["engine_launches"] >= 2 * STEPS and st["status"] == 0, st   # the decode steps ran on the persistent engine
+    for vn, r in report.items():
+        assert r["e_hip_max"] <= 1.25 * r["e_o16_max"], (vn, r)
+        assert r["e_hip_mean"] <= 1.10 * r["e_o16_mean"], (vn, r)
+        assert r["argmax_agree_hip"] >= r["argmax_agree_o16"] - 0.02, (vn, r)
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_mixtral_8x7b_dims_one_layer_vs_oracle():
+    """BASELINE.json configs[3] shapes (dim 4096, 32 q heads over 8 kv heads, hidden 14336, 8 experts top-2), ONE layer
+    (2.9 GB), small vocabulary: prefill logits of a 48-token prompt and 4 teacher-forced decode steps against the bf16
+    oracle; tokens whose router pick is a near-tie (bf16 logits within 2 ulp) are excluded, as for the 8x22B shapes."""
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    p = dict(dim=4096, n_layers=1, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+             vocab_size=2048, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2))
+    ta = TransformerArgs.from_dict(p)
+    ta.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(ta)
+    model = model.to(BF).to_empty(device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(17)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith("norm.weight"):
+                prm.copy_(1.0 + 0.1 * torch.randn(prm.shape, generator=g, device="cuda"))
+            elif name.startswith("tok_embeddings"):
+                prm.copy_(torch.randn(prm.shape, generator=g, device="cuda"))
+            else:
+                prm.copy_((torch.rand(prm.shape, generator=g, device="cuda") * 2 - 1) / prm.shape[1] ** 0.5)
+    model._weights_changed()
+    model.eval()
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oargs = mo.OracleArgs.from_params(p)
+    T, steps = 48, 4
+    ids = torch.randint(0, 2048, (T + steps,), generator=torch.Generator().manual_seed(18))
+    cache = BufferCache(1, 1, T + steps + 2, 8, 128, None, device="cuda", dtype=BF)
+    cache.reset()
+    got = [model.forward(ids[:T].cuda(), [T], cache).cpu()]
+    got += [model.forward(ids[T + i:T + i + 1].cuda(), [1], cache).cpu() for i in range(steps)]
+    om = mo.OracleModel(oargs, w)
+    oc = mo.OracleCache(1, 1, T + steps + 2, 8, 128, None, dtype=BF)
+    mo.ROUTER_TRACE = []
+    ref = [om.forward(ids[:T], [T], oc)] + [om.forward(ids[T + i:T + i + 1], [1], oc) for i in range(steps)]
+    trace, mo.ROUTER_TRACE = mo.ROUTER_TRACE, None
+    kept = 0
+    for gl, rl, lg in zip(got, ref, trace):
+        srt = torch.sort(lg, dim=1, descending=True).values
+        clear = (srt[:, 1] - srt[:, 2]) > 2 * srt[:, 1].abs().clamp(min=1e-3) * 2.0 ** -7
+        kept += int(clear.sum())
+        if clear.any():
+            assert float((gl[clear] - rl[clear]).abs().max()) <= 4e-2
+    assert kept >= 0.8 * (T + steps)

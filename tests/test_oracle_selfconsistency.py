@@ -49,3 +49,27 @@ def test_sliding_window_and_moe_selfconsistency():
             assert gen == []
             for a, b in zip(lp_old, lp_new):
                 assert all(abs(x - y) < 5e-4 for x, y in zip(a, b)), (over, chunk)
+
+
+def test_layer_major_pipeline_of_one_layer_oracles_equals_whole_model():
+    """The harness of tests/test_gpu_depth.py: an L-stage pipeline of one-layer OracleModels run LAYER-MAJOR (all
+    forwards of stage l before stage l + 1, each stage with its own one-layer cache) gives exactly the whole model's
+    logits - teacher-forced schedules make the stages independent of each other's timing."""
+    import torch.nn.functional as F
+    args = mo.OracleArgs(dim=256, n_layers=3, head_dim=128, hidden_dim=512, n_heads=4, n_kv_heads=2, norm_eps=1e-5,
+                         vocab_size=300, sliding_window=6)
+    w = mo.synth_weights(args, seed=3, dtype=torch.float32)
+    ids = torch.randint(0, 300, (14,), generator=torch.Generator().manual_seed(1))
+    P, S = 10, 4
+    whole = mo.OracleModel(args, w)
+    oc = mo.OracleCache(3, 1, 20, 2, 128, 6)
+    ref = [whole.forward(ids[:P], [P], oc)] + [whole.forward(ids[P + s:P + s + 1], [1], oc) for s in range(S)]
+    h_pre, h_dec = None, [None] * S
+    for l in range(3):
+        om = mo.OracleModel(args, w, pipeline_rank=l, num_pipeline_ranks=3)
+        c = mo.OracleCache(1, 1, 20, 2, 128, 6)
+        h_pre = om.forward_partial(ids[:P], [P], c, h_in=h_pre)
+        h_dec = [om.forward_partial(ids[P + s:P + s + 1], [1], c, h_in=h_dec[s]) for s in range(S)]
+    got = [F.linear(h_pre, w["output.weight"]).float()] + [F.linear(h, w["output.weight"]).float() for h in h_dec]
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
