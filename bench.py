@@ -296,7 +296,9 @@ def main() -> None:
     def decode_launch_label() -> str:
         # the engine counts its own launches in the workspace: that is how we know which path was timed
         kind = "persistent decode engine (1 launch per token)" if engine["engine_launches"] > 0 else "6 launches per layer"
-        return kind + (", eager" if (opt.no_graph or world > 1) else ", hipGraph replay")
+        from mistral_inference.distributed import RcclComm
+        eager = opt.no_graph or (world > 1 and not isinstance(model.pp_comm, RcclComm))
+        return kind + (", eager" if eager else ", hipGraph replay")
 
     def report() -> dict:
         ctx_len = T0 + Wm + K // 2
@@ -312,7 +314,8 @@ def main() -> None:
                        "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
                        "decode_launch": decode_launch_label(),
                        "parallelism": "single GPU" if world == 1 else
-                       f"pp{world} (layer ranges, {torch.distributed.get_backend()} send/recv + logits broadcast)"},
+                       f"pp{world} (layer ranges; {type(model.pp_comm).__name__} send/recv + logits broadcast, process group "
+                       f"{torch.distributed.get_backend()})"},
             "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                                   "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
             "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),

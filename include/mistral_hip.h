@@ -33,6 +33,7 @@ extern "C" {
 #define MI_ERR_SHAPE (-2)      /* shape not supported by the gfx950 kernels (see message) */
 #define MI_ERR_WORKSPACE (-3)  /* caller workspace too small                              */
 #define MI_ERR_UNSUPPORTED (-4)
+#define MI_ERR_RCCL (-5)       /* a RCCL call failed: text in mi_rccl_last_error()        */
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -248,6 +249,33 @@ int mi_debug_set_engine_trace(void* dev_buffer);
  * while the workgroup's consumers sweep hand-off granules (0: never); depth = fills in flight otherwise (2 or 3).
  * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults. */
 int mi_debug_set_engine_knobs(int thin, int depth);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pipeline-parallel exchange steps over RCCL (xGMI between the GPUs of a node)
+ *
+ * Replaces the reference's torch.distributed calls on the hot path: recv of the previous stage's activations
+ * (transformer.py:196), send to the next stage (:214), logits broadcast from the last stage (:237); process-group
+ * set-up of main.py:110-118.  One communicator per process (one process per GPU).  Every transfer is enqueued on the
+ * caller's HIP stream - no host synchronisation, and capturable in a hipGraph with the decode step.  librccl is
+ * dlopen()ed at the first call (MI_RCCL_LIB overrides the name): MI_ERR_UNSUPPORTED when it is absent.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mi_rccl_comm* mi_rccl_t;
+#define MI_RCCL_ID_BYTES 128
+/* rank 0 creates the 128-byte rendezvous id; the host distributes it to the other ranks (any side channel:
+ * torch.distributed object broadcast, a file, MPI) before each rank calls mi_rccl_init with the same id. */
+int mi_rccl_unique_id(void* id128);
+int mi_rccl_init(mi_rccl_t* comm, int world_size, int rank, const void* id128);
+int mi_rccl_destroy(mi_rccl_t comm);
+/* point-to-point: `bytes` from/to device memory, matched by the peer's recv/send on ITS stream */
+int mi_rccl_send(mi_rccl_t comm, const void* buf, size_t bytes, int peer, mi_stream_t stream);
+int mi_rccl_recv(mi_rccl_t comm, void* buf, size_t bytes, int peer, mi_stream_t stream);
+/* in-place broadcast of `bytes` from `root` */
+int mi_rccl_bcast(mi_rccl_t comm, void* buf, size_t bytes, int root, mi_stream_t stream);
+/* ncclGroupStart / ncclGroupEnd: a send and a recv that must progress together (a rank exchanging with itself or with
+ * both neighbours at once) are issued between the two */
+int mi_rccl_group_start(void);
+int mi_rccl_group_end(void);
+const char* mi_rccl_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
 SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "gemm256.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip",
-           "decode_engine.hip"]
+           "decode_engine.hip", "rccl_api.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
            os.path.join(CSRC, "attn_decode_core.cuh"),
            os.path.join(HERE, "..", "include", "mistral_hip.h")]
@@ -58,7 +58,7 @@ def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = L
         list(ex.map(run, jobs))
     objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
     if jobs or _stale(lib, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", lib])
     return lib
 
 

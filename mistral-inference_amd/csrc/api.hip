@@ -153,6 +153,7 @@ const char* mi_error_string(int code) {
     case MI_ERR_SHAPE: return "shape not supported by the gfx950 kernels";
     case MI_ERR_WORKSPACE: return "workspace too small";
     case MI_ERR_UNSUPPORTED: return "unsupported";
+    case MI_ERR_RCCL: return "RCCL call failed (see mi_rccl_last_error)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }

@@ -85,6 +85,15 @@ _SIGS = {
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
+    "mi_rccl_unique_id": (C.c_int, [_vp]),
+    "mi_rccl_init": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "mi_rccl_destroy": (C.c_int, [_vp]),
+    "mi_rccl_send": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "mi_rccl_recv": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "mi_rccl_bcast": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "mi_rccl_group_start": (C.c_int, []),
+    "mi_rccl_group_end": (C.c_int, []),
+    "mi_rccl_last_error": (C.c_char_p, []),
     "mi_debug_engine_trace_bytes": (C.c_size_t, []),
     "mi_debug_set_engine_trace": (C.c_int, [_vp]),
     "mi_debug_set_engine_knobs": (C.c_int, [C.c_int, C.c_int]),
@@ -113,8 +122,8 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         L = lib()
-        raise RuntimeError(f"libmistral_hip {what}: {L.mi_error_string(rc).decode()} "
-                           f"[{L.mi_last_error_detail().decode()}] (code {rc})")
+        detail = L.mi_rccl_last_error().decode() if rc == -5 else L.mi_last_error_detail().decode()
+        raise RuntimeError(f"libmistral_hip {what}: {L.mi_error_string(rc).decode()} [{detail}] (code {rc})")
 
 
 def stream_ptr(device: torch.device) -> int:

@@ -1,0 +1,97 @@
+"""Pipeline-parallel transport: RCCL over xGMI through the C ABI (`mi_rccl_*`, include/mistral_hip.h).
+
+The reference moves activations between pipeline stages and broadcasts the logits with `torch.distributed`
+(transformer.py:196,214,237).  `RcclComm` issues the same three exchanges as stream-ordered ncclSend / ncclRecv /
+ncclBroadcast on the CURRENT HIP stream: nothing passes through Python's process-group layer per token, and the calls
+can be captured in the decode step's hipGraph.  `torch.distributed` remains the bootstrap channel (it carries the
+128-byte rendezvous id once) and the transport of CPU tests (gloo).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _hip
+
+
+class RcclComm:
+    """One RCCL communicator for this process (one process per GPU)."""
+
+    def __init__(self, world_size: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        self.world_size, self.rank = world_size, rank
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, 128)
+        _hip.check(_hip.lib().mi_rccl_init(C.byref(self._h), world_size, rank, buf), "mi_rccl_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _hip.check(_hip.lib().mi_rccl_unique_id(buf), "mi_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls) -> "RcclComm":
+        """Rendezvous through the already-initialised torch.distributed group (reference main.py:110-118): rank 0's id
+        travels as ONE object broadcast, after which the group is no longer on the hot path."""
+        dist = torch.distributed
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(world, rank, box[0])
+
+    # -- the three exchanges of the pipeline (tensors: contiguous, on this process's device) ------------------------
+    def send(self, t: torch.Tensor, dst: int) -> None:
+        assert t.is_cuda and t.is_contiguous()
+        _hip.check(_hip.lib().mi_rccl_send(self._h, t.data_ptr(), t.numel() * t.element_size(), dst, _hip.stream_ptr(t.device)),
+                   "mi_rccl_send")
+
+    def recv(self, t: torch.Tensor, src: int) -> None:
+        assert t.is_cuda and t.is_contiguous()
+        _hip.check(_hip.lib().mi_rccl_recv(self._h, t.data_ptr(), t.numel() * t.element_size(), src, _hip.stream_ptr(t.device)),
+                   "mi_rccl_recv")
+
+    def broadcast(self, t: torch.Tensor, src: int) -> None:
+        assert t.is_cuda and t.is_contiguous()
+        _hip.check(_hip.lib().mi_rccl_bcast(self._h, t.data_ptr(), t.numel() * t.element_size(), src, _hip.stream_ptr(t.device)),
+                   "mi_rccl_bcast")
+
+    def exchange_with_self(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        """Grouped send + recv to this very rank (the single-GPU test of the transport)."""
+        L = _hip.lib()
+        _hip.check(L.mi_rccl_group_start(), "mi_rccl_group_start")
+        self.send(src, self.rank)
+        self.recv(dst, self.rank)
+        _hip.check(L.mi_rccl_group_end(), "mi_rccl_group_end")
+
+    def close(self) -> None:
+        if self._h:
+            _hip.check(_hip.lib().mi_rccl_destroy(self._h), "mi_rccl_destroy")
+            self._h = C.c_void_p()
+
+
+class TorchDistComm:
+    """The reference's own transport (torch.distributed send / recv / broadcast): CPU tests over gloo, and the fallback
+    selected with MI_PP_TRANSPORT=torch."""
+
+    def send(self, t: torch.Tensor, dst: int) -> None:
+        torch.distributed.send(t, dst=dst)
+
+    def recv(self, t: torch.Tensor, src: int) -> None:
+        torch.distributed.recv(t, src=src)
+
+    def broadcast(self, t: torch.Tensor, src: int) -> None:
+        torch.distributed.broadcast(t, src=src)
+
+
+def pipeline_comm(device: torch.device):
+    """Transport for a pipeline rank on `device`: RCCL through the C ABI on a GPU under the "nccl" process group (the
+    production path), torch.distributed otherwise."""
+    want = os.environ.get("MI_PP_TRANSPORT", "rccl")
+    if (want == "rccl" and device.type == "cuda" and torch.distributed.is_initialized()
+            and torch.distributed.get_backend() == "nccl"):
+        return RcclComm.from_process_group()
+    return TorchDistComm()

@@ -211,6 +211,7 @@ class Transformer(ModelBase):
         self.n_local_layers = len(self.layers)
         self._backend = backend if backend is not None else HipStackBackend()
         self._graphed: Optional[dict] = None  # state of an active graphed_decode() context
+        self._pp_comm: Optional[Any] = None   # pipeline transport (distributed.pipeline_comm), created at first use
 
     # ---- properties ----------------------------------------------------------------------------
     @property
@@ -236,6 +237,15 @@ class Transformer(ModelBase):
         out = super()._apply(fn, *a, **k)
         self._weights_changed()
         return out
+
+    # ---- pipeline transport ----------------------------------------------------------------------
+    @property
+    def pp_comm(self):
+        """RCCL communicator through the C ABI on a GPU (stream-ordered, capturable), torch.distributed otherwise."""
+        if self._pp_comm is None:
+            from .distributed import pipeline_comm
+            self._pp_comm = pipeline_comm(self.device)
+        return self._pp_comm
 
     # ---- forward -------------------------------------------------------------------------------
     def _nocache_metadata(self, seqlens: List[int]) -> BatchMetadata:
@@ -294,7 +304,7 @@ class Transformer(ModelBase):
         else:
             h = torch.empty((num_toks, self.args.dim), device=dev, dtype=self.dtype)
         if self.pipeline_rank > 0:
-            torch.distributed.recv(h, src=self.pipeline_rank - 1)
+            self.pp_comm.recv(h, src=self.pipeline_rank - 1)
         last = self.pipeline_rank == self.num_pipeline_ranks - 1
         logits = None
         if want_logits and last:
@@ -307,7 +317,7 @@ class Transformer(ModelBase):
             else:
                 cache.update_seqlens(seqlens)
         if not last:
-            torch.distributed.send(h, dst=self.pipeline_rank + 1)
+            self.pp_comm.send(h, dst=self.pipeline_rank + 1)
         return h, logits
 
     def forward_partial(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache] = None,
@@ -328,14 +338,31 @@ class Transformer(ModelBase):
         decode call, after one eager warm-up step - and replayed afterwards; only the token ids are copied into the
         graph's input buffer.  The returned logits tensor is the graph's output buffer: it is overwritten by the
         next call, which is how `generate()` uses it (it reduces the logits to a token and a logprob immediately).
-        Single-rank only; with pipeline ranks the context is a no-op.
+        Under pipeline parallelism the RCCL transfers are captured with the step (torch.distributed transports - the
+        gloo CPU tests - run eagerly: the context is a no-op there).
         """
-        usable = (self.num_pipeline_ranks == 1 and self.device.type == "cuda" and isinstance(self._backend, HipStackBackend))
+        from .distributed import RcclComm
+        usable = (self.device.type == "cuda" and isinstance(self._backend, HipStackBackend)
+                  and (self.num_pipeline_ranks == 1 or isinstance(self.pp_comm, RcclComm)))
         self._graphed = {"cache": cache, "graph": None, "warm": 0} if usable else None
         try:
             yield self
         finally:
             self._graphed = None
+
+    def _logits(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
+                images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        """One forward up to the logits every rank returns (reference transformer.py:221-242)."""
+        h, logits = self._run(input_ids, seqlens, cache, want_logits=True, images=images)
+        if self.num_pipeline_ranks > 1:
+            # every rank receives the logits in the model dtype, as the reference does (transformer.py:229-237);
+            # the kernel's fp32 logits are bf16-representable, so the narrowing is exact
+            outs = logits.to(self.dtype) if logits is not None else torch.empty(
+                h.shape[0], self.vocab_size, device=h.device, dtype=h.dtype)
+            self.pp_comm.broadcast(outs, src=self.num_pipeline_ranks - 1)
+            return outs.float() if self.softmax_fp32 else outs
+        assert logits is not None
+        return logits if self.softmax_fp32 else logits.to(self.dtype)
 
     def _graphed_step(self, input_ids: torch.Tensor, seqlens: List[int], cache: BufferCache, st: dict) -> torch.Tensor:
         if max(cache._seen) + 1 > ROPE_TABLE_LEN:  # same bound as _run (a replayed step never passes through it)
@@ -343,16 +370,16 @@ class Transformer(ModelBase):
         if st["graph"] is None:
             if st["warm"] < 1:  # eager step: sizes the workspace and the cache's device metadata before capture
                 st["warm"] += 1
-                _, logits = self._run(input_ids, seqlens, cache, want_logits=True)
-                return logits if self.softmax_fp32 else logits.to(self.dtype)
+                return self._logits(input_ids, seqlens, cache)
             st["ids"] = input_ids.to(device=self.device, dtype=torch.long).clone()
             st["B"] = len(seqlens)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             seen = list(cache._seen)
             with torch.cuda.graph(graph):
-                _, logits = self._run(st["ids"], seqlens, cache, want_logits=True)
-                st["out"] = logits if self.softmax_fp32 else logits.to(self.dtype)
+                # under pipeline parallelism the stage-to-stage ncclRecv / ncclSend and the logits broadcast are graph
+                # nodes too (RCCL enqueues on the capturing stream): a replay needs no Python per token on any rank
+                st["out"] = self._logits(st["ids"], seqlens, cache)
             cache._seen = seen  # capture enqueues nothing: the step itself is the first replay below
             st["graph"] = graph
         else:
@@ -369,16 +396,7 @@ class Transformer(ModelBase):
                 and all(s == 1 for s in seqlens) and len(seqlens) == len(cache._seen)
                 and (st["graph"] is None or len(seqlens) == st["B"])):
             return self._graphed_step(input_ids, seqlens, cache, st)
-        h, logits = self._run(input_ids, seqlens, cache, want_logits=True, images=images)
-        if self.num_pipeline_ranks > 1:
-            # every rank receives the logits in the model dtype, as the reference does (transformer.py:229-237);
-            # the kernel's fp32 logits are bf16-representable, so the narrowing is exact
-            outs = logits.to(self.dtype) if logits is not None else torch.empty(
-                h.shape[0], self.vocab_size, device=h.device, dtype=h.dtype)
-            torch.distributed.broadcast(outs, src=self.num_pipeline_ranks - 1)
-            return outs.float() if self.softmax_fp32 else outs
-        assert logits is not None
-        return logits if self.softmax_fp32 else logits.to(self.dtype)
+        return self._logits(input_ids, seqlens, cache, images)
 
     def prompt_logprobs(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
                         targets: torch.Tensor, images: Optional[List[torch.Tensor]] = None):
@@ -396,7 +414,7 @@ class Transformer(ModelBase):
         if self.num_pipeline_ranks > 1:
             # only rank 0 is guaranteed to hold the real prompt (the reference's other ranks get placeholders of the same
             # length, main.py:147-160): its target ids travel to the rank that owns the LM head
-            torch.distributed.broadcast(targets, src=0)
+            self.pp_comm.broadcast(targets, src=0)
         if last_rank:
             assert self.output is not None
             lp = _hip.lm_head_logprobs(h, self.output.weight, targets)
@@ -406,8 +424,8 @@ class Transformer(ModelBase):
             lp = torch.empty(T, dtype=torch.float32, device=dev)
             last = torch.empty((B, self.vocab_size), dtype=torch.float32, device=dev)
         if self.num_pipeline_ranks > 1:
-            torch.distributed.broadcast(lp, src=self.num_pipeline_ranks - 1)
-            torch.distributed.broadcast(last, src=self.num_pipeline_ranks - 1)
+            self.pp_comm.broadcast(lp, src=self.num_pipeline_ranks - 1)
+            self.pp_comm.broadcast(last, src=self.num_pipeline_ranks - 1)
         return lp, last
 
     # ---- weights -------------------------------------------------------------------------------
