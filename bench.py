@@ -92,8 +92,50 @@ def prefill_flops(p: dict, T: int) -> float:
     return 2.0 * T * (L * lin + V * D) + L * 4.0 * H * Dh * pairs
 
 
+def _pmc_traffic(kernel_substr: str, dims_ok: bool):
+    """HBM bytes per launch of the dominant kernel from the PMC counters: collected in separate `rocprofv3 --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` passes (scripts/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes for
+    gfx950 (2 x FETCH_SIZE), committed under profiles/.  Only valid for the named model dimensions and kernel."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+    if dims_ok and os.path.exists(pmc):
+        with open(pmc) as f:
+            rec = json.load(f)
+        if kernel_substr in rec.get("kernel", ""):
+            return rec["hbm_bytes_per_launch"], rec["source"]
+    return None, None
+
+
+def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
+    """The dominant kernel of the timed path is the persistent decode engine: ONE `decode_engine_kernel` launch per
+    token streams every local layer's weights, the K/V rings and the LM head.  Algorithmic bytes per launch = SURVEY.md
+    8(d)'s bytes per token at this context; launch duration = HIP events on the launch stream around `iters` eager decode
+    steps (each = the decode-prep/embedding kernel, ~2 us, + the engine launch), which is what `rocprofv3 --kernel-trace
+    --stats` reports for the kernel (profiles/)."""
+    dev = model.device
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(2):
+        nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+    ctx0 = cache._seen[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ids = nxt.clone()
+    e0.record(stream)
+    for _ in range(iters):
+        model.forward(ids, [1], cache)   # same token id every step: no argmax kernel between the launches
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    bytes_per_launch = decode_bytes_per_token(params, ctx0 + iters // 2)
+    gbs = bytes_per_launch / (us * 1e-6) / 1e9
+    dims_ok = (model.args.dim, model.args.hidden_dim, model.args.n_layers) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"], MISTRAL_7B["n_layers"])
+    traffic, traffic_src = _pmc_traffic("decode_engine_kernel", dims_ok)
+    return {"bound": "hbm", "kernel": "decode_engine_kernel<4> (persistent: all layers + LM head of one decode step in one launch)",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch,
+            "avg_launch_us": round(us, 2), "launches_timed": iters}
+
+
 def dominant_kernel_roofline(model, iters: int) -> dict:
-    """The W1|W3 gate/up GEMV (54 % of the decode bytes): algorithmic bytes per launch / average launch
+    """Launch path: the W1|W3 gate/up GEMV (54 % of the decode bytes): algorithmic bytes per launch / average launch
     duration, timed live with HIP events on the launch stream, cycling through all local layers' weights so
     no launch re-reads what the previous one left in the 256 MiB Infinity Cache."""
     from mistral_inference import _hip
@@ -120,15 +162,7 @@ def dominant_kernel_roofline(model, iters: int) -> dict:
     us = e0.elapsed_time(e1) * 1e3 / n
     bytes_per_launch = 2 * a.hidden_dim * a.dim * 2 + 2 * a.dim * 2 + a.hidden_dim * 2
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
-    # HBM bytes per launch from the PMC counters: collected in a separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
-    # WRITE_SIZE` pass (scripts/gpu_round.sh), corrected as MI355X_MICROARCH.md prescribes for gfx950
-    # (2 x FETCH_SIZE), committed under profiles/.  Only valid for the named model dimensions.
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
-    if os.path.exists(pmc) and (a.dim, a.hidden_dim) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"]):
-        with open(pmc) as f:
-            rec = json.load(f)
-        traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+    traffic, traffic_src = _pmc_traffic("gemv_kernel", (a.dim, a.hidden_dim) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"]))
     return {"bound": "hbm", "kernel": "gemv_kernel<1,SWIGLU> (RMSNorm + W1|W3 GEMV + SiLU*mul)", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
@@ -248,7 +282,7 @@ def main() -> None:
     from mistral_inference.cache import BufferCache
     a = model.args
     T0, K, Wm = opt.prefill, opt.steps, opt.warmup
-    cache = BufferCache(model.n_local_layers, 1, T0 + K + max(Wm, 2) + 8, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
+    cache = BufferCache(model.n_local_layers, 1, T0 + K + max(Wm, 2) + 64, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
                         dtype=torch.bfloat16)
     cache.reset()
     prompt = torch.randint(0, a.vocab_size, (T0,), generator=torch.Generator().manual_seed(0)).to(dev)
@@ -323,7 +357,12 @@ def main() -> None:
                         "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
         }
         if not params.get("moe"):  # the dominant kernel is timed on this rank's own layers (any N)
-            out["roofline"] = dominant_kernel_roofline(model, iters=4)
+            if engine["engine_launches"] > 0 and world == 1:
+                with torch.inference_mode():
+                    out["roofline"] = engine_roofline(model, cache, nxt, params, iters=24)
+                out["launch_path_gemv_w13"] = dominant_kernel_roofline(model, iters=2)
+            else:
+                out["roofline"] = dominant_kernel_roofline(model, iters=4)
         if world == 1 and not params.get("moe") and not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, T0)
         return out

@@ -18,6 +18,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 shutil.copy(os.path.join(OUT, "kernel_stats.csv"), os.path.join(PROF, f"{tag}_decode_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(OUT, "one_step_timeline.csv"), os.path.join(PROF, f"{tag}_decode_one_step_timeline.csv"))
+if os.path.exists(os.path.join(OUT, "kernel_stats_launch_path.csv")):
+    shutil.copy(os.path.join(OUT, "kernel_stats_launch_path.csv"), os.path.join(PROF, f"{tag}_decode_launch_path_kernel_stats.csv"))
 
 rows = []
 per = {}
@@ -43,12 +45,12 @@ for counter, stem in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         rows.append((short, counter, len(vs), sum(vs) / len(vs), min(vs), max(vs)))
         per.setdefault(short, {})[counter] = sum(vs) / len(vs)
 with open(os.path.join(PROF, f"{tag}_pmc_fetch_write_size.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); bench.py --layers 4 --steps 4 --prefill 512 --no-graph\n")
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); bench.py --steps 4 --warmup 2 --no-graph: the FULL headline config (32 layers, 4096-token prefill, decode at context 4096+)\n")
     f.write("# values in KiB as reported; on gfx950 FETCH_SIZE counts 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM): hbm_read_bytes = 2 * FETCH_SIZE * 1024\n")
     f.write("kernel,counter,dispatches,mean_KiB,min_KiB,max_KiB\n")
     for k, c, n, m, lo, hi in rows:
         f.write(f'"{k}",{c},{n},{m:.1f},{lo:.1f},{hi:.1f}\n')
-dom = [k for k in per if "gemv_kernel<1, 2, 2>" in k]
+dom = [k for k in per if "decode_engine_kernel" in k] or [k for k in per if "gemv_kernel<1, 2, 2>" in k]
 if dom:
     k = dom[0]
     fetch, write = per[k].get("FETCH_SIZE", 0.0), per[k].get("WRITE_SIZE", 0.0)
@@ -67,7 +69,7 @@ if os.path.exists(mf):
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(os.path.join(PROF, f"{tag}_pmc_mfma_util.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace (own pass); bench.py --layers 4 --steps 2 --prefill 4096 --no-graph\n")
+        f.write("# rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace (own pass); bench.py --steps 2 --warmup 2 --no-graph (32 layers, 4096-token prefill)\n")
         f.write("# derived metrics, mean over dispatches (gfx950 falls back to the gfx94x formulas, MI355X_MICROARCH.md 'rocprofv3 PMC slots')\n")
         f.write("kernel,dispatches,MfmaUtil_pct,VALUBusy_pct,LdsUtil_pct,LdsBankConflict_per_access\n")
         for k, d in sorted(acc.items()):

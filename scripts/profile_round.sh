@@ -25,9 +25,14 @@ if f:
 PY
 find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
 if [ "$1" == "pmc" ]; then
-(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o fetch -- python $REPO/bench.py --layers 4 --steps 4 --warmup 2 --prefill 512 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_fetch.log 2>&1)
-(cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o write -- python $REPO/bench.py --layers 4 --steps 4 --warmup 2 --prefill 512 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_write.log 2>&1)
-(cd /tmp && timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o mfma -- python $REPO/bench.py --layers 4 --steps 2 --warmup 1 --prefill 4096 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_mfma.log 2>&1)
+# the FULL headline configuration (32 layers, 4096-token prefill, decode at context 4096+): counters in their own passes
+(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o fetch -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_fetch.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o write -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_write.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o mfma -- python $REPO/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_mfma.log 2>&1)
+# the launch path (6 kernels per layer) for the per-kernel decode table
+(cd /tmp && MI_DECODE_ENGINE=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_launch -o decode -- python $REPO/bench.py --steps 16 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/prof_launch.log 2>&1)
+find gpurun_out/prof_launch -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats_launch_path.csv
+find gpurun_out/prof_launch -name "*kernel_trace.csv" -size +20M -delete
 find gpurun_out/pmc -name "*.csv" -size +20M -delete
 fi
 find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats.csv
