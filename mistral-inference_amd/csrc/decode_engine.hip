@@ -393,9 +393,36 @@ struct Cons {
       }
     }
   }
-  template <int NL = 8>
+  // Contiguous granule array (n even): 16-byte sc1 loads, two granules each - half the load instructions and wider
+  // transactions than the 8-byte sweep (each 8-byte half is still validated by its own tag).
+  template <int NL = 4>
   __device__ __forceinline__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
-    gather_fn<NL>(n, tag, dst, [&](int i) { return src + i; });
+    const int n2 = n >> 1;  // granule pairs
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n * 8, 0x00020000);
+    for (int k0 = 0; k0 * NCONS * 64 < n2; k0 += NL) {
+      u32x4 x[NL];
+      uint32_t spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int i = ((k0 + k) * NCONS + w) * 64 + lane;
+          x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, min(i, n2 - 1) * 16, 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int i = ((k0 + k) * NCONS + w) * 64 + lane;
+          ok &= (i >= n2) || (x[k][1] == tag && x[k][3] == tag);
+        }
+        if (__all(ok)) break;
+        if (!spin_ok(sh, spins, 0x400)) break;
+      }
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int i = ((k0 + k) * NCONS + w) * 64 + lane;
+        if (i < n2) *reinterpret_cast<LDS_AS u32x2*>(dst + 2 * i) = u32x2{x[k][0], x[k][2]};
+      }
+    }
   }
 
   // RMSNorm of the K-element bf16 vector in LDS, in place (transformer_layers.py:115-120), with the launch path's
@@ -694,7 +721,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     // ================================================================ h = h1 + hid @ W2^T
     cs.cbar();
     sh.ctl[C_GATHERING] = 1;
-    cs.gather<28>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
+    cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
     trace_ev(sh, c, l, 15, trc);
@@ -859,7 +886,7 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
   }
   if (g_depth < 0) {
     const char* e = getenv("MI_ENGINE_DEPTH");
-    g_depth = e ? atoi(e) : 3;
+    g_depth = e ? atoi(e) : 2;  // measured: 2 fills in flight (plus the one being issued) beats 3
   }
   a.thin = g_thin;
   a.depth = g_depth;
