@@ -64,22 +64,33 @@ __device__ __forceinline__ void reduce_slot(State<R>& st, const float (&qf)[R][8
     vf[2 * i] = bf_lo(vraw[i]);
     vf[2 * i + 1] = bf_hi(vraw[i]);
   }
+  float d[R];
+  bool grow[R], any_grow = false;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float d = 0.f;
+    float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d = fmaf(qf[r][i], kf[i], d);
-    d = row16_sum(d);
-    const bool grow = valid && (d > st.m[r] + RESCALE_T);
-    if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform branch: rare after a lane group's first slots
-      const float mn = grow ? d : st.m[r];
-      const float alpha = ex2(st.m[r] - mn);        // 1 for the lanes that keep their reference
+    for (int i = 0; i < 8; ++i) t = fmaf(qf[r][i], kf[i], t);
+    d[r] = row16_sum(t);
+    grow[r] = valid && (d[r] > st.m[r] + RESCALE_T);
+    any_grow |= grow[r];
+  }
+  // ONE wave-uniform branch per slot for all R heads (a ballot + branch per head costs a scalar round trip each);
+  // rare after a lane group's first slots.  Heads / lanes that keep their reference multiply by exactly 1.
+  if (__builtin_amdgcn_ballot_w64(any_grow) != 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float mn = grow[r] ? d[r] : st.m[r];
+      const float alpha = ex2(st.m[r] - mn);
       st.l[r] *= alpha;
 #pragma unroll
       for (int i = 0; i < 8; ++i) st.acc[r][i] *= alpha;
       st.m[r] = mn;
     }
-    const float p = valid ? ex2(d - st.m[r]) : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float p = valid ? ex2(d[r] - st.m[r]) : 0.f;
     st.l[r] += p;
 #pragma unroll
     for (int i = 0; i < 8; ++i) st.acc[r][i] = fmaf(p, vf[i], st.acc[r][i]);
