@@ -437,15 +437,48 @@ struct Cons {
 #pragma unroll
     for (int i = 0; i < 4; ++i) nw.w[i] = ld16(norm_w + (size_t)min(vt + i * 256, npieces - 1) * 8);
   }
-  __device__ __forceinline__ void rmsnorm_inplace(lbf16* xs, int K, const NormW& nw, float eps) {
+  // Pieces of the K-element vector this lane owns in the norm's reduction tree (q = vt + i * 256), from LDS ...
+  __device__ __forceinline__ void norm_load_lds(u32x4 (&xr)[4], const lbf16* xs, int K) {
     const int vt = w * 64 + lane, npieces = K >> 3;
-    u32x4 xr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = vt + i * 256;
+      if (q < npieces) xr[i] = lds16(xs + q * 8);
+    }
+  }
+  // ... or straight from the hand-off granules: piece q = granules 4q .. 4q+3 = two 16-byte sc1 loads of this lane, so the
+  // sweep IS the norm's first pass (no LDS round trip and no barrier between them).
+  __device__ __forceinline__ void norm_load_granules(u32x4 (&xr)[4], const gu64* src, int K, uint32_t tag) {
+    const int vt = w * 64 + lane, npieces = K >> 3;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (K / 2) * 8, 0x00020000);
+    u32x4 lo[4], hi[4];
+    uint32_t spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = min(vt + i * 256, npieces - 1);
+        lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * 32, 0, 16 /* sc1 */);
+        hi[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * 32 + 16, 0, 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        ok &= (vt + i * 256 >= npieces) || (lo[i][1] == tag && lo[i][3] == tag && hi[i][1] == tag && hi[i][3] == tag);
+      if (__all(ok)) break;
+      if (!spin_ok(sh, spins, 0x400)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = u32x4{lo[i][0], lo[i][2], hi[i][0], hi[i][2]};
+  }
+  // RMSNorm of the pieces in xr, written to xs (transformer_layers.py:115-120), with the launch path's reduction tree:
+  // 256 "threads" own 16-byte pieces vt + i * 256, per-piece sums, wave butterfly, 4 wave totals.
+  __device__ __forceinline__ void rmsnorm_store(const u32x4 (&xr)[4], lbf16* xs, int K, const NormW& nw, float eps) {
+    const int vt = w * 64 + lane, npieces = K >> 3;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = vt + i * 256;
       if (q < npieces) {
-        xr[i] = lds16(xs + q * 8);
         float s = 0.f;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
@@ -507,19 +540,19 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     // ================================================================ attention_norm + q|k|v + RoPE + ring write
     typename Cons::NormW nw;
     cs.norm_prefetch(nw, a.D, L.an);
+    u32x4 xr[4];
     if (l == 0 && a.first) {  // the step's input comes from global memory (embedding / previous stage / previous launch)
       const int vt = w * 64 + lane;
-      for (int q = vt; q < (a.D >> 3); q += NCONS * 64) lds_st16(xs + q * 8, ld16(a.h + (size_t)q * 8));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[i] = ld16(a.h + (size_t)min(vt + i * 256, (a.D >> 3) - 1) * 8);
       for (int r = 2 * p.o0 + vt; r < 2 * p.o1; r += NCONS * 64) sh.res[r - 2 * p.o0] = a.h[r];
-      cs.cbar();
     } else {
       sh.ctl[C_GATHERING] = 1;
-      cs.gather(G + a.g_h, a.D / 2, tag_of(l - 1, 0), xs32);
-      cs.cbar();
+      cs.norm_load_granules(xr, G + a.g_h, a.D, tag_of(l - 1, 0));
       sh.ctl[C_GATHERING] = 0;
     }
     trace_ev(sh, c, l, 1, trc);
-    cs.rmsnorm_inplace(xs, a.D, nw, a.eps);
+    cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 2, trc);
     {
       const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0, n_u = nq_u + 2 * nk_u;
@@ -585,10 +618,11 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       }
       State<R> st;
       init_state<R>(st);
+      // this CU's K/V pieces were the first thing the loader fetched after the q|k|v weights: they landed long ago -
+      // ONE wait for the last of them instead of a wait + ring bookkeeping per piece
+      if (p.n_att) cs.need_fill(g + 2 * p.n_att - 1);
       for (int j = w; j < p.n_att; j += NCONS) {  // virtual wave w of the stand-alone kernel
         const uint32_t gk = g + 2 * j;
-        cs.set_done(gk);
-        cs.need_fill(gk + 1);
         u32x4 kraw = lds16(sh.ring + (gk & sh.ring_mask) * PIECE + lane * 16);
         u32x4 vraw = lds16(sh.ring + ((gk + 1) & sh.ring_mask) * PIECE + lane * 16);
         const int slot = p.s_begin + 4 * j + gl;
@@ -694,11 +728,10 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     cs.norm_prefetch(nw, a.D, L.fn);
     cs.cbar();
     sh.ctl[C_GATHERING] = 1;
-    cs.gather(G + a.g_h1, a.D / 2, tag_of(l, 4), xs32);
-    cs.cbar();
+    cs.norm_load_granules(xr, G + a.g_h1, a.D, tag_of(l, 4));
     sh.ctl[C_GATHERING] = 0;
     trace_ev(sh, c, l, 12, trc);
-    cs.rmsnorm_inplace(xs, a.D, nw, a.eps);
+    cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
     {
       const int n_u = p.f1 - p.f0;
@@ -754,11 +787,11 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   if (a.head) {
     typename Cons::NormW nw;
     cs.norm_prefetch(nw, a.D, a.final_norm);
+    u32x4 xr[4];
     sh.ctl[C_GATHERING] = 1;
-    cs.gather(G + a.g_h, a.D / 2, tag_of(a.n_layers - 1, 0), xs32);
-    cs.cbar();
+    cs.norm_load_granules(xr, G + a.g_h, a.D, tag_of(a.n_layers - 1, 0));
     sh.ctl[C_GATHERING] = 0;
-    cs.rmsnorm_inplace(xs, a.D, nw, a.eps);
+    cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     int v0, v1;
     slab(a.V / 2, c, a.NB, v0, v1);
     for (int k = w; k < v1 - v0; k += NCONS) {
