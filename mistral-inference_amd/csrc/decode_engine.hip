@@ -619,10 +619,16 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       State<R> st;
       init_state<R>(st);
       // this CU's K/V pieces were the first thing the loader fetched after the q|k|v weights: they landed long ago -
-      // ONE wait for the last of them instead of a wait + ring bookkeeping per piece
-      if (p.n_att) cs.need_fill(g + 2 * p.n_att - 1);
+      // ONE wait for the last of them instead of a wait + ring bookkeeping per piece ... as long as they all fit the ring
+      // while this wave pins its position (a 272-slot split of an 8K ring is 136 pieces: per-piece bookkeeping then)
+      const bool streamed = 2 * p.n_att > (RING_FILLS - 2) * FILL;
+      if (p.n_att && !streamed) cs.need_fill(g + 2 * p.n_att - 1);
       for (int j = w; j < p.n_att; j += NCONS) {  // virtual wave w of the stand-alone kernel
         const uint32_t gk = g + 2 * j;
+        if (streamed) {
+          cs.set_done(gk);
+          cs.need_fill(gk + 1);
+        }
         u32x4 kraw = lds16(sh.ring + (gk & sh.ring_mask) * PIECE + lane * 16);
         u32x4 vraw = lds16(sh.ring + ((gk + 1) & sh.ring_mask) * PIECE + lane * 16);
         const int slot = p.s_begin + 4 * j + gl;

@@ -86,6 +86,9 @@ SHAPES = {
                           vocab_size=514, sliding_window=None),
     "gqa2_long_ring": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=8, n_kv_heads=4, norm_eps=1e-6,
                            vocab_size=2048, sliding_window=1200),
+    # an 8.3K-slot ring: 31 splits of 272 slots = 136 K/V pieces per CU, more than the LDS ring holds at once
+    "ring_longer_than_lds": dict(dim=512, n_layers=1, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
+                                 vocab_size=640, sliding_window=None),
 }
 
 
@@ -97,6 +100,8 @@ def test_engine_bit_equal_launch_path(name):
     W = p["sliding_window"] or 10 ** 9
     prompt_len = 40 if W < 100 else 300  # 40 + steps crosses the 48-slot ring; 300 leaves later splits empty in a 1200 ring
     steps = 12
+    if name == "ring_longer_than_lds":
+        prompt_len, steps = 8290, 6
     ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(3)).cuda()
     ref, ref_rings, st0 = _run(m, ids, prompt_len, steps, engine=False)
     got, got_rings, st1 = _run(m, ids, prompt_len, steps, engine=True)
