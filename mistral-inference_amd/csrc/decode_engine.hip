@@ -155,6 +155,9 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
   p.n_att = (p.att && p.s_end > p.s_begin) ? (p.s_end - p.s_begin + 3) >> 2 : 0;
 }
 
+// pieces per group of a unit's interleaved stream (loader and consumers must agree)
+__device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P & 1) == 0 ? 2 : 1); }
+
 // ------------------------------------------------------------------------------------------------ loader wave
 struct Loader {
   const Shared& sh;
@@ -225,16 +228,31 @@ struct Loader {
     g += 4;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
-  __device__ __forceinline__ void rows(const bf16_t* base, size_t row0, int nrows, int K) {  // contiguous row slab
-    const char* p = reinterpret_cast<const char*>(base + row0 * K) + lane * 16;
-    int n = nrows * (K >> 9);
-    while (n > 0 && (g & 3)) {  // align the group path
-      piece(p);
-      p += PIECE;
-      --n;
+  // One UNIT = NR weight rows of P pieces each that a consumer wave reduces together.  Stream order inside a unit: groups
+  // of G pieces, row after row - rows[0][0..G), rows[1][0..G), ..., rows[0][G..2G), ... - so that the consumer can start on
+  // the first group while the rest is in flight and hand ring space back group by group (a unit of W2 is 56 pieces: four
+  // waves each pinning a whole unit would need 14 fills of the 8-fill ring).
+  template <int NR>
+  __device__ __forceinline__ void unit(const bf16_t* const (&rp)[NR], int P) {
+    const int G = unit_group(P);
+    for (int p0 = 0; p0 < P; p0 += G) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const char* src = reinterpret_cast<const char*>(rp[r]) + (size_t)p0 * PIECE + lane * 16;
+        if (G == 4 && (g & 3) == 0) {
+          piece4(src);
+        } else {
+          for (int i = 0; i < G; ++i) piece(src + (size_t)i * PIECE);
+        }
+      }
     }
-    for (; n >= 4; n -= 4, p += 4 * PIECE) piece4(p);
-    for (; n > 0; --n, p += PIECE) piece(p);
+  }
+  // row-pair units u0 .. u1 of a [rows, K] matrix
+  __device__ __forceinline__ void pairs(const bf16_t* base, int u0, int u1, int K) {
+    for (int u = u0; u < u1; ++u) {
+      const bf16_t* const rp[2] = {base + (size_t)(2 * u) * K, base + (size_t)(2 * u + 1) * K};
+      unit<2>(rp, K >> 9);
+    }
   }
   __device__ __forceinline__ void flush() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -252,9 +270,9 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     plan_layer(a, L, c, pos, p);
     const bool tr = lane == 0;
     trace_ev(sh, c, l, TR_CONS + 0, tr);
-    ld.rows(L.wq, 2 * (size_t)p.q0, 2 * (p.q1 - p.q0), a.D);
-    ld.rows(L.wk, 2 * (size_t)p.k0, 2 * (p.k1 - p.k0), a.D);
-    ld.rows(L.wv, 2 * (size_t)p.v0, 2 * (p.v1 - p.v0), a.D);
+    ld.pairs(L.wq, p.q0, p.q1, a.D);
+    ld.pairs(L.wk, p.k0, p.k1, a.D);
+    ld.pairs(L.wv, p.v0, p.v1, a.D);
     trace_ev(sh, c, l, TR_CONS + 1, tr);
     if (p.n_att) {  // K piece j, V piece j: 4 ring slots x 256 B each (slots past the ring end are clamped; masked later)
       const int kv_real = p.kvh / a.kv_groups;
@@ -267,23 +285,22 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       }
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
-    ld.rows(L.wo, 2 * (size_t)p.o0, 2 * (p.o1 - p.o0), a.H * DH);
+    ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
     for (int j = p.f0; j < p.f1; ++j) {
-      ld.rows(L.w1, 2 * (size_t)j, 1, a.D);
-      ld.rows(L.w3, 2 * (size_t)j, 1, a.D);
-      ld.rows(L.w1, 2 * (size_t)j + 1, 1, a.D);
-      ld.rows(L.w3, 2 * (size_t)j + 1, 1, a.D);
+      const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
+      const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
+      ld.template unit<4>(rp, a.D >> 9);
     }
     trace_ev(sh, c, l, TR_CONS + 4, tr);
-    ld.rows(L.w2, 2 * (size_t)p.o0, 2 * (p.o1 - p.o0), a.F);
+    ld.pairs(L.w2, p.o0, p.o1, a.F);
     trace_ev(sh, c, l, TR_CONS + 5, tr);
     if (sh.trace && tr) sh.trace[((size_t)c * ENG_MAXL + l) * TR_EVENTS + TR_CONS + 6] = ld.stalls;
   }
   if (a.head) {
     int v0, v1;
     slab(a.V / 2, c, a.NB, v0, v1);
-    ld.rows(a.output, 2 * (size_t)v0, 2 * (v1 - v0), a.D);
+    ld.pairs(a.output, v0, v1, a.D);
   }
   (void)PD;
   ld.flush();
@@ -328,7 +345,6 @@ struct Cons {
     float acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-    need_fill(g0 + NR * P - 1);
     const lchar* xl = reinterpret_cast<const lchar*>(xs) + lane * 16;
     const lchar* wl = sh.ring + lane * 16;
     auto step = [&](const u32x4& xv, const u32x4 (&wv)[NR]) {
@@ -337,25 +353,35 @@ struct Cons {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(wv[r][i], xv[i], acc[r]);
     };
-    constexpr int G = (NR <= 2) ? 4 : 2;  // pieces per group: all LDS reads of a group are issued before its math
-    int p = 0;
-    for (; p + G <= P; p += G) {
-      u32x4 xv[G], wv[G][NR];
+    // the unit arrives in groups of G pieces per row (Loader::unit): wait for a group, reduce it, hand its ring space back
+    const int G = unit_group(P);
+    constexpr int S = (NR <= 2) ? 4 : 2;  // pieces per row whose LDS reads are issued together
+    uint32_t gg = g0;                     // first ring piece of the current group
+    for (int p0 = 0; p0 < P; p0 += G, gg += NR * G) {
+      need_fill(gg + NR * G - 1);
+      if (G == 4) {
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        xv[j] = lds16(xl + (p + j) * PIECE);
+        for (int h = 0; h < 4; h += S) {
+          u32x4 xv[S], wv[S][NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) wv[j][r] = lds16(wl + ((g0 + r * P + p + j) & sh.ring_mask) * PIECE);
+          for (int j = 0; j < S; ++j) {
+            xv[j] = lds16(xl + (p0 + h + j) * PIECE);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) wv[j][r] = lds16(wl + ((gg + r * 4 + h + j) & sh.ring_mask) * PIECE);
+          }
+#pragma unroll
+          for (int j = 0; j < S; ++j) step(xv[j], wv[j]);
+        }
+      } else {
+        for (int i = 0; i < G; ++i) {
+          u32x4 wv[NR];
+          const u32x4 xv = lds16(xl + (p0 + i) * PIECE);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) wv[r] = lds16(wl + ((gg + r * G + i) & sh.ring_mask) * PIECE);
+          step(xv, wv);
+        }
       }
-#pragma unroll
-      for (int j = 0; j < G; ++j) step(xv[j], wv[j]);
-    }
-    for (; p < P; ++p) {
-      u32x4 wv[NR];
-      const u32x4 xv = lds16(xl + p * PIECE);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) wv[r] = lds16(wl + ((g0 + r * P + p) & sh.ring_mask) * PIECE);
-      step(xv, wv);
+      set_done(gg + NR * G);
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) out[r] = wave_sum(acc[r]);
@@ -884,8 +910,6 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch
   if ((size_t)kmax * 2 > region) return no("activation vector does not fit beside the 8-fill ring");
-  // a consumer wave holds its ring position while it reads one unit: the unit must fit the ring minus one fill
-  if (2 * (kmax >> 9) > RING_FILLS * FILL - FILL || 4 * (pr.D >> 9) > RING_FILLS * FILL - FILL) return no("unit longer than the ring");
   const int NB = pr.NB;
   if (NB < 8 || NB > 1024) return no("CU count");
   if (((pr.D / 2 + NB - 1) / NB) * 2 * 2 > RES_BYTES) return no("residual slab");

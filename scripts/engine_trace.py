@@ -81,6 +81,11 @@ def main():
         print(f"{name:16s} {rel.mean():8.2f} {rel.min(axis=1).mean():8.2f} {rel.max(axis=1).mean():8.2f}")
     stalls = t[:, :nl, 24]
     print("loader ring-full stalls per CU (cumulative at last layer): mean %.1f max %.0f" % (stalls[:, nl - 1].mean(), stalls[:, nl - 1].max()))
+    if nl > 6:
+        d13 = ((t[:, 2:nl - 2, 14] - t[:, 2:nl - 2, 13]) * us).mean(axis=1)   # W1|W3 phase of consumer wave 0, per CU
+        d2 = ((t[:, 2:nl - 2, 16] - t[:, 2:nl - 2, 15]) * us).mean(axis=1)
+        print("W1|W3 phase by XCD (cu % 8), us:", " ".join(f"{d13[x::8].mean():.2f}" for x in range(8)),
+              "| W2:", " ".join(f"{d2[x::8].mean():.2f}" for x in range(8)))
     seg = (t[:, 2:nl - 2, 23] - t[:, 2:nl - 2, 18]) * us
     print("loader time per layer: mean %.2f us, min %.2f, max %.2f  (1.70 MB per CU per layer -> %.1f GB/s per CU, %.2f TB/s chip)"
           % (seg.mean(), seg.min(), seg.max(), 1.70e6 / seg.mean() / 1e3, 1.70e6 / seg.mean() / 1e3 * nb / 1e3))
