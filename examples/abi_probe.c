@@ -32,6 +32,15 @@ int main(int argc, char** argv) {
     fprintf(stderr, "missing symbol\n");
     return 3;
   }
+  /* ABI v3: fused decode / MoE leaf operators, the RCCL transport and the decode-engine controls are part of the surface */
+  static const char* const v3[] = {"mi_qkv_rope_kvwrite", "mi_moe_experts_decode", "mi_moe_grouped_gemm", "mi_rccl_unique_id",
+                                   "mi_rccl_init", "mi_rccl_send", "mi_rccl_recv", "mi_rccl_bcast", "mi_rccl_destroy",
+                                   "mi_set_decode_engine", "mi_decode_engine_status"};
+  for (size_t i = 0; i < sizeof(v3) / sizeof(v3[0]); ++i)
+    if (!dlsym(h, v3[i])) {
+      fprintf(stderr, "missing symbol %s\n", v3[i]);
+      return 3;
+    }
   if (abi() != MI_ABI_VERSION) {
     fprintf(stderr, "ABI %d, header %d\n", abi(), MI_ABI_VERSION);
     return 4;

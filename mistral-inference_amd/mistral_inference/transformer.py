@@ -376,10 +376,18 @@ class Transformer(ModelBase):
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             seen = list(cache._seen)
-            with torch.cuda.graph(graph):
-                # under pipeline parallelism the stage-to-stage ncclRecv / ncclSend and the logits broadcast are graph
-                # nodes too (RCCL enqueues on the capturing stream): a replay needs no Python per token on any rank
-                st["out"] = self._logits(st["ids"], seqlens, cache)
+            try:
+                with torch.cuda.graph(graph):
+                    # under pipeline parallelism the stage-to-stage ncclRecv / ncclSend and the logits broadcast are graph
+                    # nodes too (RCCL enqueues on the capturing stream): a replay needs no Python per token on any rank
+                    st["out"] = self._logits(st["ids"], seqlens, cache)
+            except RuntimeError as e:
+                # a runtime that refuses to capture (an RCCL build without graph support, a debug allocator ...): this
+                # context degrades to launch-by-launch steps instead of failing the generation
+                logging.warning("decode step not graph-capturable (%s): continuing eagerly", e)
+                cache._seen = seen
+                self._graphed = None
+                return self._logits(input_ids, seqlens, cache)
             cache._seen = seen  # capture enqueues nothing: the step itself is the first replay below
             st["graph"] = graph
         else:
