@@ -443,3 +443,20 @@ def test_module_level_decode_with_cache(name, tmp_path):
         ref = case.t[f"decode_logits.{step}"]
         assert float((logits - ref).abs().max()) <= LOGIT_ATOL, (step, float((logits - ref).abs().max()))
     assert cache.kv_seqlens.tolist() == [n + 3 for n in lens]
+
+
+def test_out_of_range_token_id_raises_index_error(tmp_path):
+    """nn.Embedding raises IndexError on an id >= vocab (reference transformer.py:193).  Host-resident ids raise before the
+    launch; ids that only exist on the device are flagged by the embedding kernel and raised by generate() at its final
+    synchronisation - never a silent clamp."""
+    case = Case("dense_bf16")
+    w = {k: v.to(BF) for k, v in mo.synth_weights(case.args, seed=case.meta["seed"], dtype=BF).items()}
+    m = _load(tmp_path, case.args, w)
+    V = case.args.vocab_size
+    with pytest.raises(IndexError):
+        m.forward(torch.tensor([1, V, 3]), [3])                      # CPU tensor: checked on the host
+    from mistral_inference.generate import generate
+    with pytest.raises(IndexError):
+        generate([[1, 5, V + 7, 9]], m, max_tokens=2, temperature=0.0)  # device tensor inside generate(): kernel flag
+    toks, _ = generate([[1, 5, 9]], m, max_tokens=2, temperature=0.0)   # the flag was consumed: the model is usable again
+    assert len(toks[0]) == 2

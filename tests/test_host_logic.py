@@ -173,3 +173,23 @@ def test_interleave_kv_and_unrotate_semantics():
     assert torch.equal(unrotate(ck[3], 10), hist[3][6:]) and torch.equal(unrotate(ck[1], 3), hist[1])
     fresh = CacheView(ck, cv, md, torch.zeros(B, dtype=torch.long))
     assert fresh.interleave_kv(xk, xk)[0] is xk   # nothing cached: the inputs come back (cache.py:101-103)
+
+
+def test_out_of_range_token_ids_raise_like_nn_embedding():
+    """Host-resident ids are validated before any launch (reference: nn.Embedding raises IndexError, transformer.py:193);
+    device-resident ids are flagged by the kernel instead (tests/test_gpu_model.py)."""
+    import pytest as _pytest
+    import torch as _torch
+    from mistral_inference import _hip
+    _hip.check_ids_on_host(_torch.tensor([0, 5, 511]), 512)
+    _hip.check_ids_on_host(_torch.tensor([], dtype=_torch.long), 512)
+    for bad in ([512], [3, -1]):
+        with _pytest.raises(IndexError):
+            _hip.check_ids_on_host(_torch.tensor(bad), 512)
+
+
+def test_pipeline_transport_selection_without_a_gpu_process_group():
+    """No "nccl" group on a GPU -> the reference's own torch.distributed transport object (what the gloo tests drive)."""
+    import torch as _torch
+    from mistral_inference.distributed import TorchDistComm, pipeline_comm
+    assert isinstance(pipeline_comm(_torch.device("cpu")), TorchDistComm)
