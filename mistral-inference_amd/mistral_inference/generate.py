@@ -60,7 +60,10 @@ def generate(
     for s in range(0, max_prompt_len, chunk_size):
         prompt_chunks = [p[s: s + chunk_size] for p in encoded_prompts]
         assert all(len(p) > 0 for p in prompt_chunks)
-        flat = torch.tensor(sum(prompt_chunks, []), device=dev, dtype=torch.long)
+        flat_ids = sum(prompt_chunks, [])
+        if min(flat_ids) < 0 or max(flat_ids) >= V:  # the prompt is host data: raise where nn.Embedding would (transformer.py:193)
+            raise IndexError("index out of range in self")
+        flat = torch.tensor(flat_ids, device=dev, dtype=torch.long)
         # token i+1 of each chunk is scored by position i
         rows, cols, owners = [], [], []
         offset = 0

@@ -457,6 +457,11 @@ def test_out_of_range_token_id_raises_index_error(tmp_path):
         m.forward(torch.tensor([1, V, 3]), [3])                      # CPU tensor: checked on the host
     from mistral_inference.generate import generate
     with pytest.raises(IndexError):
-        generate([[1, 5, V + 7, 9]], m, max_tokens=2, temperature=0.0)  # device tensor inside generate(): kernel flag
-    toks, _ = generate([[1, 5, 9]], m, max_tokens=2, temperature=0.0)   # the flag was consumed: the model is usable again
+        generate([[1, 5, V + 7, 9]], m, max_tokens=2, temperature=0.0)  # prompts are host data: raised before any launch
+    # ids that exist only on the device: the embedding kernel flags them, the next health check raises
+    m.forward(torch.tensor([1, V + 7, 3], device="cuda"), [3])
+    with pytest.raises(IndexError):
+        m._backend.raise_if_flagged()
+    m._backend.raise_if_flagged()                                       # the flag was consumed
+    toks, _ = generate([[1, 5, 9]], m, max_tokens=2, temperature=0.0)   # ... and the model is usable again
     assert len(toks[0]) == 2
