@@ -86,6 +86,9 @@ SHAPES = {
                           vocab_size=514, sliding_window=None),
     "gqa2_long_ring": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=8, n_kv_heads=4, norm_eps=1e-6,
                            vocab_size=2048, sliding_window=1200),
+    # per-layer window list (reference args.py:55-59 / cache.py:13-24): layer 0 keeps 16 slots, layer 1 the whole sequence
+    "window_list": dict(dim=512, n_layers=2, head_dim=128, hidden_dim=1024, n_heads=4, n_kv_heads=1, norm_eps=1e-5,
+                        vocab_size=512, sliding_window=[16, None]),
     # an 8.3K-slot ring: 31 splits of 272 slots = 136 K/V pieces per CU, more than the LDS ring holds at once
     "ring_longer_than_lds": dict(dim=512, n_layers=1, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
                                  vocab_size=640, sliding_window=None),
@@ -97,7 +100,7 @@ def test_engine_bit_equal_launch_path(name):
     p = SHAPES[name]
     args = mo.OracleArgs(**p)
     m, _ = _model(args, seed=11)
-    W = p["sliding_window"] or 10 ** 9
+    W = p["sliding_window"] if isinstance(p["sliding_window"], int) else 10 ** 9
     prompt_len = 40 if W < 100 else 300  # 40 + steps crosses the 48-slot ring; 300 leaves later splits empty in a 1200 ring
     steps = 12
     if name == "ring_longer_than_lds":
@@ -112,6 +115,18 @@ def test_engine_bit_equal_launch_path(name):
         assert torch.equal(a, b), (name, i, float((a - b).abs().max()))
     for l, ((k0, v0), (k1, v1)) in enumerate(zip(ref_rings, got_rings)):
         assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
+
+
+def test_engine_right_after_a_one_token_prompt():
+    """kv_len = 2, 3, ...: every split but the first is empty, the current slot is the only other key."""
+    p = SHAPES["gqa4_window_wraps"]
+    m, _ = _model(mo.OracleArgs(**p), seed=2)
+    ids = torch.randint(0, p["vocab_size"], (6,), generator=torch.Generator().manual_seed(8)).cuda()
+    ref, ref_rings, _ = _run(m, ids, 1, 5, engine=False)
+    got, got_rings, st = _run(m, ids, 1, 5, engine=True)
+    assert st["status"] == 0 and st["engine_launches"] >= 5
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    assert all(torch.equal(k0, k1) and torch.equal(v0, v1) for (k0, v0), (k1, v1) in zip(ref_rings, got_rings))
 
 
 def test_engine_summation_order_fingerprint():
