@@ -245,8 +245,9 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
  * 100 MHz clock at each phase boundary of each layer: trace[cu][layer (32)][event (26)] uint64.  NULL unregisters. */
 size_t mi_debug_engine_trace_bytes(void);
 int mi_debug_set_engine_trace(void* dev_buffer);
-/* Tuning knobs of the engine's loader wave (results never depend on them): thin = 1 keeps one 16 KiB fill outstanding
- * while the workgroup's consumers sweep hand-off granules (0: never); depth = fills in flight otherwise (2 or 3).
+/* Tuning knobs of the engine's loader wave (results never depend on them): while the workgroup's consumers
+ * sweep hand-off granules the loader wave stops (thin = 2, shipped), keeps one 16 KiB fill outstanding (1) or streams on
+ * (0); depth = fills in flight otherwise (2 or 3).
  * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults. */
 int mi_debug_set_engine_knobs(int thin, int depth);
 

@@ -193,7 +193,16 @@ struct Loader {
   // After the last piece of a fill: retire older fills (DMA completes in order; 16 instructions per fill).
   __device__ __forceinline__ void fill_end() {
     const uint32_t f = g / FILL;  // fills issued so far
-    if (thin && sh.ctl[C_GATHERING]) {  // thin the stream while this CU's consumers sweep granules (gather-pass row)
+    if (thin >= 2 && sh.ctl[C_GATHERING]) {
+      // STOP the stream while this CU's consumers sweep granules: the sweep's loads queue in the CU's vector memory
+      // pipeline behind whatever the loader has in flight, and the hand-off is the critical path - the ring is full
+      // for most of that wait anyway (2.70-2.75 ms against 2.74-2.79 ms with one fill kept in flight, same box)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish(f);
+      uint32_t spins = 0;
+      while (sh.ctl[C_GATHERING])
+        if (!spin_ok(sh, spins, 0x100)) break;
+    } else if (thin && sh.ctl[C_GATHERING]) {  // thin == 1: keep one fill in flight during sweeps (A/B)
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       publish(f - 1);
     } else if (depth >= 3) {
@@ -945,7 +954,7 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
   a.trace = (unsigned long long*)g_trace;
   if (g_thin < 0) {
     const char* e = getenv("MI_ENGINE_THIN");
-    g_thin = e ? atoi(e) : 1;
+    g_thin = e ? atoi(e) : 2;  // 0 stream through sweeps, 1 one fill in flight, 2 stop (measured best)
   }
   if (g_depth < 0) {
     const char* e = getenv("MI_ENGINE_DEPTH");

@@ -190,7 +190,7 @@ struct EngArgs {
   int NB, ring_fills;
   int seq_base;           // global index of this launch's first layer (tag sequence)
   int first, head;
-  int thin, depth;        // loader knobs (A/B): thin the stream during hand-off sweeps; fills in flight (2 or 3)
+  int thin, depth;        // loader knobs (A/B): during hand-off sweeps 0 stream / 1 one fill in flight / 2 stop; fills in flight (2 or 3)
   float eps;
   bf16_t* h;              // [D] residual stream, in (first layer) / out (last layer)
   const float* rope_cs;

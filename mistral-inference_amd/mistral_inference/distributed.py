@@ -9,6 +9,7 @@ can be captured in the decode step's hipGraph.  `torch.distributed` remains the 
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 from typing import Optional
 
@@ -89,9 +90,21 @@ class TorchDistComm:
 
 def pipeline_comm(device: torch.device):
     """Transport for a pipeline rank on `device`: RCCL through the C ABI on a GPU under the "nccl" process group (the
-    production path), torch.distributed otherwise."""
+    production path), torch.distributed otherwise.  Whether librccl can be loaded is probed locally on every rank
+    (`mi_rccl_unique_id` needs no peer) and AGREED through the process group before anyone enters the collective
+    communicator init: a rank that cannot load it would otherwise leave the others waiting in `ncclCommInitRank`."""
     want = os.environ.get("MI_PP_TRANSPORT", "rccl")
-    if (want == "rccl" and device.type == "cuda" and torch.distributed.is_initialized()
-            and torch.distributed.get_backend() == "nccl"):
-        return RcclComm.from_process_group()
+    dist = torch.distributed
+    if want == "rccl" and device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl":
+        err = None
+        try:
+            RcclComm.unique_id()
+        except (RuntimeError, OSError, AttributeError) as e:
+            err = e
+        flag = torch.tensor([0 if err else 1], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return RcclComm.from_process_group()
+        logging.getLogger(__name__).warning(
+            "RCCL through the C ABI is unavailable on at least one rank (%s): pipeline hops use torch.distributed", err)
     return TorchDistComm()

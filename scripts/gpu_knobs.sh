@@ -1,8 +1,21 @@
 #!/bin/bash
+# A/B of the engine's runtime knobs on one box.  MI_ENGINE_THIN bits: 1 thin / 2 stop the loader during sweeps, 4 arrival flags
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-for knobs in "1 3" "0 3" "1 2" "0 2"; do
-  set -- $knobs
-  echo "== thin=$1 depth=$2"
-  MI_ENGINE_THIN=$1 MI_ENGINE_DEPTH=$2 timeout 600 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
-done 2>&1 | tee gpurun_out/knobs.log
+LOG=gpurun_out/knobs.log
+: > $LOG
+run() { echo "== $*" | tee -a $LOG; env "$@" timeout 120 python bench.py --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/v.out 2>&1; tail -1 gpurun_out/v.out | cut -c1-170 | tee -a $LOG; }
+for rep in 1 2; do
+  for t in ${KNOBS:-2 6}; do
+    run MI_ENGINE_THIN=$t
+    python - <<'PY' || exit 1
+import json,sys
+try:
+    ms=json.loads(open("gpurun_out/v.out").read().strip().splitlines()[-1])["ms_per_step"]
+except Exception as e:
+    print("no bench line", e); sys.exit(1)
+sys.exit(0 if ms < 10 else 1)
+PY
+  done
+done
+MI_ENGINE_THIN=6 timeout 300 python -m pytest tests/test_gpu_engine.py -q -x 2>&1 | tail -3 | tee -a $LOG
