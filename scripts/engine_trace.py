@@ -89,7 +89,41 @@ def main():
     seg = (t[:, 2:nl - 2, 23] - t[:, 2:nl - 2, 18]) * us
     print("loader time per layer: mean %.2f us, min %.2f, max %.2f  (1.70 MB per CU per layer -> %.1f GB/s per CU, %.2f TB/s chip)"
           % (seg.mean(), seg.min(), seg.max(), 1.70e6 / seg.mean() / 1e3, 1.70e6 / seg.mean() / 1e3 * nb / 1e3))
+    handoffs(t, nl)
+
+
+def handoffs(t, nl):
+    """Every hand-off of a layer split into the part that is SKEW (how long after the median CU the slowest producer
+    finished its phase) and the part that is LATENCY (first consumer through its sweep - last producer done), from the
+    stamps of consumer wave 0 of every CU.  Usable offline: `engine_trace.py --analyze gpurun_out/engine_trace.npy`."""
+    us = 0.01
+    mid = range(2, max(3, nl - 2))
+    edges = [("W2 rows (prev) -> h", 16, 1, True), ("q|k|v rows -> q", 3, 5, False), ("partials -> merge", 7, 8, False),
+             ("merged -> attn", 9, 10, False), ("Wo rows -> h1", 11, 12, False), ("W1|W3 rows -> hid", 14, 15, False)]
+    print("\nhand-offs (us, middle layers): producers' skew max-median | first sweep done - last producer done | "
+          "median consumer's wait (median gathered - median producer end)")
+    total = 0.0
+    for name, pe, ce, prev in edges:
+        sk, lat, wait = [], [], []
+        for l in mid:
+            p = t[:, l - 1, pe] if prev else t[:, l, pe]
+            c = t[:, l, ce]
+            ok = (p > 0) & (c > 0)
+            if not ok.any():
+                continue
+            p, c = p[ok] * us, c[ok] * us
+            sk.append(p.max() - np.median(p))
+            lat.append(c.min() - p.max())
+            wait.append(np.median(c) - np.median(p))
+        if wait:
+            print(f"  {name:20s} {np.mean(sk):6.2f} | {np.mean(lat):6.2f} | {np.mean(wait):6.2f}")
+            total += np.mean(wait)
+    print(f"  sum of the median waits: {total:.1f} us per layer")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--analyze":
+        _t = np.load(sys.argv[2])
+        handoffs(_t, _t.shape[1])
+    else:
+        main()
