@@ -39,7 +39,11 @@ namespace {
 using namespace attn_core;
 
 constexpr int NCONS = 4;
-constexpr int NTHREADS = (NCONS + 1) * 64;
+#ifndef ENG_HOLDERS
+#define ENG_HOLDERS 3  // holder waves per workgroup (0: none)
+#endif
+constexpr int NHOLD = ENG_HOLDERS;
+constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
 constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
 constexpr int FILL = 16;             // pieces per fill
 constexpr int RING_FILLS = 8;        // 128 KiB ring
@@ -69,7 +73,10 @@ enum : int {
   C_CBAR = 5,       // consumer-wave barrier counter
   C_GATHERING = 6,  // consumers are sweeping granules: the loader keeps one fill outstanding
   C_ABORT = 7,
-  C_RED = 8         // [4] fp32 wave totals of the RMSNorm
+  C_RED = 8,        // [4] fp32 wave totals of the RMSNorm
+  C_LSTAGE = 12,    // loader progress: (layer + 1) once this layer's Wo rows are issued (loader -> holders)
+  C_XREADY = 13,    // (layer + 1) once ffn_norm(h1) of that layer stands in the activation region (consumers -> holders)
+  C_HDONE = 14      // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
 };
 
 // Optional timeline (mi_debug_set_engine_trace): trace[c][layer][event] = 100 MHz wall clock.  Consumer wave 0 writes
@@ -157,6 +164,16 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
 
 // pieces per group of a unit's interleaved stream (loader and consumers must agree)
 __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P & 1) == 0 ? 2 : 1); }
+
+// HOLDER waves: the last holder_units() W1|W3 units of a CU's slab never pass through the ring.  A holder wave fetches
+// its unit (4 rows x D bf16 = 32 KiB at D = 4096) straight into 128 of its VGPRs while the attention block of the layer
+// keeps the consumers busy with hand-offs and the ring is full, and reduces it from registers when ffn_norm(h1) arrives:
+// 96 KiB per CU and layer that the loader no longer has to squeeze through the HBM-bound W1|W3 phase.
+constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
+__device__ __forceinline__ int holder_units(int D, int n_f) {
+  const int P = D >> 9;
+  return (NHOLD > 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
+}
 
 // ------------------------------------------------------------------------------------------------ loader wave
 struct Loader {
@@ -296,7 +313,9 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     trace_ev(sh, c, l, TR_CONS + 2, tr);
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
-    for (int j = p.f0; j < p.f1; ++j) {
+    if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
+    const int f_ring = p.f1 - holder_units(a.D, p.f1 - p.f0);
+    for (int j = p.f0; j < f_ring; ++j) {
       const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
       const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
       ld.template unit<4>(rp, a.D >> 9);
@@ -554,6 +573,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   const int PD = a.D >> 9, PA = (a.H * DH) >> 9, PF = a.F >> 9;
   const int nq = a.H * DH, nkv = a.Hkv * DH;
   uint32_t g = 0;  // first piece of the current segment
+  uint32_t hold_target = 0;  // W1|W3 units the holder waves must have finished (cumulative)
   auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
 
   // attention scratch inside the activation region (free between the q|k|v rows and the Wo gather)
@@ -774,8 +794,10 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 12, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
+    const int n_hold = holder_units(a.D, p.f1 - p.f0);
+    if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
     {
-      const int n_u = p.f1 - p.f0;
+      const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
       for (int k = w; k < n_u; k += NCONS) {
         const uint32_t ga = g + (uint32_t)(4 * k) * PD;
         cs.set_done(ga);
@@ -794,6 +816,12 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
     // ================================================================ h = h1 + hid @ W2^T
     cs.cbar();
+    if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
+      hold_target += (uint32_t)n_hold;
+      uint32_t spins = 0;
+      while (sh.ctl[C_HDONE] < hold_target)
+        if (!spin_ok(sh, spins, 0x500)) break;
+    }
     sh.ctl[C_GATHERING] = 1;
     cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
     cs.cbar();
@@ -851,6 +879,71 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   cs.set_done(0xffffffffu);
 }
 
+// ------------------------------------------------------------------------------------------------ holder waves
+// Holder hi owns W1|W3 unit f1 - n_hold + hi of every layer (rows w1[2j], w3[2j], w1[2j+1], w3[2j+1]).  Same arithmetic
+// as Cons::unit_dot<4>: per row, pieces in ascending order, four dot2_bf16 per piece, then wave_sum - bit-identical.
+__device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, uint32_t epoch) {
+  gu64* G = (gu64*)a.gran;
+  const int PD = a.D >> 9;
+  const lchar* xl = sh.xs + lane * 16;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const EngLayer& L = a.L[l];
+    LayerPlan p;
+    plan_layer(a, L, c, pos, p);
+    const int n_hold = holder_units(a.D, p.f1 - p.f0);
+    if (hi >= n_hold) continue;
+    const int j = p.f1 - n_hold + hi;
+    uint32_t spins = 0;
+    while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
+      if (!spin_ok(sh, spins, 0x600)) return;
+    const size_t r0 = (size_t)(2 * j) * a.D + lane * 8;
+    const bf16_t* rows[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r0 + a.D, L.w3 + r0 + a.D};
+    u32x4 hw[HOLD_GROUPS][4][4];  // [group][row][piece in group]: constant indices only -> registers
+#pragma unroll
+    for (int grp = 0; grp < HOLD_GROUPS; ++grp) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
+        spins = 0;
+        while (sh.ctl[C_GATHERING])
+          if (!spin_ok(sh, spins, 0x600)) return;
+#pragma unroll
+        for (int r = 2 * half; r < 2 * half + 2; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int piece = min(grp * 4 + q, PD - 1);  // groups beyond the row are never used (holder_units: PD <= 8)
+            hw[grp][r][q] = ld16_nt(rows[r] + (size_t)piece * 512);
+          }
+      }
+    }
+    spins = 0;
+    while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
+      if (!spin_ok(sh, spins, 0x600)) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int grp = 0; grp < HOLD_GROUPS; ++grp)
+      if (grp * 4 < PD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32x4 xv = lds16(xl + (grp * 4 + q) * PIECE);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(hw[grp][r][q][i], xv[i], acc[r]);
+        }
+      }
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+      const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 5 + 1);
+      const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(v[0], v[1])) | ((uint32_t)f_to_bf(swiglu_bf(v[2], v[3])) << 16);
+      __hip_atomic_store(G + a.g_hid + j, ((unsigned long long)tag << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the LDS reads of x above were consumed by the dots: the region may be overwritten once every holder says so
+      __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
 template <int R>
 __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -873,6 +966,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int seq = a.tok_seq ? a.tok_seq[0] : 0;
   const uint32_t epoch = __hip_atomic_load(sh.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffffu;
   if (w == NCONS) run_loader(a, sh, c, lane, pos, seq);
+  else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
   else run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch);
   // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
   if (c == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(sh.ctrl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
