@@ -170,9 +170,9 @@ __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P
 // keeps the consumers busy with hand-offs and the ring is full, and reduces it from registers when ffn_norm(h1) arrives:
 // 96 KiB per CU and layer that the loader no longer has to squeeze through the HBM-bound W1|W3 phase.
 constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
-__device__ __forceinline__ int holder_units(int D, int n_f) {
-  const int P = D >> 9;
-  return (NHOLD > 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
+__device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
+  const int P = a.D >> 9;
+  return (NHOLD > 0 && a.holders && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ loader wave
@@ -314,7 +314,7 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
     if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
-    const int f_ring = p.f1 - holder_units(a.D, p.f1 - p.f0);
+    const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
     for (int j = p.f0; j < f_ring; ++j) {
       const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
       const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
@@ -794,7 +794,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 12, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
-    const int n_hold = holder_units(a.D, p.f1 - p.f0);
+    const int n_hold = holder_units(a, p.f1 - p.f0);
     if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
     {
       const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
@@ -890,7 +890,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     const EngLayer& L = a.L[l];
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
-    const int n_hold = holder_units(a.D, p.f1 - p.f0);
+    const int n_hold = holder_units(a, p.f1 - p.f0);
     if (hi >= n_hold) continue;
     const int j = p.f1 - n_hold + hi;
     uint32_t spins = 0;
@@ -1056,6 +1056,12 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
   }
   a.thin = g_thin;
   a.depth = g_depth;
+  static int holders = -1;
+  if (holders < 0) {
+    const char* e = getenv("MI_ENGINE_HOLDERS");
+    holders = e ? (atoi(e) != 0) : 1;
+  }
+  a.holders = holders;
   a.D = pr.D; a.H = pr.H; a.Hkv = pr.Hkv; a.F = pr.F; a.V = pr.V; a.eps = pr.eps; a.NB = pr.NB;
   const int Rtot = pr.H / pr.Hkv;
   a.R = attn_decode_group(Rtot);

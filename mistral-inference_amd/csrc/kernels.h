@@ -191,6 +191,7 @@ struct EngArgs {
   int seq_base;           // global index of this launch's first layer (tag sequence)
   int first, head;
   int thin, depth;        // loader knobs (A/B): during hand-off sweeps 0 stream / 1 one fill in flight / 2 stop; fills in flight (2 or 3)
+  int holders;            // 1: holder waves take the last W1|W3 units of every CU's slab (A/B: MI_ENGINE_HOLDERS=0)
   float eps;
   bf16_t* h;              // [D] residual stream, in (first layer) / out (last layer)
   const float* rope_cs;
