@@ -248,7 +248,8 @@ int mi_debug_set_engine_trace(void* dev_buffer);
 /* Tuning knobs of the engine's loader wave (results never depend on them): while the workgroup's consumers
  * sweep hand-off granules the loader wave stops (thin = 2, shipped), keeps one 16 KiB fill outstanding (1) or streams on
  * (0); depth = fills in flight otherwise (2 or 3).
- * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults. */
+ * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults.  MI_ENGINE_HOLDERS=0 (environment, read
+ * once) runs the engine without its holder waves. */
 int mi_debug_set_engine_knobs(int thin, int depth);
 
 /* ------------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@
 // the HBM stream never stops at a dependency (cdna_hip_programming.md section 5.6, MI355X_MICROARCH.md rows
 // prefetch-credit / engine-vs-launches):
 //
-//   * grid = one workgroup per CU (5 waves): wave 4 is the LOADER, waves 0-3 are CONSUMERS.
+//   * grid = one workgroup per CU (8 waves): waves 0-3 are CONSUMERS, wave 4 is the LOADER, waves 5-7 are HOLDERS
+//     (each keeps one W1|W3 unit of the layer in registers, fetched while the attention block runs: holder_units()).
 //   * The loader walks a fixed per-CU program - this CU's row slab of Wq|Wk|Wv, its K/V ring slice, its rows of Wo,
 //     W1|W3, W2 for every layer, then of the LM head - and copies it HBM -> LDS with `global_load_lds_dwordx4` (1 KiB
 //     "pieces", non-temporal) into a ring of 8 x 16 KiB "fills".  Weights and old K/V do not depend on activations, so
