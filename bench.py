@@ -107,10 +107,11 @@ def _pmc_traffic(kernel_substr: str, dims_ok: bool):
 
 def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
     """The dominant kernel of the timed path is the persistent decode engine: ONE `decode_engine_kernel` launch per
-    token streams every local layer's weights, the K/V rings and the LM head.  Algorithmic bytes per launch = SURVEY.md
-    8(d)'s bytes per token at this context; launch duration = HIP events on the launch stream around `iters` eager decode
-    steps (each = the decode-prep/embedding kernel, ~2 us, + the engine launch), which is what `rocprofv3 --kernel-trace
-    --stats` reports for the kernel (profiles/)."""
+    token streams every local layer's weights, the K/V rings and the LM head (and does the step's bookkeeping: position,
+    embedding row, greedy sample - there is no other launch in a step).  Algorithmic bytes per launch = SURVEY.md 8(d)'s
+    bytes per token at this context; launch duration = HIP events on the launch stream around `iters` eager decode steps
+    = `iters` back-to-back engine launches, which is what `rocprofv3 --kernel-trace --stats` reports for the kernel
+    (profiles/)."""
     dev = model.device
     stream = torch.cuda.current_stream(dev)
     for _ in range(2):
@@ -128,7 +129,8 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
     dims_ok = (model.args.dim, model.args.hidden_dim, model.args.n_layers) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"], MISTRAL_7B["n_layers"])
     traffic, traffic_src = _pmc_traffic("decode_engine_kernel", dims_ok)
-    return {"bound": "hbm", "kernel": "decode_engine_kernel<4> (persistent: all layers + LM head of one decode step in one launch)",
+    group = model.args.n_heads // model.args.n_kv_heads
+    return {"bound": "hbm", "kernel": f"decode_engine_kernel<{group}> (persistent: all layers + LM head + sample of one decode step in one launch)",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(us, 2), "launches_timed": iters}
@@ -258,6 +260,8 @@ def main() -> None:
     ap.add_argument("--model", default="mistral-7b", choices=sorted(PRESETS), help="default = BASELINE configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue decode steps launch by launch (no hipGraph replay)")
+    ap.add_argument("--loop", default="greedy", choices=["greedy", "forward"],
+                    help="greedy: generate()'s temperature-0 loop (sample fused into the step); forward: forward() + torch.argmax per token")
     opt = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -307,16 +311,36 @@ def main() -> None:
         del logits
         # ---- decode: the generate() loop body - forward(next_token, [1], cache) under the decode hipGraph context
         # (capture happens inside the warm-up steps; W >= 2 keeps it out of the timed region)
-        ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
-        with ctx:
-            for _ in range(max(Wm, 2)):
-                nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+        if world == 1 and opt.loop == "greedy":
+            # generate()'s temperature-0 loop body (mistral_inference/generate.py -> Transformer.greedy_session): one
+            # native call per token - argmax + log-softmax are the LM head's epilogue, the sample feeds the next step on
+            # the device - replayed from a hipGraph.  Nothing of the step is skipped: logits [1, V] are written every step.
+            sess = model.greedy_session(cache, nxt, graph=not opt.no_graph)
+            sess.run(max(Wm, 2))
+            sess.collect()
             sync()
-            t0 = time.perf_counter()
-            for _ in range(K):
-                nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
-            sync()
-            dt = time.perf_counter() - t0
+            dt, left = 0.0, K
+            while left > 0:                      # (the session's history ring holds 1024 steps between collects)
+                n = min(left, sess.HIST)
+                t0 = time.perf_counter()
+                sess.run(n)
+                sync()
+                dt += time.perf_counter() - t0
+                toks, _ = sess.collect()         # verifies that the device completed every step (and which path ran)
+                left -= n
+            nxt = toks[-1]
+        else:
+            # the sampling loop's body (temperature > 0, or pipeline stages): forward() under the decode hipGraph + torch.argmax
+            ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
+            with ctx:
+                for _ in range(max(Wm, 2)):
+                    nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(K):
+                    nxt = torch.argmax(model.forward(nxt, [1], cache), dim=-1)
+                sync()
+                dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt, prefill_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -330,6 +354,7 @@ def main() -> None:
     def decode_launch_label() -> str:
         # the engine counts its own launches in the workspace: that is how we know which path was timed
         kind = "persistent decode engine (1 launch per token)" if engine["engine_launches"] > 0 else "6 launches per layer"
+        kind += ", greedy sample fused into the step" if (world == 1 and opt.loop == "greedy") else ", forward() + torch.argmax"
         from mistral_inference.distributed import RcclComm
         eager = opt.no_graph or (world > 1 and not isinstance(model.pp_comm, RcclComm))
         return kind + (", eager" if eager else ", hipGraph replay")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
@@ -93,6 +93,11 @@ int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const vo
 size_t mi_lm_head_logprobs_scratch_bytes(int M, int vocab);
 int mi_lm_head_logprobs(float* logprob, const void* x, int ldx, int M, int K, const void* w, int vocab,
                         const int32_t* target, void* scratch, size_t scratch_bytes, mi_stream_t stream);
+
+/* generate.py:124 + :134-136 at temperature 0 for B rows of fp32 logits [B, ld]: token[b] = FIRST index of the row maximum
+ * (torch.argmax), logprob[b] = log_softmax(row)[token[b]] - one block per row.  mi_forward fuses the same reduction
+ * behind its LM head (mi_batch_t.greedy_token). */
+int mi_greedy_sample(const float* logits, int ld, int B, int vocab, int64_t* token, float* logprob, mi_stream_t stream);
 
 /* Decode-branch attention (transformer_layers.py:77-89 with the mask of cache.py:249-254):
  * one query per sequence, keys = ring slots [0, min(pos+1, W)) of its row, GQA by kv = h / (H/Hkv)
@@ -218,6 +223,22 @@ typedef struct mi_batch {
   float* logits;                /* dev [T, V] fp32 or NULL (transformer.py:235-242) */
   void* workspace;              /* dev scratch, >= mi_workspace_bytes(model, T, B, max W) */
   size_t workspace_bytes;
+  /* ABI v4 - greedy sampling fused behind the LM head (generate.py:124 `torch.argmax(logits)` and :134-136
+   * `log_softmax(logits)[token]` at temperature 0).  Optional (NULL: not computed); DECODE branch with `logits` only.
+   *   greedy_token[b]   = first index of the maximum of logits[b, :]            (torch.argmax's tie rule)
+   *   greedy_logprob[b] = log_softmax(logits[b, :])[greedy_token[b]]
+   * `input_ids` MAY ALIAS `greedy_token`: the ids are consumed before the outputs are written, so a caller can chain
+   * steps (the next step's input is this step's sample) without any copy between two mi_forward calls - the shape of
+   * generate()'s greedy loop, and of a captured hipGraph that is replayed once per token.
+   * hist_token / hist_logprob: optional rings [hist_len, B]; the step's sample is also stored at row
+   * (steps % hist_len), `steps` being the number of decode steps this workspace has run before this one
+   * (mi_decode_engine_status word 5; the caller may zero that word) - so a generation loop reads its tokens back in
+   * ONE copy at the end instead of one per step (generate.py:137 `generated_tensors.append`). */
+  int64_t* greedy_token;        /* dev [B] or NULL */
+  float* greedy_logprob;        /* dev [B] */
+  int64_t* hist_token;          /* dev [hist_len, B] or NULL */
+  float* hist_logprob;          /* dev [hist_len, B] or NULL */
+  int32_t hist_len;
 } mi_batch_t;
 
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);
@@ -232,13 +253,28 @@ int mi_forward(const mi_model_t* model, const mi_batch_t* batch, mi_stream_t str
  * mi_set_decode_engine(0) forces the launch path (A/B measurements, tests); returns the previous setting.  Initial value:
  * environment MI_DECODE_ENGINE (default 1). */
 int mi_set_decode_engine(int enabled);
+/* Residency.  The engine's workgroups wait for each other, so all of them (one per CU) must be resident at once; a plain
+ * launch checks nothing.  Two guards: (1) before its first use on a device the library runs a census kernel with the
+ * engine's launch shape (one stream synchronisation, outside any capture): if the workgroups do not all meet - a CU mask, a
+ * partition mode, a co-tenant - the engine is not used on that device and mi_forward takes the launch path;
+ * mi_decode_engine_census(1) forgets the verdicts (tests, or after the device's situation changed).  (2) Every engine
+ * launch repeats the census on itself before its first side effect; if it fails, the launch ends having written NOTHING
+ * (no ring row, no position advance, no sample), raises status word 1 = 0x700, and every later engine launch on that
+ * workspace leaves at once until the caller has run mi_decode_engine_reset - the device state stays exactly that of the
+ * first failed step, which the caller can therefore re-run on the launch path (mi_set_decode_engine(0)); the number of
+ * steps that did complete is status word 5.  Timeouts AFTER the census (codes 0x100-0x600) should not exist; they poison
+ * the workspace the same way but may leave a half-written step. */
+int mi_decode_engine_census(int forget);
+int mi_decode_engine_reset(void* workspace, mi_stream_t stream);
 /* Copies the engine's control words out of a workspace and synchronises `stream` (a health check, NOT part of the hot
  * path): status[0] = step epoch, status[1] = 0 or the code of the first bounded wait that ever timed out
- * (0x100 loader / 0x200 ring / 0x300 consumer barrier / 0x400 hand-off sweep), status[2] = abort flag of the last step,
+ * (0x100 loader / 0x200 ring / 0x300 consumer barrier / 0x400 hand-off sweep / 0x500-0x600 holder waves / 0x700 residency
+ * census of a step: nothing was written), status[2] = abort flag of the last step,
  * status[3] = 0 or 1 + the index of a token whose id was outside [0, vocab) in some mi_forward call (sticky until the
  * caller zeroes the word: the host raises the reference's IndexError from it), status[4] = launches completed by the
  * engine since the workspace was zeroed (one per <= 32 layers of a decode step; unchanged when the launch path ran),
- * status[5..7] reserved. */
+ * status[5] = decode steps run on this workspace (engine: completed; launch path: started) = next row of the greedy
+ * history ring, status[6] = workgroup arrivals of the current engine step, status[7] reserved. */
 int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[8]);
 /* Debug timeline of the engine (scripts/engine_trace.py): while a zero-filled device buffer of
  * mi_debug_engine_trace_bytes() bytes is registered, consumer wave 0 and the loader wave of every workgroup stamp a
@@ -251,6 +287,11 @@ int mi_debug_set_engine_trace(void* dev_buffer);
  * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults.  MI_ENGINE_HOLDERS=0 (environment, read
  * once) runs the engine without its holder waves. */
 int mi_debug_set_engine_knobs(int thin, int depth);
+/* holder waves on (1) / off (0) / environment default (-1); results never depend on it (bit-identical either way) */
+int mi_debug_set_engine_holders(int on);
+/* Test hook: the next `launches` engine launches wait for one workgroup more than exist, i.e. fail their residency gate
+ * after its ~50 ms bound exactly as a launch with a missing workgroup would (status 0x700, nothing written). */
+int mi_debug_engine_sabotage(int launches);
 
 /* ------------------------------------------------------------------------------------------------
  * Pipeline-parallel exchange steps over RCCL (xGMI between the GPUs of a node)

@@ -428,6 +428,31 @@ int mi_set_decode_engine(int enabled) {
   return prev;
 }
 
+int mi_decode_engine_reset(void* workspace, mi_stream_t stream) {
+  if (!workspace) return fail(MI_ERR_ARG, "mi_decode_engine_reset");
+  hipStream_t s = (hipStream_t)stream;
+  // a raised status poisons the workspace (every later engine launch leaves at once): clear it, clear the abort broadcast
+  // and the arrival count, and move to an epoch whose tags no granule of the failed step can carry
+  MI_TRY(hip_rc(launch_engine_ctrl_reset(reinterpret_cast<uint32_t*>(workspace), s), "engine reset"));
+  return MI_OK;
+}
+
+int mi_greedy_sample(const float* logits, int ld, int B, int vocab, int64_t* token, float* logprob, mi_stream_t stream) {
+  if (!logits || !token || !logprob || B <= 0 || vocab <= 0 || ld < vocab) return fail(MI_ERR_ARG, "mi_greedy_sample");
+  return hip_rc(launch_greedy_rows(logits, ld, B, vocab, token, logprob, nullptr, nullptr, 0, nullptr, (hipStream_t)stream),
+                "greedy sample");
+}
+
+int mi_debug_engine_sabotage(int launches) {
+  decode_engine_sabotage(launches);
+  return MI_OK;
+}
+
+int mi_decode_engine_census(int forget) {
+  if (forget) decode_engine_forget_census();
+  return MI_OK;
+}
+
 int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[8]) {
   if (!workspace || !status) return fail(MI_ERR_ARG, "mi_decode_engine_status");
   MI_TRY(hip_rc(hipMemcpyAsync(status, workspace, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream), "status copy"));
@@ -437,6 +462,10 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
 size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(device_cus()); }
 int mi_debug_set_engine_knobs(int thin, int depth) {
   decode_engine_set_knobs(thin, depth);
+  return MI_OK;
+}
+int mi_debug_set_engine_holders(int on) {
+  decode_engine_set_holders(on);
   return MI_OK;
 }
 int mi_debug_set_engine_trace(void* dev_buffer) {
@@ -477,6 +506,41 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
   // embeddings of transformer.py:190-191 (text rows from mi_embedding, image rows from the vision tower)
   const bool embed = m->tok_embeddings && bt->input_ids;
   uint32_t* engine_ctrl = reinterpret_cast<uint32_t*>(ws.tickets);
+  const bool want_greedy = branch == MI_BRANCH_DECODE && bt->logits && bt->greedy_token && bt->greedy_logprob;
+  if (bt->greedy_token && !want_greedy)
+    return fail(MI_ERR_ARG, "mi_forward: greedy_token needs the DECODE branch, logits and greedy_logprob");
+  if (want_greedy && bt->hist_len > 0 && (!bt->hist_token || !bt->hist_logprob))
+    return fail(MI_ERR_ARG, "mi_forward: hist_len > 0 without history buffers");
+
+  // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch, which also does
+  // the step's bookkeeping (position, embedding row, greedy sample): nothing else is enqueued for the token
+  if (branch == MI_BRANCH_DECODE && T == 1 && B == 1 && m->num_experts == 0 && m->n_layers > 0 && engine_mode()) {
+    EngProblem pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.D = D; pr.H = H; pr.Hkv = Hkv; pr.F = F; pr.V = m->vocab_size; pr.n_layers = m->n_layers; pr.NB = device_cus();
+    pr.eps = m->norm_eps; pr.layers = m->layers; pr.cache_k = bt->cache_k; pr.cache_v = bt->cache_v; pr.W = bt->cache_sizes;
+    pr.h = h; pr.rope_cs = m->rope_cs;
+    pr.emb = embed ? m->tok_embeddings : nullptr; pr.ids = bt->input_ids; pr.kv_seqlens = bt->kv_seqlens;
+    pr.q_start = bt->q_start; pr.kv_before = bt->kv_before; pr.tok_seq = bt->tok_seq; pr.tok_pos = bt->tok_pos;
+    pr.final_norm = m->final_norm; pr.output = m->output; pr.logits = bt->logits;
+    if (want_greedy) {
+      pr.greedy_tok = bt->greedy_token; pr.greedy_lp = bt->greedy_logprob;
+      pr.hist_tok = bt->hist_token; pr.hist_lp = bt->hist_logprob; pr.hist_len = bt->hist_len;
+    }
+    pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
+    bool dense_ok = true;
+    for (int l = 0; l < m->n_layers; ++l) dense_ok = dense_ok && m->layers[l].w1 && m->layers[l].w2 && m->layers[l].w3;
+    if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
+      bool declined = false;
+      MI_TRY(hip_rc(launch_decode_engine(pr, s, &declined), "decode engine"));
+      if (!declined) {
+        if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        return MI_OK;
+      }
+      snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail());  // informational
+    }
+  }
+
   if (branch == MI_BRANCH_DECODE && embed) {
     MI_TRY(hip_rc(launch_decode_prep_embedding(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, h,
                                                m->tok_embeddings, bt->input_ids, D, m->vocab_size, engine_ctrl, s),
@@ -487,24 +551,6 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
                     "decode_prep"));
     if (embed)
       MI_TRY(hip_rc(launch_embedding(h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, engine_ctrl + 3, s), "embedding"));
-  }
-
-  // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch
-  if (branch == MI_BRANCH_DECODE && T == 1 && B == 1 && m->num_experts == 0 && m->n_layers > 0 && engine_mode()) {
-    EngProblem pr;
-    memset(&pr, 0, sizeof(pr));
-    pr.D = D; pr.H = H; pr.Hkv = Hkv; pr.F = F; pr.V = m->vocab_size; pr.n_layers = m->n_layers; pr.NB = device_cus();
-    pr.eps = m->norm_eps; pr.layers = m->layers; pr.cache_k = bt->cache_k; pr.cache_v = bt->cache_v; pr.W = bt->cache_sizes;
-    pr.h = h; pr.rope_cs = m->rope_cs; pr.tok_pos = bt->tok_pos; pr.tok_seq = bt->tok_seq;
-    pr.final_norm = m->final_norm; pr.output = m->output; pr.logits = bt->logits;
-    pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
-    bool dense_ok = true;
-    for (int l = 0; l < m->n_layers; ++l) dense_ok = dense_ok && m->layers[l].w1 && m->layers[l].w2 && m->layers[l].w3;
-    if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
-      MI_TRY(hip_rc(launch_decode_engine(pr, s), "decode engine"));
-      if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
-      return MI_OK;
-    }
   }
 
   for (int l = 0; l < m->n_layers; ++l) {
@@ -651,6 +697,9 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
         a.norm_w = (const bf16_t*)m->final_norm; a.eps = m->norm_eps;
         a.w0 = (const bf16_t*)m->output; a.n0 = a.n1 = m->vocab_size; a.out = bt->logits; a.ldo = m->vocab_size;
         MI_TRY(gemv_passes(a, T, s, "lm head gemv"));
+        if (want_greedy)  // generate.py:124-136 at temperature 0, fused behind the LM head (one block per sequence)
+          MI_TRY(hip_rc(launch_greedy_rows(bt->logits, m->vocab_size, B, m->vocab_size, bt->greedy_token, bt->greedy_logprob,
+                                           bt->hist_token, bt->hist_logprob, bt->hist_len, engine_ctrl, s), "greedy sample"));
       } else {
         MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
         GemmArgs g;
@@ -658,6 +707,9 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
         g.epi = GEMM_LOGITS; g.M = T; g.N = m->vocab_size; g.K = D; g.a = ws.xn; g.lda = D;
         g.w0 = (const bf16_t*)m->output; g.n0 = g.n1 = m->vocab_size; g.out = bt->logits; g.ldo = m->vocab_size;
         MI_TRY(hip_rc(launch_gemm(g, s), "lm head gemm"));
+        if (want_greedy)
+          MI_TRY(hip_rc(launch_greedy_rows(bt->logits, m->vocab_size, B, m->vocab_size, bt->greedy_token, bt->greedy_logprob,
+                                           bt->hist_token, bt->hist_logprob, bt->hist_len, engine_ctrl, s), "greedy sample"));
       }
     } else {
       MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));

@@ -43,6 +43,12 @@ constexpr int NCONS = 4;
 #ifndef ENG_HOLDERS
 #define ENG_HOLDERS 3  // holder waves per workgroup (0: none)
 #endif
+#ifndef ENG_SPARSE_POLL
+#define ENG_SPARSE_POLL 1  // repeated hand-off sweeps re-read only the granules that were missing (0: the whole batch, A/B)
+#endif
+#ifndef ENG_LEAN_BARRIERS
+#define ENG_LEAN_BARRIERS 1  // drop the consumer barriers that the RMSNorm's own barrier already implies (0: round-2 set, A/B)
+#endif
 constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
 constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
@@ -77,8 +83,15 @@ enum : int {
   C_RED = 8,        // [4] fp32 wave totals of the RMSNorm
   C_LSTAGE = 12,    // loader progress: (layer + 1) once this layer's Wo rows are issued (loader -> holders)
   C_XREADY = 13,    // (layer + 1) once ffn_norm(h1) of that layer stands in the activation region (consumers -> holders)
-  C_HDONE = 14      // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
+  C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
+  C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
+  C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag barrier, 16-byte aligned)
+  C_AMAX = 20       // [NCONS][3] per-wave (max logit, its index, sum exp) of the LM head
 };
+// global control words (workspace): [0] step epoch, [1] sticky status, [2] abort broadcast, [3] bad token id, [4] engine
+// launches completed, [5] decode steps committed (index into the greedy history ring), [6] workgroup arrivals
+enum : int { G_EPOCH = 0, G_STATUS = 1, G_ABORT = 2, G_BADID = 3, G_LAUNCHES = 4, G_STEPS = 5, G_ARRIVE = 6 };
+constexpr uint32_t ARRIVE_POLLS = 1u << 16;  // ~50 ms: far beyond the ~1 us over which a resident grid starts
 
 // Optional timeline (mi_debug_set_engine_trace): trace[c][layer][event] = 100 MHz wall clock.  Consumer wave 0 writes
 // events [0, TR_CONS), the loader events [TR_CONS, TR_EVENTS).  The buffer is reached through an explicit
@@ -92,7 +105,7 @@ struct Shared {
   lchar* xs;    // activation vector / attention scratch
   lchar* ring;
   uint32_t ring_mask;  // ring pieces - 1
-  gu32* ctrl;          // [0] epoch, [1] sticky status, [2] per-step abort broadcast, [3] bad token id, [4] engine launches
+  gu32* ctrl;          // global control words (G_* below)
   gu64* trace;         // optional timeline buffer
 };
 
@@ -293,6 +306,7 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
   const int PD = a.D >> 9;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
+    if (sh.ctl[C_ABORT]) break;  // the consumers have given up (residency gate / a timed-out wait): nothing left to feed
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
     const bool tr = lane == 0;
@@ -354,8 +368,9 @@ struct Cons {
   }
   __device__ __forceinline__ void set_done(uint32_t piece_idx) { sh.ctl[C_DONE + w] = piece_idx; }
 
-  // barrier among the NCONS consumer waves (the loader never takes part)
-  __device__ __forceinline__ void cbar() {
+  // barrier among the NCONS consumer waves (the loader and the holders never take part, so s_barrier is out)
+#ifdef ENG_CBAR_ATOMIC
+  __device__ __forceinline__ void cbar() {  // round-2 form: one shared counter (A/B)
     cbar_target += NCONS;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_CBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -364,6 +379,27 @@ struct Cons {
       if (!spin_ok(sh, spins, 0x300)) break;
     asm volatile("" ::: "memory");
   }
+#else
+  // Flag barrier: every wave stores the phase it has reached into its own word and polls all four with ONE 16-byte
+  // LDS read.  No atomic, no sleep on the first polls (the four waves reach most barriers within ~100 cycles of each
+  // other; the counter form paid an atomic + s_sleep + two dependent LDS reads per failed poll, 14 times a layer).
+  __device__ __forceinline__ void cbar() {
+    ++cbar_target;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic of the phase is done
+    if (lane == 0) sh.ctl[C_BARW + w] = cbar_target;
+    uint32_t spins = 0, fast = 0;
+    for (;;) {
+      const u32x4 f = *reinterpret_cast<const LDS_AS volatile u32x4*>(sh.ctl + C_BARW);
+      // phases only grow and differ by at most one between waves: (int) difference handles the 2^32 wrap
+      if ((int)(f[0] - cbar_target) >= 0 && (int)(f[1] - cbar_target) >= 0 && (int)(f[2] - cbar_target) >= 0 &&
+          (int)(f[3] - cbar_target) >= 0)
+        break;
+      if (++fast < 64) continue;
+      if (!spin_ok(sh, spins, 0x300)) break;
+    }
+    asm volatile("" ::: "memory");
+  }
+#endif
 
   // fp32 dots of NR consecutive streamed weight rows (P pieces each, the first at piece g0) with the activation vector
   // in LDS.  Lane owns elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p and accumulates them pairwise
@@ -421,22 +457,35 @@ struct Cons {
   }
 
   // All consumer waves: copy n granules (granule i lives at addr(i); its tag must match) into LDS words dst[0, n).
+  // A sweep that finds some tags missing is repeated, but (ENG_SPARSE_POLL) only for the granules that were missing:
+  // lanes whose granule has arrived re-read one fixed, L2-hot granule instead (all loads stay unconditional - a
+  // predicated load would serialise them) so the polling traffic of 256 CUs waiting for the last
+  // producer shrinks from the whole edge to the few lines still outstanding, and the final successful poll is one
+  // short round trip instead of a full sweep.
   template <int NL, class AddrFn>
   __device__ __forceinline__ void gather_fn(int n, uint32_t tag, lu32* dst, AddrFn addr) {
     for (int k0 = 0; k0 * NCONS * 64 < n; k0 += NL) {
       unsigned long long x[NL];
+      bool have[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        x[k] = 0;
+        have[k] = ((k0 + k) * NCONS + w) * 64 + lane >= n;
+      }
       uint32_t spins = 0;
       for (;;) {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
           const int i = ((k0 + k) * NCONS + w) * 64 + lane;
-          x[k] = __hip_atomic_load(addr(min(i, n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long y =
+              __hip_atomic_load(addr((ENG_SPARSE_POLL && have[k]) ? 0 : min(i, n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!have[k]) x[k] = y;
         }
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-          const int i = ((k0 + k) * NCONS + w) * 64 + lane;
-          ok &= (i >= n) || ((uint32_t)(x[k] >> 32) == tag);
+          have[k] = have[k] || ((uint32_t)(x[k] >> 32) == tag);
+          ok &= have[k];
         }
         if (__all(ok)) break;
         if (!spin_ok(sh, spins, 0x400)) break;
@@ -449,25 +498,35 @@ struct Cons {
     }
   }
   // Contiguous granule array (n even): 16-byte sc1 loads, two granules each - half the load instructions and wider
-  // transactions than the 8-byte sweep (each 8-byte half is still validated by its own tag).
+  // transactions than the 8-byte sweep (each 8-byte half is still validated by its own tag).  Buffer loads: a lane whose
+  // pair has arrived polls an out-of-range offset, which returns zero WITHOUT a memory access.
   template <int NL = 4>
   __device__ __forceinline__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
     const int n2 = n >> 1;  // granule pairs
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n * 8, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
     for (int k0 = 0; k0 * NCONS * 64 < n2; k0 += NL) {
       u32x4 x[NL];
+      bool have[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        x[k] = u32x4{0u, 0u, 0u, 0u};
+        have[k] = ((k0 + k) * NCONS + w) * 64 + lane >= n2;
+      }
       uint32_t spins = 0;
       for (;;) {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
           const int i = ((k0 + k) * NCONS + w) * 64 + lane;
-          x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, min(i, n2 - 1) * 16, 0, 16 /* sc1 */);
+          const int off = (ENG_SPARSE_POLL && have[k]) ? OOB : min(i, n2 - 1) * 16;
+          const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
+          if (!have[k]) x[k] = y;
         }
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-          const int i = ((k0 + k) * NCONS + w) * 64 + lane;
-          ok &= (i >= n2) || (x[k][1] == tag && x[k][3] == tag);
+          have[k] = have[k] || (x[k][1] == tag && x[k][3] == tag);
+          ok &= have[k];
         }
         if (__all(ok)) break;
         if (!spin_ok(sh, spins, 0x400)) break;
@@ -506,19 +565,33 @@ struct Cons {
   __device__ __forceinline__ void norm_load_granules(u32x4 (&xr)[4], const gu64* src, int K, uint32_t tag) {
     const int vt = w * 64 + lane, npieces = K >> 3;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (K / 2) * 8, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
     u32x4 lo[4], hi[4];
+    bool have[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = hi[i] = u32x4{0u, 0u, 0u, 0u};
+      have[i] = vt + i * 256 >= npieces;
+    }
     uint32_t spins = 0;
     for (;;) {
       bool ok = true;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int q = min(vt + i * 256, npieces - 1);
-        lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * 32, 0, 16 /* sc1 */);
-        hi[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * 32 + 16, 0, 16);
+        const int off = (ENG_SPARSE_POLL && have[i]) ? OOB : q * 32;  // arrived pieces poll nothing (gather())
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
+        if (!have[i]) {
+          lo[i] = a;
+          hi[i] = b;
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ok &= (vt + i * 256 >= npieces) || (lo[i][1] == tag && lo[i][3] == tag && hi[i][1] == tag && hi[i][3] == tag);
+      for (int i = 0; i < 4; ++i) {
+        have[i] = have[i] || (lo[i][1] == tag && lo[i][3] == tag && hi[i][1] == tag && hi[i][3] == tag);
+        ok &= have[i];
+      }
       if (__all(ok)) break;
       if (!spin_ok(sh, spins, 0x400)) break;
     }
@@ -566,7 +639,8 @@ struct Cons {
 };
 
 template <int R>
-__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch) {
+__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch,
+                                             uint32_t arrive_target) {
   Cons cs{sh, w, lane};
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -575,6 +649,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   const int nq = a.H * DH, nkv = a.Hkv * DH;
   uint32_t g = 0;  // first piece of the current segment
   uint32_t hold_target = 0;  // W1|W3 units the holder waves must have finished (cumulative)
+  long greedy_token = 0;     // the fused greedy sample (workgroup 0, wave 0, lane 0)
+  float greedy_logprob = 0.f;
+  bool greedy_valid = false;
   auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
 
   // attention scratch inside the activation region (free between the q|k|v rows and the Wo gather)
@@ -597,11 +674,21 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     typename Cons::NormW nw;
     cs.norm_prefetch(nw, a.D, L.an);
     u32x4 xr[4];
-    if (l == 0 && a.first) {  // the step's input comes from global memory (embedding / previous stage / previous launch)
+    if (l == 0 && a.first) {  // the step's input comes from global memory: the embedding row of this step's token
+      // (transformer.py:193), or h as the previous stage / previous launch left it
+      const bf16_t* hin = a.h;
+      if (a.emb) {
+        long id = (long)a.ids[0];
+        if (id < 0 || id >= a.V) {  // the reference's nn.Embedding raises IndexError: flagged for the host, row clamped
+          if (c == 0 && w == 0 && lane == 0) atomicMax((uint32_t*)a.ctrl + G_BADID, 1u);
+          id = id < 0 ? 0 : a.V - 1;
+        }
+        hin = a.emb + (size_t)id * a.D;
+      }
       const int vt = w * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xr[i] = ld16(a.h + (size_t)min(vt + i * 256, (a.D >> 3) - 1) * 8);
-      for (int r = 2 * p.o0 + vt; r < 2 * p.o1; r += NCONS * 64) sh.res[r - 2 * p.o0] = a.h[r];
+      for (int i = 0; i < 4; ++i) xr[i] = ld16(hin + (size_t)min(vt + i * 256, (a.D >> 3) - 1) * 8);
+      for (int r = 2 * p.o0 + vt; r < 2 * p.o1; r += NCONS * 64) sh.res[r - 2 * p.o0] = hin[r];
     } else {
       sh.ctl[C_GATHERING] = 1;
       cs.norm_load_granules(xr, G + a.g_h, a.D, tag_of(l - 1, 0));
@@ -610,6 +697,32 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 1, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 2, trc);
+    if (l == 0) {
+      // RESIDENCY GATE.  Every hand-off below assumes that all NB workgroups run at the same time (one per CU).  Nothing
+      // has been written yet - no ring row, no granule - so a launch that finds a workgroup missing (a CU masked or busy
+      // with another process) gives up here WITHOUT side effects: the step can be re-run on the launch path from
+      // unchanged state (Transformer._recover_engine).  The arrival count was taken at kernel entry; by now (a norm and
+      // ~1 us later) it is complete on a healthy chip and the wait is one L2 read.
+      if (w == 0) {
+        uint32_t polls = 0;
+        while ((int)(__hip_atomic_load(sh.ctrl + G_ARRIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrive_target) < 0) {
+          __builtin_amdgcn_s_sleep(8);
+          if (sh.ctl[C_ABORT] || ++polls >= ARRIVE_POLLS) {
+            raise_abort(sh, 0x700);
+            break;
+          }
+        }
+        sh.ctl[C_ARRIVED] = 1;
+      } else {
+        uint32_t spins = 0;
+        while (!sh.ctl[C_ARRIVED])
+          if (!spin_ok(sh, spins, 0x700)) break;
+      }
+      if (sh.ctl[C_ABORT]) {
+        cs.set_done(0xffffffffu);
+        return;
+      }
+    }
     {
       const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0, n_u = nq_u + 2 * nk_u;
       for (int k = w; k < n_u; k += NCONS) {
@@ -760,7 +873,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
     // ================================================================ h1 = h + attn @ Wo^T
     trace_ev(sh, c, l, 9, trc);
-    cs.cbar();  // the attention scratch is dead
+    // the attention scratch is dead once wave 0 has merged ... unless the merge staging lies beyond the words the attn
+    // vector overwrites (GQA ratio >= 2 at these head counts): then waves 1-3 start the next sweep while wave 0 merges
+    if (!(ENG_LEAN_BARRIERS && R * 64 + 128 + 8 * R + 4 * R * DH >= nq / 2)) cs.cbar();
     sh.ctl[C_GATHERING] = 1;
     cs.gather(G + a.g_att, nq / 2, tag_of(l, 3), xs32);
     cs.cbar();
@@ -864,20 +979,134 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     int v0, v1;
     slab(a.V / 2, c, a.NB, v0, v1);
+    // greedy sampling rides on the LM head (generate.py:124-136 at temperature 0): every wave keeps the running
+    // (max, first index of the max, sum of exp(x - max)) of the logits it produces
+    float bm = -INFINITY, bs = 0.f;
+    int bi = 0x7fffffff;
+    auto fold = [&](float x, int idx) {
+      if (x > bm) {
+        bs = bs * __expf(bm - x) + 1.f;
+        bm = x;
+        bi = idx;
+      } else {
+        bs += __expf(x - bm);
+      }
+    };
     for (int k = w; k < v1 - v0; k += NCONS) {
       const uint32_t ga = g + (uint32_t)(2 * k) * PD;
       cs.set_done(ga);
       float vv[2];
       cs.template unit_dot<2>(ga, PD, xs, vv);
-      const float y0 = vv[0], y1 = vv[1];
+      const float y0 = bf_round(vv[0]), y1 = bf_round(vv[1]);
       if (lane == 0) {
-        float2 o = make_float2(bf_round(y0), bf_round(y1));
+        float2 o = make_float2(y0, y1);
         *reinterpret_cast<float2*>(a.logits + 2 * (size_t)(v0 + k)) = o;
+      }
+      if (a.greedy_tok) {  // (wave-uniform values: every lane folds the same numbers)
+        fold(y0, 2 * (v0 + k));
+        fold(y1, 2 * (v0 + k) + 1);
       }
     }
     g += (uint32_t)(2 * (v1 - v0)) * PD;
+    cs.set_done(0xffffffffu);
+    if (a.greedy_tok) {
+      // wave partials -> workgroup partial -> three granules per workgroup -> workgroup 0 reduces them all.
+      // Ties: the lower index wins at every level (torch.argmax returns the first maximal element).
+      lf32* am = reinterpret_cast<lf32*>((lu32*)(sh.ctl + C_AMAX));
+      if (lane == 0) {
+        am[w * 3 + 0] = bm;
+        am[w * 3 + 1] = __int_as_float(bi);
+        am[w * 3 + 2] = bs;
+      }
+      cs.cbar();
+      const uint32_t tg = tag_of(a.n_layers - 1, 6);
+      if (w == 0) {
+        float M = am[0], S = am[2];
+        int I = __float_as_int(am[1]);
+#pragma unroll
+        for (int j = 1; j < NCONS; ++j) {
+          const float m2 = am[j * 3], s2 = am[j * 3 + 2];
+          const int i2 = __float_as_int(am[j * 3 + 1]);
+          if (m2 > M || (m2 == M && i2 < I)) {
+            S = S * __expf(M - m2) + s2;
+            M = m2;
+            I = i2;
+          } else if (s2 > 0.f) {
+            S += s2 * __expf(m2 - M);
+          }
+        }
+        if (lane < 3)
+          cs.publish(G + a.g_amax + (size_t)c * 4 + lane, tg, lane == 0 ? __float_as_uint(M) : (lane == 1 ? (uint32_t)I : __float_as_uint(S)));
+      }
+      if (c == 0) {
+        lu32* red = xs32;  // the activation region is free: every wave of this workgroup is past its LM-head rows (cbar above)
+        sh.ctl[C_GATHERING] = 1;
+        cs.gather_fn<4>(4 * a.NB, tg, red, [&](int i) { return G + a.g_amax + ((i & 3) == 3 ? i - 3 : i); });
+        cs.cbar();
+        sh.ctl[C_GATHERING] = 0;
+        if (w == 0) {
+          float M = -INFINITY, S = 0.f;
+          int I = 0x7fffffff;
+          for (int cc = lane; cc < a.NB; cc += 64) {  // ascending workgroups = ascending vocabulary slabs
+            const float m2 = __uint_as_float(red[cc * 4]), s2 = __uint_as_float(red[cc * 4 + 2]);
+            const int i2 = (int)red[cc * 4 + 1];
+            if (m2 > M || (m2 == M && i2 < I)) {
+              S = S * __expf(M - m2) + s2;
+              M = m2;
+              I = i2;
+            } else if (s2 > 0.f) {
+              S += s2 * __expf(m2 - M);
+            }
+          }
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const float m2 = __shfl_xor(M, o, 64), s2 = __shfl_xor(S, o, 64);
+            const int i2 = __shfl_xor(I, o, 64);
+            const bool take = m2 > M || (m2 == M && i2 < I);
+            const float Mn = take ? m2 : M;
+            S = S * (M == Mn ? 1.f : __expf(M - Mn)) + s2 * (m2 == Mn ? 1.f : __expf(m2 - Mn));  // (-inf partials: lanes without work)
+            M = Mn;
+            I = take ? i2 : I;
+          }
+          if (lane == 0 && !sh.ctl[C_ABORT]) {
+            greedy_token = I;
+            greedy_logprob = -__logf(S);  // log_softmax at the argmax: x - max - log(sum exp(x - max)) with x == max
+            greedy_valid = true;
+          }
+        }
+      }
+    }
+  } else {
+    cs.set_done(0xffffffffu);
   }
-  cs.set_done(0xffffffffu);
+
+  // ================================================================ commit (workgroup 0, one lane): the step becomes visible
+  // Everything a LATER launch reads to find its place - the position, the tag epoch, the token id when the caller chains
+  // greedy_tok back in as ids - is written here, after the last all-to-all of the step: every workgroup read those words
+  // at its entry, long before any workgroup can pass that edge.  An aborted step commits nothing.
+  if (a.commit && c == 0 && w == 0 && lane == 0 && !sh.ctl[C_ABORT] &&
+      __hip_atomic_load(sh.ctrl + G_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    const uint32_t step = sh.ctrl[G_STEPS];
+    if (greedy_valid) {
+      a.greedy_tok[0] = greedy_token;
+      a.greedy_lp[0] = greedy_logprob;
+      if (a.hist_tok && a.hist_len > 0) {
+        a.hist_tok[step % (uint32_t)a.hist_len] = greedy_token;
+        a.hist_lp[step % (uint32_t)a.hist_len] = greedy_logprob;
+      }
+    }
+    a.kv_seqlens[0] = (int64_t)pos + 1;
+    if (a.tok_pos) {
+      a.q_start[0] = 0;
+      a.q_start[1] = 1;
+      a.kv_before[0] = pos;
+      a.tok_seq[0] = 0;
+      a.tok_pos[0] = pos;
+    }
+    sh.ctrl[G_STEPS] = step + 1;
+    sh.ctrl[G_ARRIVE] = 0;  // every workgroup of this launch has been counted and the next launch has not begun: no wrap
+    __hip_atomic_store(sh.ctrl + G_EPOCH, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ holder waves
@@ -963,14 +1192,31 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   if (threadIdx.x < CTL_BYTES / 4) sh.ctl[threadIdx.x] = 0;
   __syncthreads();  // the only workgroup barrier: roles split below
 
-  const int pos = a.tok_pos[0];
-  const int seq = a.tok_seq ? a.tok_seq[0] : 0;
-  const uint32_t epoch = __hip_atomic_load(sh.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffffu;
+  // A workspace whose status word is raised is poisoned until the host has dealt with it (Transformer._recover_engine):
+  // later launches leave at once, before any side effect - the device state stays the one of the first failed step.
+  if (__hip_atomic_load(sh.ctrl + G_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  // The step prepares itself (round 2 ran a decode_prep kernel first): position = kv_seqlens[0], batch row 0, tags of
+  // epoch + 1.  Workgroup 0 commits position + 1 / epoch + 1 at the very end (run_consumer), so a launch that does not
+  // complete leaves both untouched; the launches of one step (> 32 layers) all see the same values.
+  const int pos = (int)a.kv_seqlens[0];
+  const int seq = 0;
+  const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
   if (w == NCONS) run_loader(a, sh, c, lane, pos, seq);
   else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
-  else run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch);
+  else {
+    // residency census: every workgroup counts itself in; consumers check the total before their first side effect
+    uint32_t arrive_target = 0;
+    if (w == 0) {
+      uint32_t old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(sh.ctrl + G_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+      arrive_target = (old / (uint32_t)a.NB + 1u) * (uint32_t)a.NB + (uint32_t)a.arrive_extra;
+    }
+    run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
+  }
   // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
-  if (c == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(sh.ctrl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (c == 0 && threadIdx.x == 0 && !sh.ctl[C_ABORT])
+    __hip_atomic_fetch_add(sh.ctrl + G_LAUNCHES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -978,8 +1224,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 struct GranLayout {
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, total;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, g_amax, total;
 };
+constexpr int AMAX_MAX_NB = 1024;  // workgroups the greedy-sampling edge is sized for (decode_engine_applicable: NB <= 1024)
 GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   using attn_core::DH;
   const int Rtot = H / Hkv, R = attn_decode_group(Rtot), Hs = Hkv * (Rtot / R);
@@ -991,6 +1238,7 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   g.g_h1 = off;   off += D / 2;
   g.g_hid = off;  off += F / 2;
   g.g_part = off; off += (uint32_t)((size_t)Hs * max_splits * R * (DH + 2));
+  g.g_amax = off; off += 4 * AMAX_MAX_NB;  // (max logit, argmax, sum exp, pad) per workgroup
   g.total = off;
   return g;
 }
@@ -1034,8 +1282,9 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
 
 namespace {
 uint64_t* g_trace = nullptr;
-int g_thin = -1, g_depth = -1;
+int g_thin = -1, g_depth = -1, g_holders = -1;
 }
+void decode_engine_set_holders(int on) { g_holders = on; }
 void decode_engine_set_knobs(int thin, int depth) {
   g_thin = thin;
   g_depth = depth;
@@ -1043,7 +1292,73 @@ void decode_engine_set_knobs(int thin, int depth) {
 void decode_engine_set_trace(void* dev_buffer) { g_trace = (uint64_t*)dev_buffer; }
 size_t decode_engine_trace_bytes(int NB) { return (size_t)NB * ENG_MAXL * TR_EVENTS * sizeof(uint64_t); }
 
-hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
+// ---- residency census (once per device and process, outside any stream capture) ------------------------------------------
+// The engine's hand-offs need all NB workgroups resident at once.  hipOccupancy... answers for an empty device; a CU mask,
+// a partition mode or a co-tenant kernel changes the real answer, and a plain launch applies no check (MI355X_MICROARCH.md
+// "Residency and cooperative launch").  So before the engine is used on a device the first time, a probe kernel with the
+// engine's exact launch shape (512 threads, 160 KiB LDS) is run: every workgroup counts itself in and waits (bounded) for
+// the others.  A failed census disables the engine for this device - the launch path is bit-identical and needs nothing.
+// The per-step residency gate in the kernel covers what changes later (run_consumer).
+__global__ __launch_bounds__(NTHREADS, 1) void engine_census_kernel(uint32_t* words, int nb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)smem;
+  if (threadIdx.x != 0) return;
+  __hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t polls = 0; polls < ARRIVE_POLLS; ++polls) {
+    if (__hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)nb) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_store(words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // somebody never showed up
+}
+
+namespace {
+// 0 unknown, 1 passed, -1 failed; per device
+int g_census[64] = {};
+char g_census_why[160] = "";
+
+int engine_census(int dev, int nb, uint32_t* ctrl, hipStream_t s) {
+  if (dev < 0 || dev >= 64) return -1;
+  if (g_census[dev] != 0) return g_census[dev];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;  // cannot probe now
+  const void* fn = (const void*)engine_census_kernel;
+  int per_cu = 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NTHREADS, LDS_TOTAL) != hipSuccess || per_cu < 1) {
+    snprintf(g_census_why, sizeof(g_census_why), "occupancy query: %d workgroups of %d threads + %d B LDS per CU", per_cu, NTHREADS, LDS_TOTAL);
+    return g_census[dev] = -1;
+  }
+  uint32_t* words = ctrl + 8;  // two spare control words of the caller's workspace (the ABI never allocates)
+  uint32_t host[2] = {0, 0};
+  bool ok = hipMemsetAsync(words, 0, 8, s) == hipSuccess;
+  if (ok) {
+    void* params[] = {(void*)&words, (void*)&nb};
+    ok = hipLaunchKernel(fn, dim3(nb), dim3(NTHREADS), params, LDS_TOTAL, s) == hipSuccess &&
+         hipMemcpyAsync(host, words, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (!ok || host[1] != 0 || host[0] != (uint32_t)nb) {
+    snprintf(g_census_why, sizeof(g_census_why), "census: %u of %d workgroups resident together (CU mask / partition / co-tenant?)",
+             host[0], nb);
+    return g_census[dev] = -1;
+  }
+  return g_census[dev] = 1;
+}
+}  // namespace
+namespace {
+int g_sabotage = 0;
+}
+void decode_engine_sabotage(int launches) { g_sabotage = launches; }
+const char* decode_engine_census_detail() { return g_census_why; }
+void decode_engine_forget_census() { memset(g_census, 0, sizeof(g_census)); }
+
+hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* declined) {
+  if (declined) *declined = false;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (engine_census(dev, pr.NB, pr.ctrl, s) < 0) {  // not all workgroups can be resident: the caller takes the launch path
+    if (declined) *declined = true;
+    return hipSuccess;
+  }
   EngArgs a;
   memset(&a, 0, sizeof(a));
   a.trace = (unsigned long long*)g_trace;
@@ -1057,31 +1372,42 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
   }
   a.thin = g_thin;
   a.depth = g_depth;
-  static int holders = -1;
-  if (holders < 0) {
+  if (g_holders < 0) {
     const char* e = getenv("MI_ENGINE_HOLDERS");
-    holders = e ? (atoi(e) != 0) : 1;
+    g_holders = e ? (atoi(e) != 0) : 1;
   }
-  a.holders = holders;
+  a.holders = g_holders;
   a.D = pr.D; a.H = pr.H; a.Hkv = pr.Hkv; a.F = pr.F; a.V = pr.V; a.eps = pr.eps; a.NB = pr.NB;
   const int Rtot = pr.H / pr.Hkv;
   a.R = attn_decode_group(Rtot);
   a.kv_groups = Rtot / a.R;
   a.Hs = pr.Hkv * a.kv_groups;
   a.ring_fills = RING_FILLS;
-  a.h = (bf16_t*)pr.h; a.rope_cs = pr.rope_cs; a.tok_pos = pr.tok_pos; a.tok_seq = pr.tok_seq;
+  a.h = (bf16_t*)pr.h; a.rope_cs = pr.rope_cs;
+  a.kv_seqlens = pr.kv_seqlens; a.q_start = pr.q_start; a.kv_before = pr.kv_before; a.tok_seq = pr.tok_seq; a.tok_pos = pr.tok_pos;
   a.final_norm = (const bf16_t*)pr.final_norm; a.output = (const bf16_t*)pr.output; a.logits = pr.logits;
   a.gran = (uint64_t*)pr.granules; a.ctrl = pr.ctrl;
   const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
   a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
-  if ((size_t)gl.total * 8 > pr.granule_bytes) return hipErrorInvalidValue;
+  a.g_amax = gl.g_amax;
+  if ((size_t)gl.total * 8 > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
 
   for (int l0 = 0; l0 < pr.n_layers; l0 += ENG_MAXL) {
     const int nl = pr.n_layers - l0 < ENG_MAXL ? pr.n_layers - l0 : ENG_MAXL;
+    const bool last = l0 + nl == pr.n_layers;
     a.n_layers = nl;
     a.seq_base = l0;
-    a.first = 1;  // every launch starts from the residual stream in global memory
-    a.head = (l0 + nl == pr.n_layers) && pr.logits != nullptr;
+    a.first = 1;  // every launch starts from the residual stream in global memory (the first one: or the embedding row)
+    a.emb = l0 == 0 ? (const bf16_t*)pr.emb : nullptr;
+    a.ids = pr.ids;
+    a.commit = last;
+    a.head = last && pr.logits != nullptr;
+    const bool greedy = a.head && pr.greedy_tok && pr.greedy_lp;
+    a.greedy_tok = greedy ? pr.greedy_tok : nullptr;
+    a.greedy_lp = greedy ? pr.greedy_lp : nullptr;
+    a.hist_tok = greedy && pr.hist_lp ? pr.hist_tok : nullptr;
+    a.hist_lp = greedy && pr.hist_tok ? pr.hist_lp : nullptr;
+    a.hist_len = pr.hist_len;
     for (int l = 0; l < nl; ++l) {
       const mi_layer_t& M = pr.layers[l0 + l];
       EngLayer& L = a.L[l];
@@ -1103,12 +1429,15 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s) {
     }
     // 160 KiB of dynamic LDS is an opt-in per function AND per device
     static bool attr_set[64][9] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev][a.R]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 64) attr_set[dev][a.R] = true;
+    }
+    a.arrive_extra = 0;
+    if (g_sabotage > 0) {
+      --g_sabotage;
+      a.arrive_extra = 1;
     }
     void* params[] = {(void*)&a};
     hipError_t e = hipLaunchKernel(fn, dim3(pr.NB), dim3(NTHREADS), params, LDS_TOTAL, s);

@@ -119,6 +119,7 @@ __global__ void decode_prep_kernel(int64_t* kv_seqlens, int32_t* q_start, int32_
   if (b == 0 && engine_ctrl) {
     engine_ctrl[0] += 1;
     engine_ctrl[2] = 0;
+    engine_ctrl[5] += 1;  // decode steps started on this workspace (index + 1 into the greedy history ring)
   }
   if (b < B) {
     const int p = (int)kv_seqlens[b];
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void decode_prep_embedding_kernel(int64_t* kv_
     if (t == 0 && engine_ctrl) {
       engine_ctrl[0] += 1;
       engine_ctrl[2] = 0;
+      engine_ctrl[5] += 1;
     }
     const int p = (int)kv_seqlens[t];
     kv_before[t] = p;
@@ -155,6 +157,63 @@ __global__ __launch_bounds__(256) void decode_prep_embedding_kernel(int64_t* kv_
   const bf16_t* src = table + (size_t)id * D;
   bf16_t* dst = out + (size_t)t * D;
   for (int p = threadIdx.x; p < (D >> 3); p += 256) st16(dst + p * 8, ld16(src + p * 8));
+}
+
+// Greedy sampling behind the LM head on the launch path (the persistent engine does the same in its own epilogue,
+// decode_engine.hip): block b reduces logits row b to (max, FIRST index of the max, sum exp(x - max)) - generate.py:124
+// `torch.argmax` and :134-136 `log_softmax(...)[token]`, which at the argmax is -log(sum).
+__global__ __launch_bounds__(1024) void greedy_rows_kernel(const float* logits, int ld, int B, int V, int64_t* tok, float* lp,
+                                                           int64_t* hist_tok, float* hist_lp, int hist_len,
+                                                           const uint32_t* ctrl) {
+  __shared__ float s_m[16], s_s[16];
+  __shared__ int s_i[16];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* row = logits + (size_t)b * ld;
+  float M = -INFINITY, S = 0.f;
+  int I = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 1024) {  // ascending indices per thread: `>` keeps the first maximum
+    const float x = row[i];
+    if (x > M) {
+      S = S * __expf(M - x) + 1.f;
+      M = x;
+      I = i;
+    } else {
+      S += __expf(x - M);
+    }
+  }
+  auto merge = [&](float m2, int i2, float s2) {
+    const bool take = m2 > M || (m2 == M && i2 < I);
+    const float Mn = take ? m2 : M;
+    S = S * (M == Mn ? 1.f : __expf(M - Mn)) + s2 * (m2 == Mn ? 1.f : __expf(m2 - Mn));
+    M = Mn;
+    I = take ? i2 : I;
+  };
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) merge(__shfl_xor(M, o, 64), __shfl_xor(I, o, 64), __shfl_xor(S, o, 64));
+  if (lane == 0) {
+    s_m[w] = M;
+    s_i[w] = I;
+    s_s[w] = S;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int j = 1; j < 16; ++j) merge(s_m[j], s_i[j], s_s[j]);
+    const float l = -__logf(S);
+    tok[b] = I;
+    lp[b] = l;
+    if (hist_tok && hist_len > 0) {
+      const uint32_t step = (ctrl[5] - 1u) % (uint32_t)hist_len;
+      hist_tok[(size_t)step * B + b] = I;
+      hist_lp[(size_t)step * B + b] = l;
+    }
+  }
+}
+
+__global__ void engine_ctrl_reset_kernel(uint32_t* ctrl) {
+  ctrl[0] += 16;  // tags of the failed step (epoch + 1) can never match again
+  ctrl[1] = 0;
+  ctrl[2] = 0;
+  ctrl[6] = 0;
 }
 
 // out = bf16(a + b) (transformer_layers.py:168 for the MoE prefill path)
@@ -420,6 +479,15 @@ hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, i
                                         int vocab, uint32_t* engine_ctrl, hipStream_t s) {
   hipLaunchKernelGGL(decode_prep_embedding_kernel, dim3(B), dim3(256), 0, s, kv_seqlens, q_start, kv_before, tok_seq, tok_pos, B,
                      (bf16_t*)out, (const bf16_t*)table, ids, D, vocab, engine_ctrl);
+  return hipGetLastError();
+}
+hipError_t launch_greedy_rows(const float* logits, int ld, int B, int V, int64_t* tok, float* lp, int64_t* hist_tok,
+                              float* hist_lp, int hist_len, const uint32_t* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(greedy_rows_kernel, dim3(B), dim3(1024), 0, s, logits, ld, B, V, tok, lp, hist_tok, hist_lp, hist_len, ctrl);
+  return hipGetLastError();
+}
+hipError_t launch_engine_ctrl_reset(uint32_t* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(engine_ctrl_reset_kernel, dim3(1), dim3(1), 0, s, ctrl);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s) {

@@ -160,6 +160,13 @@ hipError_t launch_decode_prep_embedding(int64_t* kv_seqlens, int32_t* q_start, i
                                         int32_t* tok_pos, int B, void* out, const void* table, const int64_t* ids, int D,
                                         int vocab, uint32_t* engine_ctrl, hipStream_t s);
 hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hipStream_t s);
+// Greedy sampling of B logits rows (generate.py:124-136 at temperature 0): tok[b] = first index of the row maximum
+// (torch.argmax), lp[b] = log_softmax(row)[tok[b]]; also stored at entry (ctrl[5] - 1) % hist_len of the [hist_len, B]
+// history rings when given (ctrl[5] = decode steps started on this workspace, advanced by decode_prep).
+hipError_t launch_greedy_rows(const float* logits, int ld, int B, int V, int64_t* tok, float* lp, int64_t* hist_tok,
+                              float* hist_lp, int hist_len, const uint32_t* ctrl, hipStream_t s);
+// control words of a workspace after a raised engine status: status / abort / arrivals cleared, epoch advanced
+hipError_t launch_engine_ctrl_reset(uint32_t* ctrl, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- MoE
 hipError_t launch_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T, int D, const void* gate,
@@ -192,17 +199,26 @@ struct EngArgs {
   int first, head;
   int thin, depth;        // loader knobs (A/B): during hand-off sweeps 0 stream / 1 one fill in flight / 2 stop; fills in flight (2 or 3)
   int holders;            // 1: holder waves take the last W1|W3 units of every CU's slab (A/B: MI_ENGINE_HOLDERS=0)
+  int commit;             // 1: this launch ends the decode step: workgroup 0 advances kv_seqlens / epoch / step counter
+  int hist_len;           // entries of the greedy history ring (0: none)
+  int arrive_extra;       // debug (mi_debug_engine_sabotage): workgroups the residency gate waits for beyond NB - it fails
   float eps;
-  bf16_t* h;              // [D] residual stream, in (first layer) / out (last layer)
+  bf16_t* h;              // [D] residual stream, in (first layer, unless emb) / out (last layer)
+  const bf16_t* emb;      // token embedding table [V, D]: the first layer's input is row ids[0] (nullptr: read h)
+  const int64_t* ids;     // [1] token id of this step (may alias greedy_tok: it is read before anything is committed)
+  int64_t* kv_seqlens;    // [1] position of this step's token; + 1 at commit (cache.py:193-195)
+  int32_t *q_start, *kv_before, *tok_seq, *tok_pos;  // the step's metadata words, written at commit for callers (launch-path layout)
+  int64_t* greedy_tok;    // [1] argmax of the logits (first maximal index), or nullptr
+  float* greedy_lp;       // [1] log_softmax(logits)[argmax]
+  int64_t* hist_tok;      // [hist_len] ring indexed by the step counter (ctrl[5]) or nullptr
+  float* hist_lp;
   const float* rope_cs;
-  const int32_t* tok_pos;
-  const int32_t* tok_seq;
   const bf16_t* final_norm;
   const bf16_t* output;
   float* logits;
   uint64_t* gran;         // granule regions
   uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, g_amax;
   unsigned long long* trace;  // optional timeline buffer (debug)
   EngLayer L[ENG_MAXL];
 };
@@ -216,18 +232,31 @@ struct EngProblem {
   const int32_t* W;          // host [n_layers]
   void* h;
   const float* rope_cs;
-  const int32_t* tok_pos;
-  const int32_t* tok_seq;
+  const void* emb;           // nullptr: h holds the step's input
+  const int64_t* ids;
+  int64_t* kv_seqlens;
+  int32_t *q_start, *kv_before, *tok_seq, *tok_pos;  // decode metadata words (kept consistent for callers)
   const void* final_norm;
   const void* output;
   float* logits;             // nullptr: no LM head
+  int64_t* greedy_tok;       // optional fused greedy sampling (needs logits)
+  float* greedy_lp;
+  int64_t* hist_tok;
+  float* hist_lp;
+  int hist_len;
   void* granules;
   size_t granule_bytes;
   uint32_t* ctrl;
 };
+static_assert(sizeof(EngArgs) <= 4096, "EngArgs must fit the kernel-argument segment");
 size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW);
 bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len);
-hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s);
+// *declined = true (and nothing enqueued): the residency census failed on this device - take the launch path
+hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* declined);
+const char* decode_engine_census_detail();
+void decode_engine_forget_census();  // tests
+void decode_engine_sabotage(int launches);  // tests: the next `launches` engine launches fail their residency gate
 void decode_engine_set_trace(void* dev_buffer);  // debug: nullptr disables
 void decode_engine_set_knobs(int thin, int depth);  // debug / tuning
+void decode_engine_set_holders(int on);             // debug / A/B: -1 = environment default
 size_t decode_engine_trace_bytes(int NB);

@@ -21,7 +21,7 @@ def _default_lib() -> str:
 
 LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", _default_lib())
 
-MI_ABI_VERSION = 3
+MI_ABI_VERSION = 4
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
 BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
 GEMV_MAX_T = 8
@@ -51,6 +51,7 @@ class MiBatch(C.Structure):
         ("kv_seqlens", _vp), ("cache_k", C.POINTER(_vp)), ("cache_v", C.POINTER(_vp)),
         ("cache_sizes", C.POINTER(C.c_int32)), ("h", _vp), ("logits", _vp), ("workspace", _vp),
         ("workspace_bytes", C.c_size_t),
+        ("greedy_token", _vp), ("greedy_logprob", _vp), ("hist_token", _vp), ("hist_logprob", _vp), ("hist_len", C.c_int32),
     ]
 
 
@@ -71,6 +72,7 @@ _SIGS = {
     "mi_attn_prefill": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp,
                                   _vp, C.c_int, C.c_float, _vp]),
     "mi_gelu": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "mi_greedy_sample": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "mi_lm_head_logprobs_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mi_lm_head_logprobs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
@@ -84,6 +86,8 @@ _SIGS = {
     "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
+    "mi_decode_engine_census": (C.c_int, [C.c_int]),
+    "mi_decode_engine_reset": (C.c_int, [_vp, _vp]),
     "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "mi_rccl_unique_id": (C.c_int, [_vp]),
     "mi_rccl_init": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
@@ -97,6 +101,8 @@ _SIGS = {
     "mi_debug_engine_trace_bytes": (C.c_size_t, []),
     "mi_debug_set_engine_trace": (C.c_int, [_vp]),
     "mi_debug_set_engine_knobs": (C.c_int, [C.c_int, C.c_int]),
+    "mi_debug_engine_sabotage": (C.c_int, [C.c_int]),
+    "mi_debug_set_engine_holders": (C.c_int, [C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -259,6 +265,17 @@ def lm_head_logprobs(x: torch.Tensor, w: torch.Tensor, target: torch.Tensor) -> 
     return out
 
 
+def greedy_sample(logits: torch.Tensor):
+    """(token int64 [B], logprob fp32 [B]): first argmax of each fp32 logits row and log_softmax at it."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    B, V = logits.shape
+    tok = torch.empty(B, dtype=torch.long, device=logits.device)
+    lp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    check(lib().mi_greedy_sample(dev_ptr(logits, torch.float32), logits.stride(0), B, V, dev_ptr(tok, torch.long),
+                                 dev_ptr(lp, torch.float32), stream_ptr(logits.device)), "mi_greedy_sample")
+    return tok, lp
+
+
 def gelu_(x: torch.Tensor) -> torch.Tensor:
     """In-place exact GELU on a 2-D bf16 tensor."""
     assert x.dim() == 2
@@ -333,7 +350,13 @@ def decode_engine_status(workspace: torch.Tensor) -> dict:
     """Control words of the persistent decode engine in `workspace` (synchronises the current stream)."""
     st = (C.c_uint32 * 8)()
     check(lib().mi_decode_engine_status(workspace.data_ptr(), stream_ptr(workspace.device), st), "mi_decode_engine_status")
-    return {"epoch": int(st[0]), "status": int(st[1]), "abort": int(st[2]), "bad_id": int(st[3]), "engine_launches": int(st[4])}
+    return {"epoch": int(st[0]), "status": int(st[1]), "abort": int(st[2]), "bad_id": int(st[3]), "engine_launches": int(st[4]),
+            "steps": int(st[5]), "arrivals": int(st[6])}
+
+
+def decode_engine_reset(workspace: torch.Tensor) -> None:
+    """Clear a raised engine status (see include/mistral_hip.h: residency)."""
+    check(lib().mi_decode_engine_reset(workspace.data_ptr(), stream_ptr(workspace.device)), "mi_decode_engine_reset")
 
 
 def ptr_array(ptrs: List[Optional[int]]):

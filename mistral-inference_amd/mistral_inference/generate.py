@@ -114,6 +114,42 @@ def generate(
     gen_lp: List[torch.Tensor] = []
     is_finished = torch.zeros(B, dtype=torch.bool, device=dev)
     assert last_token_prelogits is not None
+    fused_greedy = (temperature == 0 and max_tokens > 0 and hasattr(model, "greedy_session") and dev.type == "cuda"
+                    and getattr(model, "num_pipeline_ranks", 1) == 1 and getattr(model, "softmax_fp32", True)
+                    and getattr(model, "fused_greedy", True))  # (model.fused_greedy = False: the loop below, for A/B)
+    if fused_greedy:
+        # Temperature 0 on one HIP stage: argmax and log-softmax ride on the LM head inside the step (GreedySession), the
+        # sample feeds the next step on the device, and the tokens come back in one copy per CHUNK steps.  Same values
+        # as the loop below: token i+1 = first argmax of the logits after token i; its logprob = log_softmax at it.
+        next_token = sample(last_token_prelogits, temperature=0.0, top_p=0.8)
+        lsm = torch.log_softmax(last_token_prelogits, dim=-1)
+        first_lp = lsm.gather(1, next_token[:, None])[:, 0]
+        if eos_id is not None:
+            is_finished = is_finished | (next_token == eos_id)
+        if not (eos_id is not None and bool(is_finished.all())):
+            generated.append(next_token)
+            gen_lp.append(first_lp)
+            sess = model.greedy_session(cache, next_token)
+            need = max_tokens - 1            # (the reference's last forward only feeds a sample nobody draws)
+            chunk = 32 if eos_id is not None else sess.HIST
+            stop = False
+            while need > 0 and not stop:
+                n = min(need, chunk)
+                sess.run(n)
+                toks, lps = sess.collect(n)  # [n, B] each; one synchronisation per chunk
+                keep = n
+                if eos_id is not None:       # generate.py:128-132: stop BEFORE the step at which every sequence has hit EOS
+                    fin = is_finished[None, :] | ((toks == eos_id).cumsum(0) > 0)
+                    all_fin = fin.all(dim=1)
+                    if bool(all_fin.any()):
+                        keep = int(torch.nonzero(all_fin)[0, 0])
+                        stop = True
+                    is_finished = fin[keep - 1] if keep > 0 else is_finished
+                for j in range(keep):
+                    generated.append(toks[j])
+                    gen_lp.append(lps[j])
+                need -= n
+        max_tokens = 0  # the loop below is done
     graphed = model.graphed_decode(cache) if hasattr(model, "graphed_decode") else contextlib.nullcontext()
     with graphed:  # decode steps replay a captured hipGraph (single rank; no-op otherwise)
         for _ in range(max_tokens):

@@ -50,6 +50,16 @@ class SimpleInputMetadata:
             positions=torch.cat([torch.arange(0, s) for s in seqlens]).to(device=device, dtype=torch.long))
 
 
+@dataclass
+class GreedyBuffers:
+    """Device buffers of the fused greedy sample (mi_batch_t ABI v4).  `tok` is BOTH the step's input ids and its output:
+    the kernels consume the ids before they write the sample, so consecutive steps chain without a copy."""
+    tok: torch.Tensor       # int64 [B]
+    lp: torch.Tensor        # fp32 [B]
+    hist_tok: torch.Tensor  # int64 [hist_len, B]: row (decode steps run on the workspace) % hist_len
+    hist_lp: torch.Tensor   # fp32 [hist_len, B]
+
+
 class HipStackBackend:
     """Runs the local layer stack through `mi_forward`.  The only backend shipped: the product has no
     CPU or eager path (tests may inject a different object to exercise host-side pipeline logic)."""
@@ -124,7 +134,12 @@ class HipStackBackend:
             self._workspace[12:16].zero_()
             raise IndexError(f"index out of range in self (token {st['bad_id'] - 1} of a forward call)")
         if st["status"]:
-            raise RuntimeError(f"persistent decode engine: bounded wait 0x{st['status']:x} timed out (workspace poisoned)")
+            # the raised word makes every later engine launch on this workspace leave at once: clear it now that it is reported
+            _hip.decode_engine_reset(self._workspace)
+            what = ("its workgroups were not all resident (GPU shared or CUs masked?); the step wrote nothing"
+                    if st["status"] == 0x700 else "a bounded wait timed out; the step's outputs are undefined")
+            raise RuntimeError(f"persistent decode engine: status 0x{st['status']:x} - {what}.  "
+                               "MI_DECODE_ENGINE=0 selects the launch path.")
 
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
         need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
@@ -137,7 +152,8 @@ class HipStackBackend:
 
     # -- per forward -------------------------------------------------------------------------------
     def run_stack(self, model: "Transformer", h: torch.Tensor, input_ids: Optional[torch.Tensor],
-                  meta: BatchMetadata, cache: Optional[BufferCache], logits: Optional[torch.Tensor]) -> None:
+                  meta: BatchMetadata, cache: Optional[BufferCache], logits: Optional[torch.Tensor],
+                  greedy: Optional["GreedyBuffers"] = None) -> None:
         m = self.plan(model)
         T, B = h.shape[0], len(meta.seqlens)
         bt = _hip.MiBatch()
@@ -155,6 +171,10 @@ class HipStackBackend:
             max_w = max(cache.cache_sizes)
         bt.h = _hip.dev_ptr(h)
         bt.logits = _hip.dev_ptr(logits, torch.float32)
+        if greedy is not None:  # ABI v4: sample fused behind the LM head (generate.py:124,134-136 at temperature 0)
+            bt.greedy_token, bt.greedy_logprob = _hip.dev_ptr(greedy.tok, torch.long), _hip.dev_ptr(greedy.lp, torch.float32)
+            bt.hist_token, bt.hist_logprob = _hip.dev_ptr(greedy.hist_tok, torch.long), _hip.dev_ptr(greedy.hist_lp, torch.float32)
+            bt.hist_len = greedy.hist_tok.shape[0]
         wsb = self._get_workspace(model, m, T, B, max_w)
         bt.workspace, bt.workspace_bytes = wsb.data_ptr(), wsb.numel()
         _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
@@ -349,6 +369,12 @@ class Transformer(ModelBase):
             yield self
         finally:
             self._graphed = None
+
+    # ---- greedy decoding with the sample fused into the step ------------------------------------------
+    def greedy_session(self, cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True) -> "GreedySession":
+        """Decode loop of `generate()` at temperature 0 (reference generate.py:120-140) with nothing but the model's own
+        launches per token: see GreedySession."""
+        return GreedySession(self, cache, first_tokens, graph)
 
     def _logits(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
                 images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
@@ -553,3 +579,134 @@ class Transformer(ModelBase):
                  "pre_mm_projector_norm")
         if not any(k.startswith(p) for p in known):
             raise ValueError(f"Unexpected key {k}")
+
+
+class GreedySession:
+    """`next_token = argmax(logits); logprob = log_softmax(logits)[next_token]; logits = model.forward(next_token)`
+    (reference generate.py:124-140, temperature 0) as ONE native call per token with no torch launch in between.
+
+    * the LM head's epilogue produces the sample (persistent engine: in the same launch; launch path: one more small
+      kernel) and writes it (a) into the id buffer the NEXT step reads - `mi_batch_t.input_ids` may alias
+      `greedy_token` - and (b) into a history ring on the device;
+    * a step is captured once in a hipGraph and replayed; on the persistent engine that graph is a single kernel;
+    * `run(n)` enqueues n steps without touching the host again; `collect(n)` reads the n samples back in one copy,
+      which is also where a device-side failure is noticed: an engine step whose residency census failed (status
+      0x700, include/mistral_hip.h) wrote nothing, so the missing steps are re-run on the launch path.
+
+    The [B, vocab] fp32 logits of every step are still produced (`self.logits`): the work of `forward()` is unchanged,
+    only what is done with its result moved onto the device."""
+
+    HIST = 1024
+
+    def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
+        assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"
+        assert isinstance(model._backend, HipStackBackend), "the fused greedy step needs the HIP backend"
+        dev = model.device
+        self.model, self.cache = model, cache
+        B = int(first_tokens.numel())
+        self.B = B
+        assert cache._seen is not None and len(cache._seen) == B and cache._seen[0] > 0, "prefill the cache first"
+        self.buf = GreedyBuffers(tok=first_tokens.to(device=dev, dtype=torch.long).reshape(B).clone(),
+                                 lp=torch.zeros(B, dtype=torch.float32, device=dev),
+                                 hist_tok=torch.zeros((self.HIST, B), dtype=torch.long, device=dev),
+                                 hist_lp=torch.zeros((self.HIST, B), dtype=torch.float32, device=dev))
+        self.logits = torch.empty((B, model.vocab_size), dtype=torch.float32, device=dev)
+        self.h = torch.empty((B, model.args.dim), dtype=model.dtype, device=dev)
+        self._use_graph = graph and dev.type == "cuda"
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._warm = False
+        self._base: Optional[int] = None   # value of the workspace's step counter when this session began
+        self._pending = 0                  # steps enqueued and not yet collected
+        self._n_collected = 0
+
+    # -- one step, enqueued launch by launch
+    def _step_eager(self) -> None:
+        m, cache = self.model, self.cache
+        meta = cache.batch_metadata([1] * self.B)
+        assert meta.branch == _hip.BRANCH_DECODE
+        m._backend.run_stack(m, self.h, self.buf.tok, meta, cache, self.logits, greedy=self.buf)
+
+    def _steps_now(self) -> int:
+        return _hip.decode_engine_status(self.model._backend._workspace)["steps"]
+
+    def _one_step(self) -> None:
+        m, cache = self.model, self.cache
+        if not self._warm:  # first step eagerly: sizes the workspace, runs the engine's one-time residency census
+            if m._backend._workspace is None:
+                m._backend._get_workspace(m, m._backend.plan(m), 1, self.B, max(cache.cache_sizes))
+            self._base = self._steps_now()
+            self._step_eager()
+            self._warm = True
+            return
+        if self._use_graph and self._graph is None:
+            torch.cuda.synchronize(m.device)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):  # (capture enqueues nothing: the step itself is the replay below)
+                    self._step_eager()
+                self._graph = g
+            except RuntimeError as e:  # a runtime that refuses to capture: launch by launch from here on
+                logging.warning("greedy decode step not graph-capturable (%s): continuing eagerly", e)
+                self._use_graph = False
+        if self._use_graph:
+            self._graph.replay()
+        else:
+            self._step_eager()
+
+    def run(self, n: int) -> None:
+        """Enqueue n decode steps (no host synchronisation once the step has been captured)."""
+        cache = self.cache
+        if max(cache._seen) + n > ROPE_TABLE_LEN:
+            raise IndexError(f"position {max(cache._seen) + n - 1} is beyond the {ROPE_TABLE_LEN}-entry rotary table")
+        assert self._pending + n <= self.HIST, "collect() before the history ring wraps"
+        for _ in range(n):
+            self._one_step()
+            cache.advance_host([1] * self.B)
+            self._pending += 1
+
+    def collect(self, n: Optional[int] = None):
+        """(tokens int64 [n, B], logprobs fp32 [n, B]) of the n oldest uncollected steps, on the host side of one
+        synchronisation; verifies that the device really ran them (and re-runs what an engine failure skipped)."""
+        n = self._pending if n is None else n
+        assert 0 < n <= self._pending
+        m = self.model
+        ws = m._backend._workspace
+        st = _hip.decode_engine_status(ws)  # synchronises
+        assert self._base is not None
+        done_total = st["steps"] - self._base      # steps the device completed since the session began
+        issued_total = self._issued()
+        if st["status"] != 0:
+            missing = issued_total - done_total
+            if st["status"] != 0x700:
+                raise RuntimeError(f"persistent decode engine: bounded wait 0x{st['status']:x} timed out (workspace poisoned)")
+            logging.warning("persistent decode engine: %d of the GPU's workgroups were not resident together; %d step(s) "
+                            "re-run on the launch path (engine off for this process)", st["arrivals"], missing)
+            self._recover(missing)
+        elif done_total != issued_total:
+            raise RuntimeError(f"decode steps issued {issued_total} != completed {done_total}")
+        first = self._collected()
+        idx = torch.arange(first, first + n, device=m.device) + self._base
+        idx = idx % self.HIST
+        toks, lps = self.buf.hist_tok[idx], self.buf.hist_lp[idx]
+        self._pending -= n
+        self._n_collected = first + n
+        return toks, lps
+
+    def _collected(self) -> int:
+        return self._n_collected
+
+    def _issued(self) -> int:
+        return self._n_collected + self._pending
+
+    def _recover(self, missing: int) -> None:
+        """The device state is that of the first failed step (nothing was written since): clear the status, switch
+        this process to the launch path and run the `missing` steps again."""
+        m, cache = self.model, self.cache
+        _hip.decode_engine_reset(m._backend._workspace)
+        _hip.set_decode_engine(False)
+        self._graph = None  # it holds the engine launch
+        cache._seen = [p - missing for p in cache._seen]
+        for _ in range(missing):
+            self._step_eager()
+            cache.advance_host([1] * self.B)
+        torch.cuda.synchronize(m.device)

@@ -135,6 +135,132 @@ def test_32_layers_vs_bf16_and_fp32_oracle():
     torch.cuda.empty_cache()
 
 
+def test_8_layers_4096_token_prompt_and_ring_wrap_vs_oracle():
+    """The HEADLINE prefill shape against the oracle (round 2 only had self-consistency at T = 4096): 8 layers of the
+    BASELINE configs[1] dims, one 4096-token prompt through the 256-query / 8-wave prefill attention and the 256x256 GEMMs,
+    then 4 teacher-forced decode steps on the persistent engine that wrap the 4096-slot ring (positions 4096..4099
+    overwrite slots 0..3).  Same three-number criterion as the 32-layer test, oracle layer-major in bf16 and fp32."""
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    p = dict(P7B, n_layers=8, sliding_window=4096)
+    L, V, D = p["n_layers"], p["vocab_size"], p["dim"]
+    T, steps = 4096, 4
+    oargs = mo.OracleArgs.from_params(p)
+    ta = TransformerArgs.from_dict(p)
+    ta.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(ta)
+    model = model.to(BF).to_empty(device="cuda").eval()
+    sd = dict(model.named_parameters())
+    g = torch.Generator().manual_seed(4321)
+    emb = torch.randn(V, D, generator=g).to(BF)
+    final_norm = (1 + 0.1 * torch.randn(D, generator=g)).to(BF)
+    out_w = _lin(V, D, g)
+    with torch.no_grad():
+        sd["tok_embeddings.weight"].copy_(emb)
+        sd["norm.weight"].copy_(final_norm)
+        sd["output.weight"].copy_(out_w)
+    ids = torch.randint(0, V, (T + steps,), generator=torch.Generator().manual_seed(6))
+    dtypes = {"bf16": BF, "fp32": torch.float32}
+    acts = {d: (None, [None] * steps) for d in dtypes}
+    t0 = time.time()
+    for l in range(L):
+        w = _layer_weights(l, p, g)
+        with torch.no_grad():
+            for k, t in w.items():
+                sd[k].copy_(t)
+        extra = {}
+        if l == 0:
+            extra["tok_embeddings.weight"] = emb
+        if l == L - 1:
+            extra["norm.weight"] = final_norm
+        for dn, dt in dtypes.items():
+            wl = {k: t.to(dt) for k, t in {**w, **extra}.items()}
+            om = mo.OracleModel(oargs, wl, pipeline_rank=l, num_pipeline_ranks=L)
+            oc = mo.OracleCache(1, 1, T + steps + 2, p["n_kv_heads"], p["head_dim"], 4096, dtype=dt)
+            h_pre, h_dec = acts[dn]
+            h_pre = om.forward_partial(ids[:T], [T], oc, h_in=h_pre)
+            h_dec = [om.forward_partial(ids[T + s:T + s + 1], [1], oc, h_in=h_dec[s]) for s in range(steps)]
+            acts[dn] = (h_pre, h_dec)
+        del w
+    oracle_s = time.time() - t0
+    model._weights_changed()
+    cache = BufferCache(L, 1, T + steps + 2, p["n_kv_heads"], p["head_dim"], 4096, device="cuda", dtype=BF)
+    cache.reset()
+    with torch.inference_mode():
+        hip_pre = model.forward(ids[:T].cuda(), [T], cache)
+        hip = [hip_pre[-260:].cpu(), hip_pre[::17].cpu()]   # the last rows (longest contexts) + a stride over all of them
+        sel = torch.cat([torch.arange(T - 260, T), torch.arange(0, T, 17)])
+        del hip_pre
+        hip += [model.forward(ids[T + s:T + s + 1].cuda(), [1], cache).cpu() for s in range(steps)]
+    hip = torch.cat(hip)
+    ref = {}
+    for dn, dt in dtypes.items():
+        h_pre, h_dec = acts[dn]
+        ref[dn] = F.linear(torch.cat([h_pre[sel]] + h_dec), out_w.to(dt)).float()
+    e_hip, e_o16, d = (hip - ref["fp32"]).abs(), (ref["bf16"] - ref["fp32"]).abs(), (hip - ref["bf16"]).abs()
+    n_dec = steps
+    print(f"\n8 layers, 4096-token prompt + {steps} decode steps over the ring wrap (oracle: {oracle_s:.0f} s on the host): "
+          f"max|HIP-fp32| {float(e_hip.max()):.4f}  max|oracle_bf16-fp32| {float(e_o16.max()):.4f}  max|HIP-oracle_bf16| "
+          f"{float(d.max()):.4f}  means {float(e_hip.mean()):.5f} / {float(e_o16.mean()):.5f} / {float(d.mean()):.5f}  "
+          f"decode rows only: max|HIP-fp32| {float(e_hip[-n_dec:].max()):.4f} vs {float(e_o16[-n_dec:].max()):.4f}  "
+          f"|logit|max {float(ref['fp32'].abs().max()):.2f}")
+    from mistral_inference import _hip
+    st = _hip.decode_engine_status(model._backend._workspace)
+    assert st["engine_launches"] >= steps and st["status"] == 0, st
+    assert float(e_hip.max()) <= 1.25 * float(e_o16.max()), (float(e_hip.max()), float(e_o16.max()))
+    assert float(e_hip.mean()) <= 1.10 * float(e_o16.mean())
+    assert float(e_hip[-n_dec:].max()) <= 1.5 * float(e_o16.max())   # the wrapped-ring decode rows on their own
+    agree_hip = float((hip.argmax(1) == ref["fp32"].argmax(1)).float().mean())
+    agree_o16 = float((ref["bf16"].argmax(1) == ref["fp32"].argmax(1)).float().mean())
+    assert agree_hip >= agree_o16 - 0.02, (agree_hip, agree_o16)
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_mixtral_8x7b_dims_4_layers_vs_oracle():
+    """Inter-layer MoE accumulation at real width (round 2 had one layer per MoE config): 4 layers of the BASELINE
+    configs[3] dims (8 experts top-2, 11.6 GB), 20-token prompt + 4 teacher-forced decode steps against the bf16 oracle
+    (layer-major, tests/moe_depth_util.py).  The seed is one for which no router pick of the run is a near-tie (checked
+    again here), so every row is compared."""
+    import moe_depth_util as mu
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    p = dict(mu.P8X7B_4L)
+    ta = TransformerArgs.from_dict(p)
+    ta.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(ta)
+    model = model.to(BF).to_empty(device="cuda").eval()
+    sd = dict(model.named_parameters())
+
+    def sink(w):
+        with torch.no_grad():
+            for k, t in w.items():
+                sd[k].copy_(t)
+
+    ids, ref, gap = mu.oracle_run(sink=sink)
+    assert gap > 4.0, f"router near-tie in the oracle run (gap {gap:.2f} ulp): pick another seed (python tests/moe_depth_util.py)"
+    model._weights_changed()
+    T, steps = mu.PROMPT, mu.STEPS
+    cache = BufferCache(p["n_layers"], 1, T + steps + 2, 8, 128, None, device="cuda", dtype=BF)
+    cache.reset()
+    with torch.inference_mode():
+        got = [model.forward(ids[:T].cuda(), [T], cache).cpu()]
+        got += [model.forward(ids[T + i:T + i + 1].cuda(), [1], cache).cpu() for i in range(steps)]
+    got = torch.cat(got)
+    d = (got - ref).abs()
+    print(f"\nMixtral-8x7B dims x 4 layers: max|HIP - oracle_bf16| {float(d.max()):.4f} (prefill rows {float(d[:T].max()):.4f}, "
+          f"decode rows {float(d[T:].max()):.4f}), mean {float(d.mean()):.5f}, |logit|max {float(ref.abs().max()):.2f}, "
+          f"min router gap {gap:.1f} ulp")
+    assert float(d.max()) <= 4e-2 and float(d.mean()) <= 3e-3
+    assert float((got.argmax(1) == ref.argmax(1)).float().mean()) >= 0.9
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_mixtral_8x7b_dims_one_layer_vs_oracle():
     """BASELINE.json configs[3] shapes (dim 4096, 32 q heads over 8 kv heads, hidden 14336, 8 experts top-2), ONE layer
     (2.9 GB), small vocabulary: prefill logits of a 48-token prompt and 4 teacher-forced decode steps against the bf16

@@ -92,7 +92,90 @@ SHAPES = {
     # an 8.3K-slot ring: 31 splits of 272 slots = 136 K/V pieces per CU, more than the LDS ring holds at once
     "ring_longer_than_lds": dict(dim=512, n_layers=1, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
                                  vocab_size=640, sliding_window=None),
+    # HOLDER WAVES at a size the whole suite can afford: they need dim % 2048 == 0 and >= 11 W1|W3 units per CU
+    # (decode_engine.hip holder_units): hidden_dim 5632 = 11 units x 256 CUs exactly
+    "holders_mid_size": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=5632, n_heads=16, n_kv_heads=4, norm_eps=1e-5,
+                             vocab_size=1024, sliding_window=256),
+    # more layers than one launch takes (ENG_MAXL = 32): two engine launches per step, the residual stream handed over
+    # through global memory, the LM head and the step's commit only in the second (BASELINE configs[2], Nemo: 40 layers)
+    "two_launches_34_layers": dict(dim=512, n_layers=34, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2,
+                                   norm_eps=1e-5, vocab_size=600, sliding_window=40),
 }
+
+
+def test_two_launch_depth_vs_oracle_and_graph():
+    """34 layers = 32 + 2: engine == launch path bit for bit is in test_engine_bit_equal_launch_path; here graph replay
+    of the two-launch step and the CPU oracle (the path BASELINE configs[2] runs on had no parity evidence)."""
+    p = SHAPES["two_launches_34_layers"]
+    args = mo.OracleArgs(**p)
+    m, w = _model(args, seed=13)
+    prompt_len, steps = 30, 14   # crosses the 40-slot ring
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(6)).cuda()
+    ref, _, st0 = _run(m, ids, prompt_len, steps, engine=False)
+    eager, _, st1 = _run(m, ids, prompt_len, steps, engine=True)
+    graph, _, st2 = _run(m, ids, prompt_len, steps, engine=True, graph=True)
+    assert st1["status"] == 0 and st2["status"] == 0
+    assert st1["engine_launches"] - st0["engine_launches"] == 2 * steps   # two launches per step
+    assert all(torch.equal(a, b) for a, b in zip(ref, eager))
+    assert all(torch.equal(a, b) for a, b in zip(ref, graph))
+    om = mo.OracleModel(args, w)
+    oc = mo.OracleCache(args.n_layers, 1, prompt_len + steps + 2, args.n_kv_heads, args.head_dim, args.sliding_window, dtype=BF)
+    om.forward(ids[:prompt_len].cpu(), [prompt_len], oc)
+    worst = 0.0
+    for i in range(steps):
+        o = om.forward(ids[prompt_len + i:prompt_len + i + 1].cpu(), [1], oc)[0]
+        worst = max(worst, float((eager[i].cpu() - o).abs().max()))
+    assert worst < 6e-2, worst   # 34 layers of bf16 storage (the 32-layer floor of test_gpu_depth is 4.7e-2)
+
+
+@pytest.mark.parametrize("holders", [1, 0])
+def test_holder_waves_fingerprint(holders):
+    """Holder waves reduce their W1|W3 unit from REGISTERS, not from the ring: same arithmetic, same order - made visible
+    the way test_engine_summation_order_fingerprint does it for q|k|v.  W1/W3[:, D/2:] = -W1/W3[:, :D/2] and ffn_norm
+    symmetric: with an input whose halves are equal every hidden value would be the rounding residue of the summation
+    order.  h1 = h + Wo(attn) is not symmetric, so the property is arranged one level down: Wo rows are duplicated
+    (row D/2 + i = row i) and the embedding halves equal, which makes h1's halves equal.  The residues then flow through
+    W2 into layer 1's K/V rows and the logits: any difference in order shows up as a bit difference against the launch
+    path, with the holder waves on and off."""
+    from mistral_inference import _hip
+    p = SHAPES["holders_mid_size"]
+    args = mo.OracleArgs(**p)
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.transformer import Transformer
+    w = mo.synth_weights(args, seed=23)
+    half = p["dim"] // 2
+    w["tok_embeddings.weight"][:, half:] = w["tok_embeddings.weight"][:, :half]
+    for l in range(p["n_layers"]):
+        w[f"layers.{l}.attention.wo.weight"][half:] = w[f"layers.{l}.attention.wo.weight"][:half]
+        w[f"layers.{l}.ffn_norm.weight"][half:] = w[f"layers.{l}.ffn_norm.weight"][:half]
+        w[f"layers.{l}.feed_forward.w2.weight"][half:] = w[f"layers.{l}.feed_forward.w2.weight"][:half]
+        # silu(residue) * residue ~ 1e-8: scaled by an exact power of two so that it survives the bf16 residual add and
+        # steers everything downstream (layer 1's K/V rows, the logits)
+        w[f"layers.{l}.feed_forward.w2.weight"] *= 2.0 ** 24
+        for n in ("w1", "w3"):
+            t = w[f"layers.{l}.feed_forward.{n}.weight"]
+            t[:, half:] = -t[:, :half]
+    targs = TransformerArgs.from_dict(mo.params_json(args))
+    targs.max_batch_size = 1
+    with torch.device("meta"):
+        m = Transformer(targs)
+    m = m.to(BF).to_empty(device="cuda")
+    m.load_state_dict({k: v.cuda() for k, v in w.items()}, assign=True)
+    m.eval()
+    prompt_len, steps = 7, 6
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(4)).cuda()
+    _hip.check(_hip.lib().mi_debug_set_engine_holders(holders), "holders")
+    try:
+        ref, ref_rings, _ = _run(m, ids, prompt_len, steps, engine=False)
+        got, got_rings, st = _run(m, ids, prompt_len, steps, engine=True)
+    finally:
+        _hip.check(_hip.lib().mi_debug_set_engine_holders(-1), "holders")
+    assert st["status"] == 0 and st["engine_launches"] > 0
+    assert all(torch.isfinite(a).all() for a in ref)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (holders, i, float((a - b).abs().max()))
+    for l, ((k0, v0), (k1, v1)) in enumerate(zip(ref_rings, got_rings)):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1), (holders, l, _where(k0, k1), _where(v0, v1))
 
 
 @pytest.mark.parametrize("name", sorted(SHAPES))
@@ -103,6 +186,8 @@ def test_engine_bit_equal_launch_path(name):
     W = p["sliding_window"] if isinstance(p["sliding_window"], int) else 10 ** 9
     prompt_len = 40 if W < 100 else 300  # 40 + steps crosses the 48-slot ring; 300 leaves later splits empty in a 1200 ring
     steps = 12
+    if name == "two_launches_34_layers":
+        prompt_len = 33  # + 12 steps crosses the 40-slot ring
     if name == "ring_longer_than_lds":
         prompt_len, steps = 8290, 6
     ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(3)).cuda()

@@ -99,6 +99,7 @@ def test_logits_vs_reference_and_oracle(name, tmp_path):
 
     worst, compared = 0.0, 0
     within, elems, abs_sum = 0, 0, 0.0  # BASELINE.json's "within 1e-2 max-abs": see the note below
+    exact, in1, in2, in3 = 0, 0, 0, 0   # ... and in units of the reference value's own bf16 spacing
     refs = [case.t.get(f"prefill_logits.{c}") for c in range(len(pre))] + \
            [case.t.get(f"decode_logits.{s}") for s in range(len(dec))]
     for f, (got, ref) in enumerate(zip(pre + dec, o_pre + o_dec)):
@@ -113,6 +114,13 @@ def test_logits_vs_reference_and_oracle(name, tmp_path):
                 within += int((d <= 1e-2).sum())
                 elems += d.numel()
                 abs_sum += float(d.sum())
+                # bf16 spacing at the reference value; below |x| = 1 the error is inherited from the hidden state, not from
+                # the logit's own rounding, so the spacing of [1, 2) is the floor (7.8e-3)
+                ulp = refs[f][r].abs().clamp(min=1.0) * 2.0 ** -7
+                exact += int((d == 0).sum())
+                in1 += int((d <= 1.0 * ulp + 1e-7).sum())
+                in2 += int((d <= 2.0 * ulp + 1e-7).sum())
+                in3 += int((d <= 3.0 * ulp + 1e-7).sum())
     total = sum(sum(s) for s in schedule)
     assert compared >= 0.5 * total, (name, "too many tie-ambiguous rows", compared, total)
     assert worst <= LOGIT_ATOL, (name, "vs bf16 oracle", worst)
@@ -123,6 +131,11 @@ def test_logits_vs_reference_and_oracle(name, tmp_path):
         # bit differ by more than 1e-2 on some elements (the reference does so against itself when only its CPU thread
         # count changes).  What is asserted: max-abs within the 2-3 ulp bound above, at least 97 %
         # of all logits within 1e-2, and a mean error an order of magnitude below it.
+        print(f"\n{name}: vs the reference's stored logits - bit-exact {exact / elems:.3f}, within 1 / 2 / 3 bf16 ulp(ref) "
+              f"{in1 / elems:.4f} / {in2 / elems:.4f} / {in3 / elems:.4f}, within 1e-2 {within / elems:.4f}, mean |d| {abs_sum / elems:.5f}")
+        assert in2 >= 0.999 * elems, (name, "fraction of logits within 2 bf16 ulp of the reference value", in2 / elems)
+        assert in3 == elems, (name, "a logit further than 3 bf16 ulp from the reference value", in3 / elems)
+        assert exact >= 0.25 * elems, (name, "bit-exact fraction", exact / elems)
         assert within >= 0.97 * elems, (name, "fraction of logits within 1e-2 of the reference", within / elems)
         assert abs_sum / elems <= 2.5e-3, (name, "mean abs logit error vs the reference", abs_sum / elems)
 

@@ -274,6 +274,8 @@ def test_attn_decode_wide_ring_constant_v(H, Hkv, W):
     (512, [0], [700]),                    # several key tiles, window cuts early tiles
     (4096, [0, 0], [1100, 900]),          # with 32 heads: enough 256-query blocks for the 8-wave kernel, ragged tail
     (512, [600, 30, 0], [700, 520, 300]), # 8-wave kernel over wrapped rings with the window cutting tiles
+    (4096, [0], [4096]),                  # THE headline prefill shape (with 32/8 heads): one 4096-token sequence, W = 4096
+    (4096, [4096], [2048]),               # second chunk over a full ring: every query sees exactly 4096 keys
 ])
 def test_attn_prefill(H, Hkv, W, seen, new):
     h = _hip()
@@ -293,7 +295,13 @@ def test_attn_prefill(H, Hkv, W, seen, new):
         keys = torch.cat([hk[b][p - n_old:p], rows[:, nq:nq + nkv].reshape(s, Hkv, Dh)])
         vals = torch.cat([hv[b][p - n_old:p], rows[:, nq + nkv:].reshape(s, Hkv, Dh)])
         kpos = torch.arange(p - n_old, p + s)
-        ref = mo._attend(rows[:, :nq].reshape(s, H, Dh), keys, vals, torch.arange(p, p + s), kpos, W, causal=True)
+        if s * keys.shape[0] * H > 2 ** 28:   # [H, s, n] fp32 scores would be GBs: one kv head (and its q heads) at a time
+            R = H // Hkv
+            qh = rows[:, :nq].reshape(s, Hkv, R, Dh)
+            ref = torch.cat([mo._attend(qh[:, g], keys[:, g:g + 1], vals[:, g:g + 1], torch.arange(p, p + s), kpos, W, causal=True)
+                             .view(s, R, Dh) for g in range(Hkv)], dim=1).reshape(s, nq)
+        else:
+            ref = mo._attend(rows[:, :nq].reshape(s, H, Dh), keys, vals, torch.arange(p, p + s), kpos, W, causal=True)
         # P is rounded to bf16 for the P.V MFMA (as in every flash kernel, xformers' included; SURVEY.md
         # Appendix A): absolute error <= ~2^-9 * max|V| + one output rounding, independent of |out|
         err = (got[o:o + s].float() - ref.float()).abs().max().item()
