@@ -311,6 +311,7 @@ def main() -> None:
         del logits
         # ---- decode: the generate() loop body - forward(next_token, [1], cache) under the decode hipGraph context
         # (capture happens inside the warm-up steps; W >= 2 keeps it out of the timed region)
+        units_moved = None
         if world == 1 and opt.loop == "greedy":
             # generate()'s temperature-0 loop body (mistral_inference/generate.py -> Transformer.greedy_session): one
             # native call per token - argmax + log-softmax are the LM head's epilogue, the sample feeds the next step on
@@ -329,6 +330,7 @@ def main() -> None:
                 toks, _ = sess.collect()         # verifies that the device completed every step (and which path ran)
                 left -= n
             nxt = toks[-1]
+            units_moved = sess.units_moved
         else:
             # the sampling loop's body (temperature > 0, or pipeline stages): forward() under the decode hipGraph + torch.argmax
             ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
@@ -372,6 +374,7 @@ def main() -> None:
                                    f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
                        "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
                        "decode_launch": decode_launch_label(),
+                       "engine_w13_units_rebalanced": units_moved,
                        "parallelism": "single GPU" if world == 1 else
                        f"pp{world} (layer ranges; {type(model.pp_comm).__name__} send/recv + logits broadcast, process group "
                        f"{torch.distributed.get_backend()})"},

@@ -265,6 +265,14 @@ int mi_set_decode_engine(int enabled);
  * steps that did complete is status word 5.  Timeouts AFTER the census (codes 0x100-0x600) should not exist; they poison
  * the workspace the same way but may leave a half-written step. */
 int mi_decode_engine_census(int forget);
+/* W1|W3 load balance of the engine.  That phase (54 % of a layer's bytes) ends in an all-to-all, so every workgroup waits
+ * for the slowest one; part of who is slow is systematic (XCD position, single CUs).  The kernel samples, per workgroup,
+ * how long it waited at that hand-off; this call (mode 0) reads the samples and moves W1|W3 units - whose outputs are not
+ * tied to a workgroup - from late workgroups to early ones in the table the next launches read.  Host-side, SYNCHRONISES
+ * the stream: call it where the caller synchronises anyway (GreedySession.collect does).  mode 1 restores the uniform
+ * split, mode 2 installs a skewed split (tests).  *moved = units that changed owner.  Results never depend on the split. */
+int mi_decode_engine_balance(const mi_model_t* model, void* workspace, size_t workspace_bytes, int max_cache_size, int mode,
+                             int* moved, mi_stream_t stream);
 int mi_decode_engine_reset(void* workspace, mi_stream_t stream);
 /* Copies the engine's control words out of a workspace and synchronises `stream` (a health check, NOT part of the hot
  * path): status[0] = step epoch, status[1] = 0 or the code of the first bounded wait that ever timed out
@@ -289,9 +297,10 @@ int mi_debug_set_engine_trace(void* dev_buffer);
 int mi_debug_set_engine_knobs(int thin, int depth);
 /* holder waves on (1) / off (0) / environment default (-1); results never depend on it (bit-identical either way) */
 int mi_debug_set_engine_holders(int on);
-/* Test hook: the next `launches` engine launches wait for one workgroup more than exist, i.e. fail their residency gate
- * after its ~50 ms bound exactly as a launch with a missing workgroup would (status 0x700, nothing written). */
-int mi_debug_engine_sabotage(int launches);
+/* Test hook: the next `launches` engine launches on this workspace (hipGraph replays included: the count lives in the
+ * workspace) wait for one workgroup more than exist, i.e. fail their residency gate after its ~50 ms bound exactly as a
+ * launch with a missing workgroup would (status 0x700, nothing written).  Synchronises the stream. */
+int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pipeline-parallel exchange steps over RCCL (xGMI between the GPUs of a node)

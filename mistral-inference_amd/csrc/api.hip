@@ -437,15 +437,33 @@ int mi_decode_engine_reset(void* workspace, mi_stream_t stream) {
   return MI_OK;
 }
 
+int mi_decode_engine_balance(const mi_model_t* m, void* workspace, size_t workspace_bytes, int max_cache_size, int mode,
+                             int* moved, mi_stream_t stream) {
+  MI_TRY(check_model(m));
+  if (!workspace || mode < 0 || mode > 2) return fail(MI_ERR_ARG, "mi_decode_engine_balance");
+  if (moved) *moved = 0;
+  Workspace ws = carve(m, 1, 1, max_cache_size > 0 ? max_cache_size : 1, (char*)workspace);
+  if (ws.total > workspace_bytes) return fail(MI_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
+  if (!ws.gran_bytes) return MI_OK;  // MoE models: no engine, nothing to balance
+  EngProblem pr;
+  memset(&pr, 0, sizeof(pr));
+  pr.D = m->dim; pr.H = m->n_heads; pr.Hkv = m->n_kv_heads; pr.F = m->hidden_dim; pr.V = m->vocab_size; pr.NB = device_cus();
+  pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes;
+  return hip_rc(decode_engine_balance(pr, mode, moved, (hipStream_t)stream), "engine balance");
+}
+
 int mi_greedy_sample(const float* logits, int ld, int B, int vocab, int64_t* token, float* logprob, mi_stream_t stream) {
   if (!logits || !token || !logprob || B <= 0 || vocab <= 0 || ld < vocab) return fail(MI_ERR_ARG, "mi_greedy_sample");
   return hip_rc(launch_greedy_rows(logits, ld, B, vocab, token, logprob, nullptr, nullptr, 0, nullptr, (hipStream_t)stream),
                 "greedy sample");
 }
 
-int mi_debug_engine_sabotage(int launches) {
-  decode_engine_sabotage(launches);
-  return MI_OK;
+int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream) {
+  if (!workspace || launches < 0) return fail(MI_ERR_ARG, "mi_debug_engine_sabotage");
+  static thread_local uint32_t v;
+  v = (uint32_t)launches;
+  MI_TRY(hip_rc(hipMemcpyAsync((uint32_t*)workspace + 7, &v, 4, hipMemcpyHostToDevice, (hipStream_t)stream), "sabotage word"));
+  return hip_rc(hipStreamSynchronize((hipStream_t)stream), "sabotage sync");
 }
 
 int mi_decode_engine_census(int forget) {

@@ -43,11 +43,15 @@ constexpr int NCONS = 4;
 #ifndef ENG_HOLDERS
 #define ENG_HOLDERS 3  // holder waves per workgroup (0: none)
 #endif
+// Three round-3 experiments, all MEASURED SLOWER on the full model (same box, profiles/EXPERIMENTS.md) and therefore off:
 #ifndef ENG_SPARSE_POLL
-#define ENG_SPARSE_POLL 1  // repeated hand-off sweeps re-read only the granules that were missing (0: the whole batch, A/B)
+#define ENG_SPARSE_POLL 0  // 1: repeated hand-off sweeps re-read only the granules that were missing (+25 us per step)
 #endif
 #ifndef ENG_LEAN_BARRIERS
-#define ENG_LEAN_BARRIERS 1  // drop the consumer barriers that the RMSNorm's own barrier already implies (0: round-2 set, A/B)
+#define ENG_LEAN_BARRIERS 0  // 1: waves 1-3 start the attn sweep while wave 0 still merges the splits (+45 us per step)
+#endif
+#ifndef ENG_CBAR_FLAGS
+#define ENG_CBAR_FLAGS 0  // 1: consumer barrier on per-wave flag words polled without sleeping (+10..20 us per step)
 #endif
 constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
@@ -85,12 +89,12 @@ enum : int {
   C_XREADY = 13,    // (layer + 1) once ffn_norm(h1) of that layer stands in the activation region (consumers -> holders)
   C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
-  C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag barrier, 16-byte aligned)
-  C_AMAX = 20       // [NCONS][3] per-wave (max logit, its index, sum exp) of the LM head
+  C_BARW = 16       // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
 };
 // global control words (workspace): [0] step epoch, [1] sticky status, [2] abort broadcast, [3] bad token id, [4] engine
 // launches completed, [5] decode steps committed (index into the greedy history ring), [6] workgroup arrivals
-enum : int { G_EPOCH = 0, G_STATUS = 1, G_ABORT = 2, G_BADID = 3, G_LAUNCHES = 4, G_STEPS = 5, G_ARRIVE = 6 };
+// [7] test hook: engine launches that shall fail their residency gate (mi_debug_engine_sabotage)
+enum : int { G_EPOCH = 0, G_STATUS = 1, G_ABORT = 2, G_BADID = 3, G_LAUNCHES = 4, G_STEPS = 5, G_ARRIVE = 6, G_SABOTAGE = 7 };
 constexpr uint32_t ARRIVE_POLLS = 1u << 16;  // ~50 ms: far beyond the ~1 us over which a resident grid starts
 
 // Optional timeline (mi_debug_set_engine_trace): trace[c][layer][event] = 100 MHz wall clock.  Consumer wave 0 writes
@@ -165,6 +169,13 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
   p.v1 = p.k1;
   slab(a.D / 2, c, a.NB, p.o0, p.o1);
   slab(a.F / 2, c, a.NB, p.f0, p.f1);
+  if (a.f_tab && a.f_tab[a.NB] == (uint16_t)(a.F / 2) && a.f_tab[0] == 0) {  // balanced split (decode_engine_balance)
+    const int t0 = a.f_tab[c], t1 = a.f_tab[c + 1];
+    if (t0 <= t1 && t1 <= a.F / 2) {
+      p.f0 = t0;
+      p.f1 = t1;
+    }
+  }
   slab(a.H * DH / 2, c, a.NB, p.e0, p.e1);
   const int kv_len = min(pos + 1, L.W);
   p.cur_slot = pos % L.W;
@@ -369,8 +380,8 @@ struct Cons {
   __device__ __forceinline__ void set_done(uint32_t piece_idx) { sh.ctl[C_DONE + w] = piece_idx; }
 
   // barrier among the NCONS consumer waves (the loader and the holders never take part, so s_barrier is out)
-#ifdef ENG_CBAR_ATOMIC
-  __device__ __forceinline__ void cbar() {  // round-2 form: one shared counter (A/B)
+#if !ENG_CBAR_FLAGS
+  __device__ __forceinline__ void cbar() {  // one shared counter; waiting waves sleep between polls, which leaves the SIMD's issue slots to the wave still working
     cbar_target += NCONS;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_CBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -380,9 +391,9 @@ struct Cons {
     asm volatile("" ::: "memory");
   }
 #else
-  // Flag barrier: every wave stores the phase it has reached into its own word and polls all four with ONE 16-byte
-  // LDS read.  No atomic, no sleep on the first polls (the four waves reach most barriers within ~100 cycles of each
-  // other; the counter form paid an atomic + s_sleep + two dependent LDS reads per failed poll, 14 times a layer).
+  // Flag barrier (experiment): every wave stores the phase it has reached into its own word and polls all four with ONE
+  // 16-byte LDS read, no atomic, no sleep on the first polls.  Slower in practice: the tight polls of the early waves take
+  // issue slots and LDS cycles from the wave that is still working on the same SIMD.
   __device__ __forceinline__ void cbar() {
     ++cbar_target;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic of the phase is done
@@ -649,6 +660,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   const int nq = a.H * DH, nkv = a.Hkv * DH;
   uint32_t g = 0;  // first piece of the current segment
   uint32_t hold_target = 0;  // W1|W3 units the holder waves must have finished (cumulative)
+  uint32_t stat_wait = 0, stat_dur = 0, stat_n = 0;  // load-balance samples (wave 0, lane 0)
   long greedy_token = 0;     // the fused greedy sample (workgroup 0, wave 0, lane 0)
   float greedy_logprob = 0.f;
   bool greedy_valid = false;
@@ -709,6 +721,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           __builtin_amdgcn_s_sleep(8);
           if (sh.ctl[C_ABORT] || ++polls >= ARRIVE_POLLS) {
             raise_abort(sh, 0x700);
+            if (c == 0 && lane == 0 && sh.ctrl[G_SABOTAGE] != 0) sh.ctrl[G_SABOTAGE] -= 1;  // (every workgroup read it at entry)
             break;
           }
         }
@@ -910,6 +923,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 12, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
+    uint64_t t_norm2 = 0;
+    if (a.f_stat && trc && (l & 7) == 3) t_norm2 = __builtin_amdgcn_s_memrealtime();
     const int n_hold = holder_units(a, p.f1 - p.f0);
     if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
     {
@@ -932,6 +947,11 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
     // ================================================================ h = h1 + hid @ W2^T
     cs.cbar();
+    // load-balance statistics on every 8th layer (a clock read is an SMEM round trip: not on every layer): how long this
+    // workgroup's W1|W3 phase took and how long it then waits for the slowest workgroup's hid values
+    const bool sample = a.f_stat && trc && (l & 7) == 3;
+    uint64_t t_w13 = 0;
+    if (sample) t_w13 = __builtin_amdgcn_s_memrealtime();
     if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
       hold_target += (uint32_t)n_hold;
       uint32_t spins = 0;
@@ -942,6 +962,12 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
+    if (sample) {
+      const uint64_t t_hid = __builtin_amdgcn_s_memrealtime();
+      stat_wait += (uint32_t)(t_hid - t_w13);
+      stat_dur += (uint32_t)(t_w13 - t_norm2);
+      ++stat_n;
+    }
     trace_ev(sh, c, l, 15, trc);
     {
       const int n_u = p.o1 - p.o0;
@@ -979,67 +1005,59 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     int v0, v1;
     slab(a.V / 2, c, a.NB, v0, v1);
-    // greedy sampling rides on the LM head (generate.py:124-136 at temperature 0): every wave keeps the running
-    // (max, first index of the max, sum of exp(x - max)) of the logits it produces
-    float bm = -INFINITY, bs = 0.f;
-    int bi = 0x7fffffff;
-    auto fold = [&](float x, int idx) {
-      if (x > bm) {
-        bs = bs * __expf(bm - x) + 1.f;
-        bm = x;
-        bi = idx;
-      } else {
-        bs += __expf(x - bm);
-      }
-    };
+    // greedy sampling rides on the LM head (generate.py:124-136 at temperature 0).  Inside the row loop the only extra work
+    // is one LDS store of the two logits (a running max / sum-exp in the loop cost 18 us per step: it sits in the
+    // dependency chain of every unit); the reduction runs once, afterwards, on wave 0.
+    lf32* lg_lds = reinterpret_cast<lf32*>(sh.xs + (size_t)a.D * 2);  // behind the normalised activations: 2 (v1 - v0) floats
+    const bool greedy = a.greedy_tok != nullptr;
     for (int k = w; k < v1 - v0; k += NCONS) {
       const uint32_t ga = g + (uint32_t)(2 * k) * PD;
       cs.set_done(ga);
       float vv[2];
       cs.template unit_dot<2>(ga, PD, xs, vv);
-      const float y0 = bf_round(vv[0]), y1 = bf_round(vv[1]);
       if (lane == 0) {
-        float2 o = make_float2(y0, y1);
-        *reinterpret_cast<float2*>(a.logits + 2 * (size_t)(v0 + k)) = o;
-      }
-      if (a.greedy_tok) {  // (wave-uniform values: every lane folds the same numbers)
-        fold(y0, 2 * (v0 + k));
-        fold(y1, 2 * (v0 + k) + 1);
+        const float y0 = bf_round(vv[0]), y1 = bf_round(vv[1]);
+        *reinterpret_cast<float2*>(a.logits + 2 * (size_t)(v0 + k)) = make_float2(y0, y1);
+        if (greedy) *reinterpret_cast<LDS_AS u32x2*>(lg_lds + 2 * k) = u32x2{__float_as_uint(y0), __float_as_uint(y1)};
       }
     }
     g += (uint32_t)(2 * (v1 - v0)) * PD;
     cs.set_done(0xffffffffu);
-    if (a.greedy_tok) {
-      // wave partials -> workgroup partial -> three granules per workgroup -> workgroup 0 reduces them all.
+    if (greedy) {
+      // workgroup partial (max, FIRST index of the max, sum exp(x - max)) -> three granules -> workgroup 0 reduces them all.
       // Ties: the lower index wins at every level (torch.argmax returns the first maximal element).
-      lf32* am = reinterpret_cast<lf32*>((lu32*)(sh.ctl + C_AMAX));
-      if (lane == 0) {
-        am[w * 3 + 0] = bm;
-        am[w * 3 + 1] = __int_as_float(bi);
-        am[w * 3 + 2] = bs;
-      }
       cs.cbar();
       const uint32_t tg = tag_of(a.n_layers - 1, 6);
       if (w == 0) {
-        float M = am[0], S = am[2];
-        int I = __float_as_int(am[1]);
-#pragma unroll
-        for (int j = 1; j < NCONS; ++j) {
-          const float m2 = am[j * 3], s2 = am[j * 3 + 2];
-          const int i2 = __float_as_int(am[j * 3 + 1]);
-          if (m2 > M || (m2 == M && i2 < I)) {
-            S = S * __expf(M - m2) + s2;
-            M = m2;
-            I = i2;
-          } else if (s2 > 0.f) {
-            S += s2 * __expf(m2 - M);
+        const int n = 2 * (v1 - v0);
+        float M = -INFINITY, S = 0.f;
+        int I = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {  // ascending indices per lane: `>` keeps the first maximum
+          const float x = lg_lds[i];
+          if (x > M) {
+            S = S * __expf(M - x) + 1.f;
+            M = x;
+            I = 2 * v0 + i;
+          } else {
+            S += __expf(x - M);
           }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float m2 = __shfl_xor(M, o, 64), s2 = __shfl_xor(S, o, 64);
+          const int i2 = __shfl_xor(I, o, 64);
+          const bool take = m2 > M || (m2 == M && i2 < I);
+          const float Mn = take ? m2 : M;
+          S = S * (M == Mn ? 1.f : __expf(M - Mn)) + s2 * (m2 == Mn ? 1.f : __expf(m2 - Mn));
+          M = Mn;
+          I = take ? i2 : I;
         }
         if (lane < 3)
           cs.publish(G + a.g_amax + (size_t)c * 4 + lane, tg, lane == 0 ? __float_as_uint(M) : (lane == 1 ? (uint32_t)I : __float_as_uint(S)));
       }
       if (c == 0) {
-        lu32* red = xs32;  // the activation region is free: every wave of this workgroup is past its LM-head rows (cbar above)
+        // staging behind the logits stash (wave 0 may still be reading the stash when waves 1-3 begin the sweep)
+        lu32* red = reinterpret_cast<lu32*>(lg_lds + ((2 * ((a.V / 2 + a.NB - 1) / a.NB) + 3) & ~3));
         sh.ctl[C_GATHERING] = 1;
         cs.gather_fn<4>(4 * a.NB, tg, red, [&](int i) { return G + a.g_amax + ((i & 3) == 3 ? i - 3 : i); });
         cs.cbar();
@@ -1078,6 +1096,13 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     }
   } else {
     cs.set_done(0xffffffffu);
+  }
+
+  if (stat_n && w == 0 && lane == 0 && !sh.ctl[C_ABORT]) {  // one writer per workgroup; the host reads and zeroes (decode_engine_balance)
+    uint32_t* st = a.f_stat + 4 * c;
+    st[0] += stat_wait;
+    st[1] += stat_dur;
+    st[2] += stat_n;
   }
 
   // ================================================================ commit (workgroup 0, one lane): the step becomes visible
@@ -1210,7 +1235,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
       uint32_t old = 0;
       if (lane == 0) old = __hip_atomic_fetch_add(sh.ctrl + G_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-      arrive_target = (old / (uint32_t)a.NB + 1u) * (uint32_t)a.NB + (uint32_t)a.arrive_extra;
+      arrive_target = (old / (uint32_t)a.NB + 1u) * (uint32_t)a.NB;
+      // test hook: wait for one workgroup more than exist - the gate fails exactly as it would with one missing
+      if (__hip_atomic_load(sh.ctrl + G_SABOTAGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) arrive_target += 1u;
     }
     run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
   }
@@ -1225,7 +1252,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
 namespace {
 struct GranLayout {
   uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, g_amax, total;
+  size_t tune_off;
 };
+constexpr size_t TUNE_TAB_BYTES = 2304, TUNE_STAT_BYTES = 1024 * 16;
 constexpr int AMAX_MAX_NB = 1024;  // workgroups the greedy-sampling edge is sized for (decode_engine_applicable: NB <= 1024)
 GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   using attn_core::DH;
@@ -1240,6 +1269,7 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   g.g_part = off; off += (uint32_t)((size_t)Hs * max_splits * R * (DH + 2));
   g.g_amax = off; off += 4 * AMAX_MAX_NB;  // (max logit, argmax, sum exp, pad) per workgroup
   g.total = off;
+  g.tune_off = ((size_t)off * 8 + 255) / 256 * 256;  // bytes: W1|W3 balance table (uint16 [1025], padded) then statistics
   return g;
 }
 }  // namespace
@@ -1247,7 +1277,7 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
 size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW) {
   if (Hkv <= 0 || H % Hkv) return 0;
   (void)maxW;  // sized for the maximum of 32 splits so that the layout depends on the model only
-  return (size_t)gran_layout(D, H, Hkv, F, 32).total * 8;
+  return gran_layout(D, H, Hkv, F, 32).tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES;
 }
 
 bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
@@ -1262,6 +1292,8 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch
   if ((size_t)kmax * 2 > region) return no("activation vector does not fit beside the 8-fill ring");
+  if ((size_t)pr.D * 2 + (size_t)((pr.V / 2 + pr.NB - 1) / pr.NB) * 8 + 16 + (size_t)pr.NB * 16 > region)
+    return no("LM-head logits stash + greedy reduction staging");
   const int NB = pr.NB;
   if (NB < 8 || NB > 1024) return no("CU count");
   if (((pr.D / 2 + NB - 1) / NB) * 2 * 2 > RES_BYTES) return no("residual slab");
@@ -1283,6 +1315,7 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
 namespace {
 uint64_t* g_trace = nullptr;
 int g_thin = -1, g_depth = -1, g_holders = -1;
+int g_balance_stats = -1;  // the kernel samples its W1|W3 phase for decode_engine_balance (MI_ENGINE_BALANCE=0: never)
 }
 void decode_engine_set_holders(int on) { g_holders = on; }
 void decode_engine_set_knobs(int thin, int depth) {
@@ -1344,10 +1377,6 @@ int engine_census(int dev, int nb, uint32_t* ctrl, hipStream_t s) {
   return g_census[dev] = 1;
 }
 }  // namespace
-namespace {
-int g_sabotage = 0;
-}
-void decode_engine_sabotage(int launches) { g_sabotage = launches; }
 const char* decode_engine_census_detail() { return g_census_why; }
 void decode_engine_forget_census() { memset(g_census, 0, sizeof(g_census)); }
 
@@ -1390,7 +1419,13 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
   a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
   a.g_amax = gl.g_amax;
-  if ((size_t)gl.total * 8 > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
+  if (gl.tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
+  a.f_tab = reinterpret_cast<const uint16_t*>((const char*)pr.granules + gl.tune_off);
+  if (g_balance_stats < 0) {
+    const char* e = getenv("MI_ENGINE_BALANCE");
+    g_balance_stats = e ? (atoi(e) != 0) : 1;
+  }
+  a.f_stat = g_balance_stats ? reinterpret_cast<uint32_t*>((char*)pr.granules + gl.tune_off + TUNE_TAB_BYTES) : nullptr;
 
   for (int l0 = 0; l0 < pr.n_layers; l0 += ENG_MAXL) {
     const int nl = pr.n_layers - l0 < ENG_MAXL ? pr.n_layers - l0 : ENG_MAXL;
@@ -1434,14 +1469,93 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
       if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 64) attr_set[dev][a.R] = true;
     }
-    a.arrive_extra = 0;
-    if (g_sabotage > 0) {
-      --g_sabotage;
-      a.arrive_extra = 1;
-    }
     void* params[] = {(void*)&a};
     hipError_t e = hipLaunchKernel(fn, dim3(pr.NB), dim3(NTHREADS), params, LDS_TOTAL, s);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------------- W1|W3 load balance
+// The W1|W3 phase is 54 % of a layer's bytes and ends in an all-to-all: every workgroup waits for the SLOWEST one's hid
+// values.  The trace shows a systematic part in who is slow (profiles/r03_*: odd XCDs ~2 us late on this phase - and only
+// this phase - on every layer; single CUs up to 2.3 us late on average) next to ~1.5 us of per-layer jitter.  W1|W3 outputs
+// are not tied to a workgroup's residual slab, so the split of its units is free: the kernel samples (every 8th layer) how
+// long each workgroup waited at the hid hand-off, and this host routine - called where the caller synchronises anyway
+// (GreedySession.collect) - moves units from the workgroups that waited least (late) to those that waited longest
+// (early), one unit (~1 us) at a time while the gap exceeds 1.5 units.  Results are bit-identical for any split.
+hipError_t decode_engine_balance(const EngProblem& pr, int mode, int* moved, hipStream_t s) {
+  if (moved) *moved = 0;
+  const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
+  if (!pr.granules || gl.tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES > pr.granule_bytes) return hipErrorInvalidValue;
+  const int NB = pr.NB, U = pr.F / 2;
+  if (NB < 1 || NB > 1024 || U > 65535) return hipErrorInvalidValue;
+  char* tab_dev = (char*)pr.granules + gl.tune_off;
+  char* stat_dev = tab_dev + TUNE_TAB_BYTES;
+  static thread_local uint16_t tab[1025];
+  static thread_local uint32_t stat[1024 * 4];
+  hipError_t e = hipMemcpyAsync(tab, tab_dev, (NB + 1) * 2, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(stat, stat_dev, (size_t)NB * 16, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  int n[1024];
+  const bool valid = tab[NB] == (uint16_t)U && tab[0] == 0;
+  for (int c = 0; c < NB; ++c)
+    n[c] = valid ? (int)tab[c + 1] - (int)tab[c] : (int)((long)U * (c + 1) / NB) - (int)((long)U * c / NB);
+  int changed = 0;
+  if (mode == 1) {
+    for (int c = 0; c < NB; ++c) {
+      const int u = (int)((long)U * (c + 1) / NB) - (int)((long)U * c / NB);
+      changed += abs(u - n[c]);
+      n[c] = u;
+    }
+  } else if (mode == 2) {  // tests: a deterministic, strongly skewed split (some workgroups below the holder threshold)
+    for (int c = 0; c < NB; ++c) n[c] = (int)((long)U * (c + 1) / NB) - (int)((long)U * c / NB);
+    for (int c = 0; c + 1 < NB; c += 2) {
+      const int d = (c / 2) % 4 < n[c] ? (c / 2) % 4 : 0;
+      n[c] -= d;
+      n[c + 1] += d;
+      changed += 2 * d;
+    }
+  } else {
+    double wait[1024], mean_wait = 0, mean_dur = 0;
+    int with = 0;
+    for (int c = 0; c < NB; ++c)
+      if (stat[4 * c + 2]) {
+        wait[c] = stat[4 * c] / (100.0 * stat[4 * c + 2]);  // us (100 MHz clock)
+        mean_wait += wait[c];
+        mean_dur += stat[4 * c + 1] / (100.0 * stat[4 * c + 2]);
+        ++with;
+      }
+    if (with == NB && stat[2] >= 8) {  // every workgroup has samples, and enough of them (>= 2 steps of 32 layers)
+      mean_wait /= NB;
+      mean_dur /= NB;
+      const double ut = mean_dur / ((double)U / NB);  // time of one unit
+      double late[1024];
+      for (int c = 0; c < NB; ++c) late[c] = mean_wait - wait[c];  // waited less than the others = finished later
+      const int floor_units = U / NB - 4 > 12 ? U / NB - 4 : (U / NB > 2 ? U / NB - 2 : 1);
+      for (int it = 0; it < NB; ++it) {
+        int hi = 0, lo = 0;
+        for (int c = 1; c < NB; ++c) {
+          if (late[c] > late[hi]) hi = c;
+          if (late[c] < late[lo]) lo = c;
+        }
+        if (late[hi] - late[lo] <= 1.5 * ut || n[hi] <= floor_units || n[lo] >= U / NB + 4) break;
+        --n[hi];
+        ++n[lo];
+        late[hi] -= ut;
+        late[lo] += ut;
+        changed += 2;
+      }
+    }
+  }
+  tab[0] = 0;
+  for (int c = 0; c < NB; ++c) tab[c + 1] = (uint16_t)(tab[c] + n[c]);
+  if (tab[NB] != (uint16_t)U) return hipErrorInvalidValue;  // (cannot happen: every move keeps the total)
+  memset(stat, 0, (size_t)NB * 16);
+  e = hipMemcpyAsync(tab_dev, tab, (NB + 1) * 2, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(stat_dev, stat, (size_t)NB * 16, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (moved) *moved = changed / 2;
+  return e;
 }

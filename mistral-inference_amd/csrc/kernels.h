@@ -201,7 +201,6 @@ struct EngArgs {
   int holders;            // 1: holder waves take the last W1|W3 units of every CU's slab (A/B: MI_ENGINE_HOLDERS=0)
   int commit;             // 1: this launch ends the decode step: workgroup 0 advances kv_seqlens / epoch / step counter
   int hist_len;           // entries of the greedy history ring (0: none)
-  int arrive_extra;       // debug (mi_debug_engine_sabotage): workgroups the residency gate waits for beyond NB - it fails
   float eps;
   bf16_t* h;              // [D] residual stream, in (first layer, unless emb) / out (last layer)
   const bf16_t* emb;      // token embedding table [V, D]: the first layer's input is row ids[0] (nullptr: read h)
@@ -219,6 +218,8 @@ struct EngArgs {
   uint64_t* gran;         // granule regions
   uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
   uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, g_amax;
+  const uint16_t* f_tab;  // [NB + 1] first W1|W3 unit of every workgroup (valid iff f_tab[NB] == F / 2), see decode_engine_balance
+  uint32_t* f_stat;       // [NB][4] per workgroup: ticks waited at the hid hand-off, ticks of the W1|W3 phase, samples, -
   unsigned long long* trace;  // optional timeline buffer (debug)
   EngLayer L[ENG_MAXL];
 };
@@ -255,8 +256,10 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len);
 hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* declined);
 const char* decode_engine_census_detail();
 void decode_engine_forget_census();  // tests
-void decode_engine_sabotage(int launches);  // tests: the next `launches` engine launches fail their residency gate
 void decode_engine_set_trace(void* dev_buffer);  // debug: nullptr disables
 void decode_engine_set_knobs(int thin, int depth);  // debug / tuning
 void decode_engine_set_holders(int on);             // debug / A/B: -1 = environment default
+// W1|W3 load balance (decode_engine.hip): mode 0 adapt from the statistics the kernel collected, 1 uniform split, 2 a
+// deterministic skewed split (tests).  Synchronises `s`.  *moved = units that changed owner.
+hipError_t decode_engine_balance(const EngProblem& pr, int mode, int* moved, hipStream_t s);
 size_t decode_engine_trace_bytes(int NB);

@@ -88,6 +88,7 @@ _SIGS = {
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_census": (C.c_int, [C.c_int]),
     "mi_decode_engine_reset": (C.c_int, [_vp, _vp]),
+    "mi_decode_engine_balance": (C.c_int, [C.POINTER(MiModel), _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int), _vp]),
     "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "mi_rccl_unique_id": (C.c_int, [_vp]),
     "mi_rccl_init": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
@@ -101,7 +102,7 @@ _SIGS = {
     "mi_debug_engine_trace_bytes": (C.c_size_t, []),
     "mi_debug_set_engine_trace": (C.c_int, [_vp]),
     "mi_debug_set_engine_knobs": (C.c_int, [C.c_int, C.c_int]),
-    "mi_debug_engine_sabotage": (C.c_int, [C.c_int]),
+    "mi_debug_engine_sabotage": (C.c_int, [_vp, C.c_int, _vp]),
     "mi_debug_set_engine_holders": (C.c_int, [C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -352,6 +353,11 @@ def decode_engine_status(workspace: torch.Tensor) -> dict:
     check(lib().mi_decode_engine_status(workspace.data_ptr(), stream_ptr(workspace.device), st), "mi_decode_engine_status")
     return {"epoch": int(st[0]), "status": int(st[1]), "abort": int(st[2]), "bad_id": int(st[3]), "engine_launches": int(st[4]),
             "steps": int(st[5]), "arrivals": int(st[6])}
+
+
+def debug_engine_sabotage(workspace: torch.Tensor, launches: int) -> None:
+    """Test hook: the next `launches` engine launches on this workspace fail their residency gate."""
+    check(lib().mi_debug_engine_sabotage(workspace.data_ptr(), launches, stream_ptr(workspace.device)), "mi_debug_engine_sabotage")
 
 
 def decode_engine_reset(workspace: torch.Tensor) -> None:

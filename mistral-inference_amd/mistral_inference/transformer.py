@@ -19,6 +19,7 @@ import ctypes as C
 import json
 import logging
 import math
+import os
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Any, List, Mapping, Optional, Union
@@ -140,6 +141,18 @@ class HipStackBackend:
                     if st["status"] == 0x700 else "a bounded wait timed out; the step's outputs are undefined")
             raise RuntimeError(f"persistent decode engine: status 0x{st['status']:x} - {what}.  "
                                "MI_DECODE_ENGINE=0 selects the launch path.")
+
+    def balance_engine(self, model: "Transformer", mode: int = 0) -> int:
+        """W1|W3 load balance of the persistent decode engine (include/mistral_hip.h mi_decode_engine_balance): reads the
+        hand-off waits the kernel sampled and moves units from late workgroups to early ones.  Synchronises.  Returns the
+        number of units moved (0 for MoE models / no samples)."""
+        if self._workspace is None:
+            return 0
+        moved = C.c_int(0)
+        ws = self._workspace
+        _hip.check(_hip.lib().mi_decode_engine_balance(C.byref(self.plan(model)), ws.data_ptr(), ws.numel(), 1, mode,
+                                                       C.byref(moved), _hip.stream_ptr(ws.device)), "mi_decode_engine_balance")
+        return int(moved.value)
 
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
         need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
@@ -597,6 +610,8 @@ class GreedySession:
     only what is done with its result moved onto the device."""
 
     HIST = 1024
+    GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "8"))   # decode steps per hipGraph launch (1: one graph per token)
+    BALANCE = os.environ.get("MI_ENGINE_BALANCE", "1") != "0"    # adapt the engine's W1|W3 split at collect() time
 
     def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
         assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"
@@ -613,11 +628,13 @@ class GreedySession:
         self.logits = torch.empty((B, model.vocab_size), dtype=torch.float32, device=dev)
         self.h = torch.empty((B, model.args.dim), dtype=model.dtype, device=dev)
         self._use_graph = graph and dev.type == "cuda"
-        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graphs: dict = {}            # steps per graph -> captured hipGraph
         self._warm = False
         self._base: Optional[int] = None   # value of the workspace's step counter when this session began
         self._pending = 0                  # steps enqueued and not yet collected
         self._n_collected = 0
+        self._balance_calls = 0
+        self.units_moved = 0               # W1|W3 units the engine's load balancer re-assigned during this session
 
     # -- one step, enqueued launch by launch
     def _step_eager(self) -> None:
@@ -638,31 +655,51 @@ class GreedySession:
             self._step_eager()
             self._warm = True
             return
-        if self._use_graph and self._graph is None:
-            torch.cuda.synchronize(m.device)
+        if self._use_graph:
+            g = self._captured(1)
+            if g is not None:
+                g.replay()
+                return
+        self._step_eager()
+
+    def _captured(self, steps: int):
+        """hipGraph of `steps` consecutive decode steps (the sample of one is the input of the next on the device, so a
+        graph may hold any number of them).  Between two graph launches the GPU idles for a few microseconds that it does
+        not between two kernels of one graph: the loop is replayed GRAPH_STEPS steps at a time."""
+        g = self._graphs.get(steps)
+        if g is None:
+            torch.cuda.synchronize(self.model.device)
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):  # (capture enqueues nothing: the step itself is the replay below)
-                    self._step_eager()
-                self._graph = g
+                with torch.cuda.graph(g):  # (capture enqueues nothing: the steps themselves are the replays)
+                    for _ in range(steps):
+                        self._step_eager()
             except RuntimeError as e:  # a runtime that refuses to capture: launch by launch from here on
                 logging.warning("greedy decode step not graph-capturable (%s): continuing eagerly", e)
                 self._use_graph = False
-        if self._use_graph:
-            self._graph.replay()
-        else:
-            self._step_eager()
+                return None
+            self._graphs[steps] = g
+        return g
 
     def run(self, n: int) -> None:
-        """Enqueue n decode steps (no host synchronisation once the step has been captured)."""
+        """Enqueue n decode steps (no host synchronisation once the steps have been captured)."""
         cache = self.cache
         if max(cache._seen) + n > ROPE_TABLE_LEN:
             raise IndexError(f"position {max(cache._seen) + n - 1} is beyond the {ROPE_TABLE_LEN}-entry rotary table")
         assert self._pending + n <= self.HIST, "collect() before the history ring wraps"
-        for _ in range(n):
-            self._one_step()
-            cache.advance_host([1] * self.B)
-            self._pending += 1
+        left = n
+        while left > 0:
+            k = 1
+            if self._warm and self._use_graph and left >= self.GRAPH_STEPS > 1:
+                g = self._captured(self.GRAPH_STEPS)
+                if g is not None:
+                    g.replay()
+                    k = self.GRAPH_STEPS
+            if k == 1:
+                self._one_step()
+            cache.advance_host([k] * self.B)
+            self._pending += k
+            left -= k
 
     def collect(self, n: Optional[int] = None):
         """(tokens int64 [n, B], logprobs fp32 [n, B]) of the n oldest uncollected steps, on the host side of one
@@ -684,6 +721,10 @@ class GreedySession:
             self._recover(missing)
         elif done_total != issued_total:
             raise RuntimeError(f"decode steps issued {issued_total} != completed {done_total}")
+        elif self.BALANCE and self.B == 1 and self._balance_calls < 16:
+            # the stream is idle right here: let the engine re-balance its W1|W3 split from the waits it sampled
+            self._balance_calls += 1
+            self.units_moved += m._backend.balance_engine(m)
         first = self._collected()
         idx = torch.arange(first, first + n, device=m.device) + self._base
         idx = idx % self.HIST
@@ -704,7 +745,7 @@ class GreedySession:
         m, cache = self.model, self.cache
         _hip.decode_engine_reset(m._backend._workspace)
         _hip.set_decode_engine(False)
-        self._graph = None  # it holds the engine launch
+        self._graphs = {}  # they hold engine launches
         cache._seen = [p - missing for p in cache._seen]
         for _ in range(missing):
             self._step_eager()

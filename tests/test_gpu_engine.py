@@ -128,6 +128,33 @@ def test_two_launch_depth_vs_oracle_and_graph():
     assert worst < 6e-2, worst   # 34 layers of bf16 storage (the 32-layer floor of test_gpu_depth is 4.7e-2)
 
 
+@pytest.mark.parametrize("name", ["gqa4_window_wraps", "holders_mid_size"])
+def test_engine_bit_equal_for_any_w13_split(name):
+    """The W1|W3 load balancer (mi_decode_engine_balance) may hand any workgroup any number of units: results must not
+    move by a bit.  Mode 2 installs a strongly skewed split (0..3 units shifted between neighbours: at the mid size some
+    workgroups drop below the holder-wave threshold while their neighbours keep it), mode 1 the uniform one."""
+    p = SHAPES[name]
+    m, _ = _model(mo.OracleArgs(**p), seed=17)
+    prompt_len, steps = 40, 10
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(12)).cuda()
+    ref, ref_rings, _ = _run(m, ids, prompt_len, steps, engine=False)
+    _run(m, ids, prompt_len, 2, engine=True)             # (creates the workspace the table lives in)
+    assert m._backend.balance_engine(m, mode=2) > 0
+    got, got_rings, st = _run(m, ids, prompt_len, steps, engine=True)
+    graph, _, st2 = _run(m, ids, prompt_len, steps, engine=True, graph=True)
+    assert st["status"] == 0 and st2["status"] == 0
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)) and all(torch.equal(a, b) for a, b in zip(ref, graph))
+    for (k0, v0), (k1, v1) in zip(ref_rings, got_rings):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    # the adaptive mode on real samples: whatever it decides, the results stay put
+    m._backend.balance_engine(m, mode=0)
+    again, _, _ = _run(m, ids, prompt_len, steps, engine=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, again))
+    assert m._backend.balance_engine(m, mode=1) >= 0
+    back, _, _ = _run(m, ids, prompt_len, steps, engine=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, back))
+
+
 @pytest.mark.parametrize("holders", [1, 0])
 def test_holder_waves_fingerprint(holders):
     """Holder waves reduce their W1|W3 unit from REGISTERS, not from the ring: same arithmetic, same order - made visible

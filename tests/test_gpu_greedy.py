@@ -194,7 +194,7 @@ def test_residency_gate_failure_writes_nothing_and_steps_are_rerun():
         sess.run(4)
         a_t, _ = sess.collect()
         kv_before = int(c.kv_seqlens[0])
-        _hip.check(_hip.lib().mi_debug_engine_sabotage(1), "sabotage")
+        _hip.debug_engine_sabotage(m._backend._workspace, 1)
         sess.run(7)                       # the first of these fails its gate; the other six find the workspace poisoned
         torch.cuda.synchronize()
         st = _hip.decode_engine_status(m._backend._workspace)
@@ -207,11 +207,12 @@ def test_residency_gate_failure_writes_nothing_and_steps_are_rerun():
         assert torch.equal(got, ref_t), (got[:, 0].tolist(), ref_t[:, 0].tolist())
         assert _hip.set_decode_engine(True) is False      # the session switched the process to the launch path
         # forward() callers: the flag is raised (and cleared) by raise_if_flagged
-        _hip.check(_hip.lib().mi_debug_engine_sabotage(1), "sabotage")
+        _hip.debug_engine_sabotage(m._backend._workspace, 1)
         m.forward(first, [1], c)
         with pytest.raises(RuntimeError, match="0x700"):
             m._backend.raise_if_flagged()
         assert _hip.decode_engine_status(m._backend._workspace)["status"] == 0
     finally:
-        _hip.check(_hip.lib().mi_debug_engine_sabotage(0), "sabotage")
+        if m._backend._workspace is not None:
+            _hip.debug_engine_sabotage(m._backend._workspace, 0)
         _hip.set_decode_engine(True)
