@@ -15,7 +15,7 @@ BF = torch.bfloat16
 P8X7B_4L = dict(dim=4096, n_layers=4, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
                 vocab_size=2048, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2))
 PROMPT, STEPS = 20, 4
-SEED = 3   # chosen with `python tests/moe_depth_util.py`: no router near-tie anywhere in this run
+SEED = 17  # chosen with `python tests/moe_depth_util.py`: the closest router call of this run is 2.87 bf16 ulp (most seeds: < 1)
 
 
 def _lin(o, i, g):
@@ -77,12 +77,12 @@ def oracle_run(seed=SEED, sink=None, p=P8X7B_4L, prompt=PROMPT, steps=STEPS):
     return ids, logits, min_gap
 
 
-if __name__ == "__main__":  # seed search (host only): the first seed whose run has no near-tie (gap > 4 ulp everywhere)
+if __name__ == "__main__":  # seed search (host only): the first seed whose run has no near-tie (gap > 2.5 ulp everywhere)
     import sys
     import time
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 0, 64):
         t0 = time.time()
         _, lg, gap = oracle_run(seed)
         print(f"seed {seed}: min (2nd - 3rd) router gap = {gap:.2f} bf16 ulp, |logit|max {float(lg.abs().max()):.2f}, {time.time() - t0:.0f} s", flush=True)
-        if gap > 4.0:
+        if gap > 2.5:
             break
