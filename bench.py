@@ -38,6 +38,10 @@ PRESETS = {
     "mixtral-8x7b": (dict(dim=4096, n_layers=32, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
                           vocab_size=32000, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2)),
                      "Mixtral-8x7B"),
+    # BASELINE configs[4]: 281 GB of bf16 weights - needs the 8 pipeline stages north_star names (35 GB per stage)
+    "mixtral-8x22b": (dict(dim=6144, n_layers=56, head_dim=128, hidden_dim=16384, n_heads=48, n_kv_heads=8, norm_eps=1e-5,
+                           vocab_size=32768, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2)),
+                      "Mixtral-8x22B"),
 }
 
 
@@ -206,14 +210,15 @@ def port_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
     import torch.nn.functional as F
     import mistral_oracle as mo
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    p2 = dict(params, n_layers=2)
+    nl = 1 if params.get("moe") else 2   # (an 8-expert layer of the 8x7B dims is 2.9 GB of host weights)
+    p2 = dict(params, n_layers=nl)
     oargs = mo.OracleArgs.from_params(p2)
     w = mo.synth_weights(oargs, seed=1)
     om = mo.OracleModel(oargs, w)
     W = params.get("sliding_window") or ctx
-    cache = mo.OracleCache(2, 1, ctx + steps + 2, oargs.n_kv_heads, oargs.head_dim, params.get("sliding_window"),
+    cache = mo.OracleCache(nl, 1, ctx + steps + 2, oargs.n_kv_heads, oargs.head_dim, params.get("sliding_window"),
                            dtype=torch.bfloat16)
-    for l in range(2):  # a full ring, as after the 4096-token prefill
+    for l in range(nl):  # a full ring, as after the 4096-token prefill
         cache.k[l].copy_(torch.randn(cache.k[l].shape).to(torch.bfloat16))
         cache.v[l].copy_(torch.randn(cache.v[l].shape).to(torch.bfloat16))
     cache.seen = [ctx]
@@ -242,60 +247,25 @@ def port_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
         for _ in range(steps):
             F.linear(mo.rms_norm(h, w["norm.weight"], 1e-5), w["output.weight"]).float()
         t_head = (time.perf_counter() - t0) / steps
-    per_layer = max(1e-9, (t_full - t_head) / 2)
+    per_layer = max(1e-9, (t_full - t_head) / nl)
     t_model = t_head + params["n_layers"] * per_layer
     return {"value": round(1.0 / t_model, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle decode step at ctx {ctx} (W={W}) with 2 of {params['n_layers']} layers + LM head, "
+            "sample": f"oracle decode step at ctx {ctx} (W={W}) with {nl} of {params['n_layers']} layers + LM head, "
                       f"{steps} steps, bf16, {cores} threads; per-layer time x{params['n_layers']} + head "
                       f"({per_layer * 1e3:.1f} ms/layer, {t_head * 1e3:.1f} ms head)"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--prefill", type=int, default=4096, help="prompt tokens (BASELINE configs[1]: 4096)")
-    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers => NOT the named config")
-    ap.add_argument("--model", default="mistral-7b", choices=sorted(PRESETS), help="default = BASELINE configs[1]")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue decode steps launch by launch (no hipGraph replay)")
-    ap.add_argument("--loop", default="greedy", choices=["greedy", "forward"],
-                    help="greedy: generate()'s temperature-0 loop (sample fused into the step); forward: forward() + torch.argmax per token")
-    opt = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == opt.gpus, f"--gpus {opt.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
-    local = local % torch.cuda.device_count()  # (test rigs may run several ranks on one GPU)
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
-    if world > 1:
-        # "nccl" is RCCL on ROCm (xGMI between the GPUs of a node).  MI_DIST_BACKEND=gloo exists only so that the
-        # pipeline path can be exercised on a single-GPU box (RCCL refuses two ranks on one device).
-        torch.distributed.init_process_group(os.environ.get("MI_DIST_BACKEND", "nccl"))
-
-    params, model_name = PRESETS[opt.model]
-    params = dict(params)
-    if opt.layers:
-        params["n_layers"] = opt.layers
-    model = build_model(params, rank, world, dev)
-
+def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: int, Wm: int, sync):
+    """Build the model (this rank's pipeline stage), run one untimed and one timed T0-token prefill, W warm-up decode steps,
+    then time exactly K decode steps between two synchronisations (+ barriers).  Returns the model, its cache, the last
+    token, the decode seconds, the prefill seconds (both the maximum over ranks) and the engine's rebalanced unit count."""
     from mistral_inference.cache import BufferCache
+    model = build_model(params, rank, world, dev)
     a = model.args
-    T0, K, Wm = opt.prefill, opt.steps, opt.warmup
     cache = BufferCache(model.n_local_layers, 1, T0 + K + max(Wm, 2) + 64, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
                         dtype=torch.bfloat16)
     cache.reset()
     prompt = torch.randint(0, a.vocab_size, (T0,), generator=torch.Generator().manual_seed(0)).to(dev)
-
-    def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
     with torch.inference_mode():
         # ---- prefill: one untimed pass (allocates the workspace / logits buffers), then the timed pass on a
         # reset cache; includes the [T, V] fp32 LM head the API contract requires
@@ -347,7 +317,50 @@ def main() -> None:
         tmax = torch.tensor([dt, prefill_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt, prefill_s = tmax.tolist()
+    return model, cache, nxt, dt, prefill_s, units_moved
 
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--prefill", type=int, default=4096, help="prompt tokens (BASELINE configs[1]: 4096)")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers => NOT the named config")
+    ap.add_argument("--model", default="mistral-7b", choices=sorted(PRESETS), help="default = BASELINE configs[1]")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue decode steps launch by launch (no hipGraph replay)")
+    ap.add_argument("--loop", default="greedy", choices=["greedy", "forward"],
+                    help="greedy: generate()'s temperature-0 loop (sample fused into the step); forward: forward() + torch.argmax per token")
+    ap.add_argument("--no-mixtral", action="store_true", help="N > 1: skip the Mixtral sub-measurement")
+    ap.add_argument("--mixtral-layers", type=int, default=None, help="debug only: layers of the N > 1 Mixtral sub-measurement")
+    opt = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == opt.gpus, f"--gpus {opt.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    local = local % torch.cuda.device_count()  # (test rigs may run several ranks on one GPU)
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        # "nccl" is RCCL on ROCm (xGMI between the GPUs of a node).  MI_DIST_BACKEND=gloo exists only so that the
+        # pipeline path can be exercised on a single-GPU box (RCCL refuses two ranks on one device).
+        torch.distributed.init_process_group(os.environ.get("MI_DIST_BACKEND", "nccl"))
+
+    params, model_name = PRESETS[opt.model]
+    params = dict(params)
+    if opt.layers:
+        params["n_layers"] = opt.layers
+    T0, K, Wm = opt.prefill, opt.steps, opt.warmup
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    model, cache, nxt, dt, prefill_s, units_moved = timed_run(opt, params, rank, world, dev, T0, K, Wm, sync)
 
     from mistral_inference import _hip
     engine = _hip.decode_engine_status(model._backend._workspace)
@@ -384,21 +397,47 @@ def main() -> None:
                         "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
                         "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
         }
-        if not params.get("moe"):  # the dominant kernel is timed on this rank's own layers (any N)
-            if engine["engine_launches"] > 0 and world == 1:
-                with torch.inference_mode():
-                    out["roofline"] = engine_roofline(model, cache, nxt, params, iters=24)
+        # the dominant kernel is timed on this rank's own layers (any N)
+        if engine["engine_launches"] > 0 and world == 1:
+            with torch.inference_mode():
+                out["roofline"] = engine_roofline(model, cache, nxt, params, iters=24)
+            if not params.get("moe"):
                 out["launch_path_gemv_w13"] = dominant_kernel_roofline(model, iters=2)
-            else:
-                out["roofline"] = dominant_kernel_roofline(model, iters=4)
-        if world == 1 and not params.get("moe") and not opt.no_cpu_baseline:
+        elif not params.get("moe"):
+            out["roofline"] = dominant_kernel_roofline(model, iters=4)
+        else:  # MoE on the launch path: no single dominant kernel is timed - the whole-step figure is the roofline number
+            out["roofline"] = {"bound": "hbm", "kernel": "decode step (launch path: router + expert GEMVs)", "achieved": round(step_gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "bytes_per_launch": step_bytes}
+        if world == 1 and not opt.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, T0)
         return out
 
-
-
     out = report() if rank == 0 else None
-    if world > 1:  # the other ranks wait here while rank 0 times its dominant kernel, then everybody leaves together
+    if world > 1:  # the other ranks wait here while rank 0 times its dominant kernel
+        torch.distributed.barrier()
+    if world > 1 and not opt.no_mixtral and opt.model == "mistral-7b" and (not opt.layers or opt.mixtral_layers):
+        # north_star: "Mixtral-8x7B pipeline-parallel tokens/sec reported at 1/2/4/8 GPUs" (BASELINE configs[3], and
+        # configs[4] - Mixtral-8x22B over 8 stages - where 8 GPUs are present).  The N = 1 headline line is untouched; a
+        # multi-GPU run additionally measures the Mixtral model over the same N stages and reports it as a sub-object.
+        del model, cache, nxt
+        torch.cuda.empty_cache()
+        mx_name = "mixtral-8x22b" if world >= 8 else "mixtral-8x7b"
+        mx_params = dict(PRESETS[mx_name][0])
+        if opt.mixtral_layers:
+            mx_params["n_layers"] = opt.mixtral_layers
+        m2, c2, _, dt2, pre2, _ = timed_run(opt, mx_params, rank, world, dev, T0, K, Wm, sync)
+        if rank == 0:
+            ctx_len = T0 + Wm + K // 2
+            b2 = decode_bytes_per_token(mx_params, ctx_len)
+            out["mixtral"] = {"model": f"{PRESETS[mx_name][1]} dims, {mx_params['n_layers']} layers, random-init bf16, pp{world}",
+                              "tokens_per_s": round(K / dt2, 2), "ms_per_step": round(dt2 / K * 1e3, 4), "bytes_per_token": b2,
+                              "hbm_roofline_frac": round(b2 / (dt2 / K) / 1e9 / HBM_PEAK_GBS, 4),
+                              "prefill_tokens_per_s": round(T0 / pre2, 1),
+                              "prefill_mfma_frac": round(prefill_flops(mx_params, T0) / pre2 / 2.5e15 / world, 4),
+                              "transport": type(m2.pp_comm).__name__}
+        del m2, c2
+    if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if out is not None:

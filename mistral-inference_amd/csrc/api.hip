@@ -89,7 +89,7 @@ Workspace carve(const mi_model_t* m, int T, int B, int maxW, char* base) {
   w.tickets = (int32_t*)take(TICKET_BYTES);
   // engine granules at a FIXED offset (independent of T): nothing else ever writes them, so a stale word can never
   // look like a valid {value, tag} granule
-  w.gran_bytes = (m->num_experts == 0 && m->n_kv_heads > 0 && m->n_heads % m->n_kv_heads == 0)
+  w.gran_bytes = (m->n_kv_heads > 0 && m->n_heads % m->n_kv_heads == 0)
                      ? decode_engine_granule_bytes(m->dim, m->n_heads, m->n_kv_heads, m->hidden_dim, maxW) : 0;
   w.gran = take(w.gran_bytes);
   w.xn = (bf16_t*)take((size_t)T * m->dim * 2);
@@ -444,7 +444,7 @@ int mi_decode_engine_balance(const mi_model_t* m, void* workspace, size_t worksp
   if (moved) *moved = 0;
   Workspace ws = carve(m, 1, 1, max_cache_size > 0 ? max_cache_size : 1, (char*)workspace);
   if (ws.total > workspace_bytes) return fail(MI_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
-  if (!ws.gran_bytes) return MI_OK;  // MoE models: no engine, nothing to balance
+  if (!ws.gran_bytes || m->num_experts) return MI_OK;  // MoE: the W1|W3 split is per expert and the holders are off - nothing to balance
   EngProblem pr;
   memset(&pr, 0, sizeof(pr));
   pr.D = m->dim; pr.H = m->n_heads; pr.Hkv = m->n_kv_heads; pr.F = m->hidden_dim; pr.V = m->vocab_size; pr.NB = device_cus();
@@ -532,7 +532,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
 
   // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch, which also does
   // the step's bookkeeping (position, embedding row, greedy sample): nothing else is enqueued for the token
-  if (branch == MI_BRANCH_DECODE && T == 1 && B == 1 && m->num_experts == 0 && m->n_layers > 0 && engine_mode()) {
+  if (branch == MI_BRANCH_DECODE && T == 1 && B == 1 && m->n_layers > 0 && engine_mode()) {
     EngProblem pr;
     memset(&pr, 0, sizeof(pr));
     pr.D = D; pr.H = H; pr.Hkv = Hkv; pr.F = F; pr.V = m->vocab_size; pr.n_layers = m->n_layers; pr.NB = device_cus();
@@ -546,8 +546,11 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       pr.hist_tok = bt->hist_token; pr.hist_lp = bt->hist_logprob; pr.hist_len = bt->hist_len;
     }
     pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
+    pr.E = m->num_experts; pr.top_k = m->top_k;
     bool dense_ok = true;
-    for (int l = 0; l < m->n_layers; ++l) dense_ok = dense_ok && m->layers[l].w1 && m->layers[l].w2 && m->layers[l].w3;
+    for (int l = 0; l < m->n_layers; ++l)
+      dense_ok = dense_ok && (m->num_experts ? (m->layers[l].gate && m->layers[l].expert_w_dev)
+                                             : (m->layers[l].w1 && m->layers[l].w2 && m->layers[l].w3));
     if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
       bool declined = false;
       MI_TRY(hip_rc(launch_decode_engine(pr, s, &declined), "decode engine"));

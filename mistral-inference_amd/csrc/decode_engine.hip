@@ -89,7 +89,9 @@ enum : int {
   C_XREADY = 13,    // (layer + 1) once ffn_norm(h1) of that layer stands in the activation region (consumers -> holders)
   C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
-  C_BARW = 16       // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
+  C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
+  C_EXPERT = 20,    // MoE: ((layer + 1) << 16) | expert A | expert B << 8 (ascending ids) once the router has decided (consumers -> loader)
+  C_RLOGIT = 24     // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
 };
 // global control words (workspace): [0] step epoch, [1] sticky status, [2] abort broadcast, [3] bad token id, [4] engine
 // launches completed, [5] decode steps committed (index into the greedy history ring), [6] workgroup arrivals
@@ -197,7 +199,7 @@ __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P
 constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
 __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
   const int P = a.D >> 9;
-  return (NHOLD > 0 && a.holders && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
+  return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ loader wave
@@ -311,6 +313,7 @@ struct Loader {
   }
 };
 
+template <bool MOE>
 __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
   Loader ld{sh, lane, a.ring_fills, a.thin, a.depth};
   __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
@@ -340,14 +343,39 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
     if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
-    const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
-    for (int j = p.f0; j < f_ring; ++j) {
-      const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
-      const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
-      ld.template unit<4>(rp, a.D >> 9);
+    if constexpr (!MOE) {
+      const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
+      for (int j = p.f0; j < f_ring; ++j) {
+        const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
+        const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
+        ld.template unit<4>(rp, a.D >> 9);
+      }
+      trace_ev(sh, c, l, TR_CONS + 4, tr);
+      ld.pairs(L.w2, p.o0, p.o1, a.F);
+    } else {
+      // MoE (moe.py:24-32): WHICH expert matrices stream next is decided by the router, i.e. by this layer's activations:
+      // the one edge where the loader cannot run ahead.  Everything issued so far must be visible to the consumers (they
+      // need the Wo rows to get to the router at all), so the stream is flushed and restarts on a fill boundary - a
+      // published fill must never gain pieces afterwards (the consumers skip to the same boundary).
+      ld.flush();
+      ld.g = (ld.g + FILL - 1) & ~(uint32_t)(FILL - 1);
+      uint32_t word = 0, spins = 0;
+      while (((word = sh.ctl[C_EXPERT]) >> 16) != (uint32_t)(l + 1))
+        if (!spin_ok(sh, spins, 0x100)) break;
+      const void* const* tab = reinterpret_cast<const void* const*>(L.w2);  // device table [E][3] of (w1, w2, w3)
+      const int ex[2] = {__builtin_amdgcn_readfirstlane((int)(word & 0xffu)), __builtin_amdgcn_readfirstlane((int)((word >> 8) & 0xffu))};
+      for (int q = 0; q < 2; ++q) {  // ascending expert id: the order of moe.py's accumulation, and of the consumers
+        const bf16_t* e1 = reinterpret_cast<const bf16_t*>(tab[ex[q] * 3 + 0]);
+        const bf16_t* e3 = reinterpret_cast<const bf16_t*>(tab[ex[q] * 3 + 2]);
+        for (int j = p.f0; j < p.f1; ++j) {
+          const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
+          const bf16_t* const rp[4] = {e1 + r0, e3 + r0, e1 + r1, e3 + r1};
+          ld.template unit<4>(rp, a.D >> 9);
+        }
+      }
+      trace_ev(sh, c, l, TR_CONS + 4, tr);
+      for (int q = 0; q < 2; ++q) ld.pairs(reinterpret_cast<const bf16_t*>(tab[ex[q] * 3 + 1]), p.o0, p.o1, a.F);
     }
-    trace_ev(sh, c, l, TR_CONS + 4, tr);
-    ld.pairs(L.w2, p.o0, p.o1, a.F);
     trace_ev(sh, c, l, TR_CONS + 5, tr);
     if (sh.trace && tr) sh.trace[((size_t)c * ENG_MAXL + l) * TR_EVENTS + TR_CONS + 6] = ld.stalls;
   }
@@ -649,7 +677,161 @@ struct Cons {
   }
 };
 
-template <int R>
+// ---------------------------------------------------------------------------------------------------- MoE feed-forward
+// moe.py:24-32 for the one token of a decode step (top-2 routing), behind ffn_norm - whose output stands in the activation
+// region, with the raw h1 pieces of this lane still in `xr`:
+//   router   every workgroup computes the E gate logits itself (the gate matrix is 64 KB, read from L2 by everybody - no
+//            hand-off), with the arithmetic of the launch path's moe_router_kernel: its own sum of squares over the lane-
+//            strided pieces, fp32 fmaf chain per lane, wave sum, bf16 logit; top-k with ties to the lower id; softmax over
+//            the picks in fp32, rounded to bf16.  The two picks, in ASCENDING id, go to the loader (C_EXPERT).
+//   W1|W3    this workgroup's unit slab of expert A, then of expert B -> two hid vectors (granule arrays g_hid, g_hid2)
+//   W2       expert A rows with hid A (gathered long after its last producer finished: the sweep is one pass), then
+//            expert B rows with hid B; r = bf16(bf16(0 + bf16(wA yA)) + bf16(wB yB)); h = bf16(h1 + r)  (moe.py:28-32 +
+//            transformer_layers.py:168, the order of the launch path's moe_w2_kernel)
+__device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons& cs, const EngLayer& L, const LayerPlan& p, int l,
+                                        int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
+                                        const u32x4 (&xr)[4], bool trc) {
+  lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
+  lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
+  gu64* G = (gu64*)a.gran;
+  const int PD = a.D >> 9, PF = a.F >> 9, np = a.D >> 3;
+  // ---- raw h1 next to the normalised vector: the router normalises on its own (different reduction tree)
+  lbf16* raw = xs + a.D;
+  {
+    const int vt = w * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = vt + i * 256;
+      if (q < np) lds_st16(raw + q * 8, xr[i]);
+    }
+  }
+  cs.cbar();
+  // ---- router (moe_router_kernel: one wave per expert there, experts w, w + 4, ... per wave here)
+  {
+    const bf16_t* gate = L.w1;  // (MoE layers carry the gate in the w1 slot and the expert table in the w2 slot)
+    float ss = 0.f;
+    for (int pp = lane; pp < np; pp += 64) {
+      const u32x4 v = lds16(raw + pp * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = bf_lo(v[i]), x1 = bf_hi(v[i]);
+        ss = fmaf(x0, x0, ss);
+        ss = fmaf(x1, x1, ss);
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+    for (int e = w; e < a.E; e += NCONS) {
+      const bf16_t* gr = gate + (size_t)e * a.D;
+      float acc = 0.f;
+      for (int pp = lane; pp < np; pp += 64) {
+        const u32x4 v = lds16(raw + pp * 8);
+        const u32x4 gv = ld16(gr + pp * 8);
+        const u32x4 wv = ld16(L.fn + pp * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = bf_round(bf_round(bf_lo(v[i]) * inv) * bf_lo(wv[i]));
+          const float x1 = bf_round(bf_round(bf_hi(v[i]) * inv) * bf_hi(wv[i]));
+          acc = fmaf(bf_lo(gv[i]), x0, acc);
+          acc = fmaf(bf_hi(gv[i]), x1, acc);
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[e] = bf_round(acc);
+    }
+  }
+  cs.cbar();
+  int eA, eB;
+  float wA, wB;
+  {
+    const lvf32* lg = reinterpret_cast<const lvf32*>(sh.ctl + C_RLOGIT);
+    int ti[2];
+    float tw[2];
+    unsigned taken = 0;
+    for (int k = 0; k < 2; ++k) {
+      int best = -1;
+      float bv = -INFINITY;
+      for (int j = 0; j < a.E; ++j) {
+        const float v = lg[j];
+        if (!((taken >> j) & 1u) && (best < 0 || v > bv)) {  // ties: lowest expert id
+          best = j;
+          bv = v;
+        }
+      }
+      taken |= 1u << best;
+      ti[k] = best;
+      tw[k] = bv;
+    }
+    const float ex0 = expf(tw[0] - tw[0]), ex1 = expf(tw[1] - tw[0]);
+    float den = 0.f;
+    den += ex0;
+    den += ex1;
+    const float w0 = bf_round(ex0 / den), w1 = bf_round(ex1 / den);
+    const bool swap = ti[1] < ti[0];
+    eA = swap ? ti[1] : ti[0];
+    eB = swap ? ti[0] : ti[1];
+    wA = swap ? w1 : w0;
+    wB = swap ? w0 : w1;
+  }
+  if (w == 0 && lane == 0) sh.ctl[C_EXPERT] = ((uint32_t)(l + 1) << 16) | (uint32_t)eA | ((uint32_t)eB << 8);
+  trace_ev(sh, c, l, 13, trc);
+  // ---- W1|W3 of the two experts (the loader restarts on a fill boundary behind the router edge)
+  g = (g + FILL - 1) & ~(uint32_t)(FILL - 1);
+  {
+    const int n_u = p.f1 - p.f0;
+    for (int k = w; k < 2 * n_u; k += NCONS) {
+      const uint32_t ga = g + (uint32_t)(4 * k) * PD;
+      cs.set_done(ga);
+      float vv[4];
+      cs.template unit_dot<4>(ga, PD, xs, vv);
+      if (lane == 0) {
+        const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(vv[0], vv[1])) | ((uint32_t)f_to_bf(swiglu_bf(vv[2], vv[3])) << 16);
+        const int q = k >= n_u, j = k - q * n_u;
+        cs.publish(G + (q ? a.g_hid2 : a.g_hid) + p.f0 + j, tag_hid, packed);
+      }
+    }
+    g += (uint32_t)(4 * 2 * n_u) * PD;
+    cs.set_done(g);
+  }
+  trace_ev(sh, c, l, 14, trc);
+  // ---- W2 of expert A, then of expert B
+  lf32* keep = reinterpret_cast<lf32*>(sh.xs + (size_t)a.F * 2);  // r after expert A, two floats per unit of this workgroup
+  const int n_o = p.o1 - p.o0;
+  const bool to_global = (l == a.n_layers - 1);
+  for (int q = 0; q < 2; ++q) {
+    cs.cbar();  // the region's previous content (x, or hid A) is dead
+    sh.ctl[C_GATHERING] = 1;
+    cs.template gather<14>(G + (q ? a.g_hid2 : a.g_hid), a.F / 2, tag_hid, xs32);
+    cs.cbar();
+    sh.ctl[C_GATHERING] = 0;
+    if (q == 0) trace_ev(sh, c, l, 15, trc);
+    const float wq = q ? wB : wA;
+    for (int k = w; k < n_o; k += NCONS) {
+      const uint32_t ga = g + (uint32_t)(2 * k) * PF;
+      cs.set_done(ga);
+      float vv[2];
+      cs.template unit_dot<2>(ga, PF, xs, vv);
+      if (lane == 0) {
+        const float t0 = bf_round(wq * bf_round(vv[0])), t1 = bf_round(wq * bf_round(vv[1]));
+        if (q == 0) {
+          keep[2 * k] = bf_round(0.f + t0);
+          keep[2 * k + 1] = bf_round(0.f + t1);
+        } else {
+          const float r0 = bf_round(keep[2 * k] + t0), r1 = bf_round(keep[2 * k + 1] + t1);
+          const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
+          const uint32_t packed = pack_bf2(bf_lo(rs) + r0, bf_hi(rs) + r1);
+          *reinterpret_cast<lu32*>(sh.res + 2 * k) = packed;  // residual of the next layer's Wo epilogue
+          cs.publish(G + a.g_h + p.o0 + k, tag_h, packed);
+          if (to_global) *reinterpret_cast<uint32_t*>(a.h + 2 * (size_t)(p.o0 + k)) = packed;
+        }
+      }
+    }
+    g += (uint32_t)(2 * n_o) * PF;
+    cs.set_done(g);
+  }
+}
+
+template <int R, bool MOE>
 __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch,
                                              uint32_t arrive_target) {
   Cons cs{sh, w, lane};
@@ -923,71 +1105,75 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 12, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
-    uint64_t t_norm2 = 0;
-    if (a.f_stat && trc && (l & 7) == 3) t_norm2 = __builtin_amdgcn_s_memrealtime();
-    const int n_hold = holder_units(a, p.f1 - p.f0);
-    if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
-    {
-      const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
-      for (int k = w; k < n_u; k += NCONS) {
-        const uint32_t ga = g + (uint32_t)(4 * k) * PD;
-        cs.set_done(ga);
-        float vv[4];
-        cs.template unit_dot<4>(ga, PD, xs, vv);
-        const float a0 = vv[0], b0 = vv[1], a1 = vv[2], b1 = vv[3];
-        if (lane == 0) {
-          const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(a0, b0)) | ((uint32_t)f_to_bf(swiglu_bf(a1, b1)) << 16);
-          cs.publish(G + a.g_hid + p.f0 + k, tag_of(l, 5), packed);
+    if constexpr (!MOE) {
+      uint64_t t_norm2 = 0;
+      if (a.f_stat && trc && (l & 7) == 3) t_norm2 = __builtin_amdgcn_s_memrealtime();
+      const int n_hold = holder_units(a, p.f1 - p.f0);
+      if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
+      {
+        const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
+        for (int k = w; k < n_u; k += NCONS) {
+          const uint32_t ga = g + (uint32_t)(4 * k) * PD;
+          cs.set_done(ga);
+          float vv[4];
+          cs.template unit_dot<4>(ga, PD, xs, vv);
+          const float a0 = vv[0], b0 = vv[1], a1 = vv[2], b1 = vv[3];
+          if (lane == 0) {
+            const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(a0, b0)) | ((uint32_t)f_to_bf(swiglu_bf(a1, b1)) << 16);
+            cs.publish(G + a.g_hid + p.f0 + k, tag_of(l, 5), packed);
+          }
         }
+        g += (uint32_t)(4 * n_u) * PD;
+        cs.set_done(g);
       }
-      g += (uint32_t)(4 * n_u) * PD;
-      cs.set_done(g);
-    }
-    trace_ev(sh, c, l, 14, trc);
+      trace_ev(sh, c, l, 14, trc);
 
-    // ================================================================ h = h1 + hid @ W2^T
-    cs.cbar();
-    // load-balance statistics on every 8th layer (a clock read is an SMEM round trip: not on every layer): how long this
-    // workgroup's W1|W3 phase took and how long it then waits for the slowest workgroup's hid values
-    const bool sample = a.f_stat && trc && (l & 7) == 3;
-    uint64_t t_w13 = 0;
-    if (sample) t_w13 = __builtin_amdgcn_s_memrealtime();
-    if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
-      hold_target += (uint32_t)n_hold;
-      uint32_t spins = 0;
-      while (sh.ctl[C_HDONE] < hold_target)
-        if (!spin_ok(sh, spins, 0x500)) break;
-    }
-    sh.ctl[C_GATHERING] = 1;
-    cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
-    cs.cbar();
-    sh.ctl[C_GATHERING] = 0;
-    if (sample) {
-      const uint64_t t_hid = __builtin_amdgcn_s_memrealtime();
-      stat_wait += (uint32_t)(t_hid - t_w13);
-      stat_dur += (uint32_t)(t_w13 - t_norm2);
-      ++stat_n;
-    }
-    trace_ev(sh, c, l, 15, trc);
-    {
-      const int n_u = p.o1 - p.o0;
-      const bool to_global = (l == a.n_layers - 1);
-      for (int k = w; k < n_u; k += NCONS) {
-        const uint32_t ga = g + (uint32_t)(2 * k) * PF;
-        cs.set_done(ga);
-        float vv[2];
-        cs.template unit_dot<2>(ga, PF, xs, vv);
-        const float v0 = vv[0], v1 = vv[1];
-        if (lane == 0) {
-          const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
-          const uint32_t packed = pack_bf2(bf_lo(rs) + bf_round(v0), bf_hi(rs) + bf_round(v1));
-          *reinterpret_cast<lu32*>(sh.res + 2 * k) = packed;  // residual of the next layer's Wo epilogue
-          cs.publish(G + a.g_h + p.o0 + k, tag_of(l, 0), packed);
-          if (to_global) *reinterpret_cast<uint32_t*>(a.h + 2 * (size_t)(p.o0 + k)) = packed;
-        }
+      // ================================================================ h = h1 + hid @ W2^T
+      cs.cbar();
+      // load-balance statistics on every 8th layer (a clock read is an SMEM round trip: not on every layer): how long this
+      // workgroup's W1|W3 phase took and how long it then waits for the slowest workgroup's hid values
+      const bool sample = a.f_stat && trc && (l & 7) == 3;
+      uint64_t t_w13 = 0;
+      if (sample) t_w13 = __builtin_amdgcn_s_memrealtime();
+      if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
+        hold_target += (uint32_t)n_hold;
+        uint32_t spins = 0;
+        while (sh.ctl[C_HDONE] < hold_target)
+          if (!spin_ok(sh, spins, 0x500)) break;
       }
-      g += (uint32_t)(2 * n_u) * PF;
-      cs.set_done(g);
+      sh.ctl[C_GATHERING] = 1;
+      cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
+      cs.cbar();
+      sh.ctl[C_GATHERING] = 0;
+      if (sample) {
+        const uint64_t t_hid = __builtin_amdgcn_s_memrealtime();
+        stat_wait += (uint32_t)(t_hid - t_w13);
+        stat_dur += (uint32_t)(t_w13 - t_norm2);
+        ++stat_n;
+      }
+      trace_ev(sh, c, l, 15, trc);
+      {
+        const int n_u = p.o1 - p.o0;
+        const bool to_global = (l == a.n_layers - 1);
+        for (int k = w; k < n_u; k += NCONS) {
+          const uint32_t ga = g + (uint32_t)(2 * k) * PF;
+          cs.set_done(ga);
+          float vv[2];
+          cs.template unit_dot<2>(ga, PF, xs, vv);
+          const float v0 = vv[0], v1 = vv[1];
+          if (lane == 0) {
+            const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
+            const uint32_t packed = pack_bf2(bf_lo(rs) + bf_round(v0), bf_hi(rs) + bf_round(v1));
+            *reinterpret_cast<lu32*>(sh.res + 2 * k) = packed;  // residual of the next layer's Wo epilogue
+            cs.publish(G + a.g_h + p.o0 + k, tag_of(l, 0), packed);
+            if (to_global) *reinterpret_cast<uint32_t*>(a.h + 2 * (size_t)(p.o0 + k)) = packed;
+          }
+        }
+        g += (uint32_t)(2 * n_u) * PF;
+        cs.set_done(g);
+      }
+    } else {
+      moe_ffn(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
     }
     trace_ev(sh, c, l, 16, trc);
     cs.cbar();
@@ -1199,7 +1385,9 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
   }
 }
 
-template <int R>
+// MOE is a separate instantiation: the dense kernel must not pay registers for the router / two-expert code (it sits at
+// 247 of 256 VGPRs and spilled with the MoE path compiled in)
+template <int R, bool MOE>
 __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int c = blockIdx.x;
@@ -1226,7 +1414,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int pos = (int)a.kv_seqlens[0];
   const int seq = 0;
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
-  if (w == NCONS) run_loader(a, sh, c, lane, pos, seq);
+  if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
   else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
   else {
     // residency census: every workgroup counts itself in; consumers check the total before their first side effect
@@ -1239,7 +1427,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
       // test hook: wait for one workgroup more than exist - the gate fails exactly as it would with one missing
       if (__hip_atomic_load(sh.ctrl + G_SABOTAGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) arrive_target += 1u;
     }
-    run_consumer<R>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
+    run_consumer<R, MOE>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
   }
   // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
   if (c == 0 && threadIdx.x == 0 && !sh.ctl[C_ABORT])
@@ -1251,7 +1439,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 struct GranLayout {
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, g_amax, total;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, total;
   size_t tune_off;
 };
 constexpr size_t TUNE_TAB_BYTES = 2304, TUNE_STAT_BYTES = 1024 * 16;
@@ -1266,6 +1454,7 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   g.g_att = off;  off += H * DH / 2;
   g.g_h1 = off;   off += D / 2;
   g.g_hid = off;  off += F / 2;
+  g.g_hid2 = off; off += F / 2;  // MoE: hid of the second expert
   g.g_part = off; off += (uint32_t)((size_t)Hs * max_splits * R * (DH + 2));
   g.g_amax = off; off += 4 * AMAX_MAX_NB;  // (max logit, argmax, sum exp, pad) per workgroup
   g.total = off;
@@ -1292,6 +1481,11 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch
   if ((size_t)kmax * 2 > region) return no("activation vector does not fit beside the 8-fill ring");
+  if (pr.E) {
+    if (pr.E > 16 || pr.top_k != 2) return no("MoE: at most 16 experts, top-2 routing");
+    if ((size_t)pr.D * 4 > region) return no("MoE: normalised + raw activation vector");
+    if ((size_t)pr.F * 2 + (size_t)((pr.D / 2 + pr.NB - 1) / pr.NB) * 8 > region) return no("MoE: hid vector + per-unit partial sums");
+  }
   if ((size_t)pr.D * 2 + (size_t)((pr.V / 2 + pr.NB - 1) / pr.NB) * 8 + 16 + (size_t)pr.NB * 16 > region)
     return no("LM-head logits stash + greedy reduction staging");
   const int NB = pr.NB;
@@ -1418,12 +1612,12 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   a.gran = (uint64_t*)pr.granules; a.ctrl = pr.ctrl;
   const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
   a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
-  a.g_amax = gl.g_amax;
+  a.g_amax = gl.g_amax; a.g_hid2 = gl.g_hid2; a.E = pr.E;
   if (gl.tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
   a.f_tab = reinterpret_cast<const uint16_t*>((const char*)pr.granules + gl.tune_off);
   if (g_balance_stats < 0) {
     const char* e = getenv("MI_ENGINE_BALANCE");
-    g_balance_stats = e ? (atoi(e) != 0) : 1;
+    g_balance_stats = e ? (atoi(e) != 0) : 0;  // off: balancing measured slower (GreedySession.BALANCE)
   }
   a.f_stat = g_balance_stats ? reinterpret_cast<uint32_t*>((char*)pr.granules + gl.tune_off + TUNE_TAB_BYTES) : nullptr;
 
@@ -1448,26 +1642,32 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
       EngLayer& L = a.L[l];
       L.an = (const bf16_t*)M.attention_norm; L.wq = (const bf16_t*)M.wq; L.wk = (const bf16_t*)M.wk;
       L.wv = (const bf16_t*)M.wv; L.wo = (const bf16_t*)M.wo; L.fn = (const bf16_t*)M.ffn_norm;
-      L.w1 = (const bf16_t*)M.w1; L.w2 = (const bf16_t*)M.w2; L.w3 = (const bf16_t*)M.w3;
+      if (pr.E) {  // MoE layers: the gate in the w1 slot, the DEVICE table [E][3] of expert matrices in the w2 slot
+        L.w1 = (const bf16_t*)M.gate; L.w2 = (const bf16_t*)M.expert_w_dev; L.w3 = nullptr;
+      } else {
+        L.w1 = (const bf16_t*)M.w1; L.w2 = (const bf16_t*)M.w2; L.w3 = (const bf16_t*)M.w3;
+      }
       L.ck = (bf16_t*)pr.cache_k[l0 + l]; L.cv = (bf16_t*)pr.cache_v[l0 + l];
       L.W = pr.W[l0 + l];
       L.n_splits = attn_decode_splits(L.W);
       L.chunk = attn_core::split_chunk(L.W, L.n_splits);
     }
     const void* fn = nullptr;
+    const bool moe = pr.E > 0;
     switch (a.R) {
-      case 1: fn = (const void*)decode_engine_kernel<1>; break;
-      case 2: fn = (const void*)decode_engine_kernel<2>; break;
-      case 4: fn = (const void*)decode_engine_kernel<4>; break;
-      case 8: fn = (const void*)decode_engine_kernel<8>; break;
+      case 1: fn = moe ? (const void*)decode_engine_kernel<1, true> : (const void*)decode_engine_kernel<1, false>; break;
+      case 2: fn = moe ? (const void*)decode_engine_kernel<2, true> : (const void*)decode_engine_kernel<2, false>; break;
+      case 4: fn = moe ? (const void*)decode_engine_kernel<4, true> : (const void*)decode_engine_kernel<4, false>; break;
+      case 8: fn = moe ? (const void*)decode_engine_kernel<8, true> : (const void*)decode_engine_kernel<8, false>; break;
       default: return hipErrorInvalidValue;
     }
     // 160 KiB of dynamic LDS is an opt-in per function AND per device
-    static bool attr_set[64][9] = {};
-    if (dev < 0 || dev >= 64 || !attr_set[dev][a.R]) {
+    static bool attr_set[64][18] = {};
+    const int slot = a.R + (moe ? 9 : 0);
+    if (dev < 0 || dev >= 64 || !attr_set[dev][slot]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;
-      if (dev >= 0 && dev < 64) attr_set[dev][a.R] = true;
+      if (dev >= 0 && dev < 64) attr_set[dev][slot] = true;
     }
     void* params[] = {(void*)&a};
     hipError_t e = hipLaunchKernel(fn, dim3(pr.NB), dim3(NTHREADS), params, LDS_TOTAL, s);
@@ -1518,21 +1718,23 @@ hipError_t decode_engine_balance(const EngProblem& pr, int mode, int* moved, hip
       changed += 2 * d;
     }
   } else {
-    double wait[1024], mean_wait = 0, mean_dur = 0;
+    // Signal: the DURATION of the workgroup's W1|W3 phase (ffn_norm done -> last consumer wave done).  The phase begins
+    // within +-0.3 us everywhere (it follows an all-to-all), so a longer phase is a later end.  The wait at the hid
+    // hand-off was tried first and is the wrong signal - it contains the workgroup's own sweep time, which differs by XCD:
+    // balancing on it made the step 50 us SLOWER.
+    double dur[1024], mean_dur = 0;
     int with = 0;
     for (int c = 0; c < NB; ++c)
       if (stat[4 * c + 2]) {
-        wait[c] = stat[4 * c] / (100.0 * stat[4 * c + 2]);  // us (100 MHz clock)
-        mean_wait += wait[c];
-        mean_dur += stat[4 * c + 1] / (100.0 * stat[4 * c + 2]);
+        dur[c] = stat[4 * c + 1] / (100.0 * stat[4 * c + 2]);  // us (100 MHz clock)
+        mean_dur += dur[c];
         ++with;
       }
     if (with == NB && stat[2] >= 8) {  // every workgroup has samples, and enough of them (>= 2 steps of 32 layers)
-      mean_wait /= NB;
       mean_dur /= NB;
       const double ut = mean_dur / ((double)U / NB);  // time of one unit
       double late[1024];
-      for (int c = 0; c < NB; ++c) late[c] = mean_wait - wait[c];  // waited less than the others = finished later
+      for (int c = 0; c < NB; ++c) late[c] = dur[c] - mean_dur;
       const int floor_units = U / NB - 4 > 12 ? U / NB - 4 : (U / NB > 2 ? U / NB - 2 : 1);
       for (int it = 0; it < NB; ++it) {
         int hi = 0, lo = 0;

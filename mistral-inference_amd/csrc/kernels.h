@@ -217,7 +217,8 @@ struct EngArgs {
   float* logits;
   uint64_t* gran;         // granule regions
   uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_part, g_amax;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax;
+  int E;                  // experts (0: dense).  MoE layers: EngLayer.w1 = gate [E, D], .w2 = device table [E][3] of (w1, w2, w3)
   const uint16_t* f_tab;  // [NB + 1] first W1|W3 unit of every workgroup (valid iff f_tab[NB] == F / 2), see decode_engine_balance
   uint32_t* f_stat;       // [NB][4] per workgroup: ticks waited at the hid hand-off, ticks of the W1|W3 phase, samples, -
   unsigned long long* trace;  // optional timeline buffer (debug)
@@ -226,6 +227,7 @@ struct EngArgs {
 
 struct EngProblem {
   int D, H, Hkv, F, V, n_layers, NB;
+  int E, top_k;              // MoE (0, 0: dense)
   float eps;
   const mi_layer_t* layers;  // host
   void* const* cache_k;      // host [n_layers]

@@ -610,8 +610,12 @@ class GreedySession:
     only what is done with its result moved onto the device."""
 
     HIST = 1024
-    GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "8"))   # decode steps per hipGraph launch (1: one graph per token)
-    BALANCE = os.environ.get("MI_ENGINE_BALANCE", "1") != "0"    # adapt the engine's W1|W3 split at collect() time
+    # decode steps per hipGraph launch.  Measured (profiles/EXPERIMENTS.md): 8 steps per graph close the ~9 us gap between two
+    # graph launches, and the kernels then run ~10 us longer each (their ramp-up is no longer hidden in the gap): no gain -> 1
+    GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "1"))
+    # adapt the engine's W1|W3 split at collect() time (mi_decode_engine_balance).  Measured 35-50 us per step SLOWER on two
+    # boxes, with either signal: off.  (The mechanism stays: any split is bit-identical, tests/test_gpu_engine.py.)
+    BALANCE = os.environ.get("MI_ENGINE_BALANCE", "0") != "0"
 
     def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
         assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"

@@ -92,6 +92,12 @@ SHAPES = {
     # an 8.3K-slot ring: 31 splits of 272 slots = 136 K/V pieces per CU, more than the LDS ring holds at once
     "ring_longer_than_lds": dict(dim=512, n_layers=1, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
                                  vocab_size=640, sliding_window=None),
+    # MoE on the engine (top-2 routing; router in every workgroup, the loader waits for its decision, two experts' W1|W3
+    # and W2 slabs per layer): 8 experts as Mixtral, and 4 experts with MHA
+    "moe_8_experts_top2": dict(dim=512, n_layers=3, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
+                               vocab_size=1000, sliding_window=48, num_experts=8, num_experts_per_tok=2),
+    "moe_4_experts_mha": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=8, n_kv_heads=8, norm_eps=1e-5,
+                              vocab_size=514, sliding_window=None, num_experts=4, num_experts_per_tok=2),
     # HOLDER WAVES at a size the whole suite can afford: they need dim % 2048 == 0 and >= 11 W1|W3 units per CU
     # (decode_engine.hip holder_units): hidden_dim 5632 = 11 units x 256 CUs exactly
     "holders_mid_size": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=5632, n_heads=16, n_kv_heads=4, norm_eps=1e-5,

@@ -72,7 +72,7 @@ def test_bench_two_ranks_prints_one_json_line():
     env = dict(os.environ, MI_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29377", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--layers", "4", "--prefill", "256"]
+           "--layers", "4", "--prefill", "256", "--mixtral-layers", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -80,3 +80,6 @@ def test_bench_two_ranks_prints_one_json_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
+    # north_star's multi-GPU model: a Mixtral sub-measurement over the same stages (8x7B dims for N < 8, layer-truncated here)
+    mx = d["mixtral"]
+    assert "Mixtral-8x7B" in mx["model"] and mx["tokens_per_s"] > 0 and 0 < mx["hbm_roofline_frac"] < 1 and mx["prefill_tokens_per_s"] > 0
