@@ -131,7 +131,8 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
     us = e0.elapsed_time(e1) * 1e3 / iters
     bytes_per_launch = decode_bytes_per_token(params, ctx0 + iters // 2)
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
-    dims_ok = (model.args.dim, model.args.hidden_dim, model.args.n_layers) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"], MISTRAL_7B["n_layers"])
+    dims_ok = ((model.args.dim, model.args.hidden_dim, model.args.n_layers) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"], MISTRAL_7B["n_layers"])
+               and not params.get("moe"))
     traffic, traffic_src = _pmc_traffic("decode_engine_kernel", dims_ok)
     group = model.args.n_heads // model.args.n_kv_heads
     return {"bound": "hbm", "kernel": f"decode_engine_kernel<{group}> (persistent: all layers + LM head + sample of one decode step in one launch)",

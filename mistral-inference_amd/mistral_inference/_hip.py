@@ -129,7 +129,9 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         L = lib()
-        detail = L.mi_rccl_last_error().decode() if rc == -5 else L.mi_last_error_detail().decode()
+        detail = L.mi_last_error_detail().decode()
+        if rc == -5 or "rccl" in what:  # mi_rccl_* keep their own text (a failed dlopen of librccl returns MI_ERR_UNSUPPORTED)
+            detail = (L.mi_rccl_last_error().decode() or detail)
         raise RuntimeError(f"libmistral_hip {what}: {L.mi_error_string(rc).decode()} [{detail}] (code {rc})")
 
 

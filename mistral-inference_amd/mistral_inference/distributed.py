@@ -90,10 +90,14 @@ class TorchDistComm:
 
 def pipeline_comm(device: torch.device):
     """Transport for a pipeline rank on `device`: RCCL through the C ABI on a GPU under the "nccl" process group (the
-    production path), torch.distributed otherwise.  Whether librccl can be loaded is probed locally on every rank
+    opt-in path, MI_PP_TRANSPORT=rccl), torch.distributed otherwise (default).  Whether librccl can be loaded is probed locally on every rank
     (`mi_rccl_unique_id` needs no peer) and AGREED through the process group before anyone enters the collective
     communicator init: a rank that cannot load it would otherwise leave the others waiting in `ncclCommInitRank`."""
-    want = os.environ.get("MI_PP_TRANSPORT", "rccl")
+    # Default: torch.distributed ("nccl" there IS RCCL over xGMI).  The C-ABI communicator below is a second RCCL
+    # communicator that has only ever run at world size 1 (tests/test_gpu_rccl.py - a 1-GPU lease cannot host two ranks);
+    # until a multi-GPU run has covered send/recv/bcast and graph replay it is opt-in: MI_PP_TRANSPORT=rccl.  Since a
+    # stage's decode step is ONE launch on the persistent engine, the eager torch hop costs a few microseconds per token.
+    want = os.environ.get("MI_PP_TRANSPORT", "torch")
     dist = torch.distributed
     if want == "rccl" and device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl":
         err = None

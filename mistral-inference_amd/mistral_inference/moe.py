@@ -38,6 +38,31 @@ class MoeLayer(nn.Module):
         T <= 8 the selected experts' fused gate/up GEMV + the down-projection/combine kernel (`mi_moe_experts_decode`),
         for larger T the on-device expert sort + ONE token-grouped MFMA GEMM launch per projection + ordered combine
         (`mi_moe_grouped_gemm`).  No host synchronisation (the reference does one `torch.where` sync per expert)."""
-        k = self.args.num_experts_per_tok
+        k, E = self.args.num_experts_per_tok, len(self.experts)
+        F, T = self.experts[0].w1.weight.shape[0], inputs.shape[0]
+        # shapes the fused kernels are built for (csrc/api.hip check_model / mi_moe_grouped_gemm); the reference accepts any
+        # num_experts / top_k, so everything else takes the general route below instead of raising
+        fused = E <= 16 and k in (1, 2, 4) and k <= E and (T > _hip.GEMV_MAX_T or k * F * 2 <= 65536)
+        if not fused:
+            return self._forward_general(inputs)
         idx, w = _hip.moe_router(inputs, self.gate.weight, k)          # [T, k] int32 / fp32 (bf16-valued)
-        return _hip.moe_experts(inputs, self._expert_table(), len(self.experts), self.experts[0].w1.weight.shape[0], idx, w)
+        return _hip.moe_experts(inputs, self._expert_table(), E, F, idx, w)
+
+    def _forward_general(self, inputs: torch.Tensor) -> torch.Tensor:
+        """Any expert count / top-k (reference moe.py:24-32 literally): the routing bookkeeping in torch on the device, the
+        dense work - gate logits and every expert's SwiGLU FFN on its tokens - on the HIP GEMM / GEMV kernels (`mi_linear`).
+        One `torch.where` host sync per expert, as in the reference."""
+        k = self.args.num_experts_per_tok
+        gate_logits = _hip.linear(inputs, (self.gate.weight,), _hip.EPI_STORE)
+        weights, selected = torch.topk(gate_logits, k)
+        weights = torch.softmax(weights, dim=1, dtype=torch.float).to(inputs.dtype)
+        results = torch.zeros_like(inputs)
+        for e, expert in enumerate(self.experts):
+            tok, slot = torch.where(selected == e)
+            if tok.numel() == 0:
+                continue
+            x = inputs.index_select(0, tok).contiguous()
+            hid = _hip.linear(x, (expert.w1.weight, expert.w3.weight), _hip.EPI_SWIGLU)
+            y = _hip.linear(hid, (expert.w2.weight,), _hip.EPI_STORE)
+            results[tok] += weights[tok, slot, None] * y
+        return results

@@ -415,15 +415,24 @@ class Transformer(ModelBase):
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             seen = list(cache._seen)
+            captured, why = True, None
             try:
                 with torch.cuda.graph(graph):
                     # under pipeline parallelism the stage-to-stage ncclRecv / ncclSend and the logits broadcast are graph
                     # nodes too (RCCL enqueues on the capturing stream): a replay needs no Python per token on any rank
                     st["out"] = self._logits(st["ids"], seqlens, cache)
             except RuntimeError as e:
+                captured, why = False, e
+            if self.num_pipeline_ranks > 1 and torch.distributed.is_initialized():
+                # every stage replays or every stage runs eagerly: a rank that could not capture while its neighbours
+                # replay would post its sends / receives in a different order (agreed over the bootstrap process group)
+                flag = torch.tensor([1 if captured else 0], device=self.device, dtype=torch.int32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                captured = bool(int(flag.item()))
+            if not captured:
                 # a runtime that refuses to capture (an RCCL build without graph support, a debug allocator ...): this
                 # context degrades to launch-by-launch steps instead of failing the generation
-                logging.warning("decode step not graph-capturable (%s): continuing eagerly", e)
+                logging.warning("decode step not graph-capturable on every stage (%s): continuing eagerly", why)
                 cache._seen = seen
                 self._graphed = None
                 return self._logits(input_ids, seqlens, cache)

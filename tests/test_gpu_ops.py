@@ -460,3 +460,35 @@ def test_moe_layer_module_uses_the_native_kernels():
         out = layer(x.cuda()).cpu()
     ref = mo.moe_ffn(x, gate, experts, k)
     assert float((out.float() - ref.float()).abs().max()) <= 3e-2 * max(1.0, float(ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("E,k,T", [(6, 3, 5), (20, 2, 33), (4, 4, 3)])
+def test_moe_layer_general_route_any_expert_count_and_topk(E, k, T):
+    """The reference accepts any num_experts / num_experts_per_tok (moe.py:24-32); the fused kernels take E <= 16 and
+    k in {1, 2, 4}.  Everything else runs the reference's loop with the dense work on mi_linear (MoeLayer._forward_general)
+    instead of raising.  (4, 4, 3) is a fused shape: both routes must agree on it.)"""
+    from torch import nn
+    from mistral_inference.args import MoeArgs
+    from mistral_inference.moe import MoeLayer
+    from mistral_inference.transformer_layers import FeedForward
+    D, Fh = 512, 1024
+    x, gate, experts = _moe_case(T, D, Fh, E, k, seed=90 + E)
+    layer = MoeLayer([FeedForward(D, Fh) for _ in range(E)], nn.Linear(D, E, bias=False), MoeArgs(num_experts=E, num_experts_per_tok=k))
+    layer = layer.to(BF).cuda()
+    with torch.no_grad():
+        layer.gate.weight.copy_(gate)
+        for ex, (w1, w2, w3) in zip(layer.experts, experts):
+            ex.w1.weight.copy_(w1)
+            ex.w2.weight.copy_(w2)
+            ex.w3.weight.copy_(w3)
+        out = layer(x.cuda()).cpu()
+        gen = layer._forward_general(x.cuda()).cpu()
+    mo.ROUTER_TRACE = []
+    ref = mo.moe_ffn(x, gate, experts, k)
+    lg, mo.ROUTER_TRACE = mo.ROUTER_TRACE[0], None
+    srt = torch.sort(lg, dim=1, descending=True).values
+    clear = torch.ones(T, dtype=torch.bool) if k >= E else (srt[:, k - 1] - srt[:, k]) > 2 * srt[:, k - 1].abs().clamp(min=1e-3) * 2.0 ** -7
+    tol = 3e-2 * max(1.0, float(ref.float().abs().max()))
+    assert clear.any()
+    assert float((out.float() - ref.float())[clear].abs().max()) <= tol
+    assert float((gen.float() - ref.float())[clear].abs().max()) <= tol
