@@ -259,7 +259,7 @@ def port_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
 def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: int, Wm: int, sync):
     """Build the model (this rank's pipeline stage), run one untimed and one timed T0-token prefill, W warm-up decode steps,
     then time exactly K decode steps between two synchronisations (+ barriers).  Returns the model, its cache, the last
-    token, the decode seconds, the prefill seconds (both the maximum over ranks) and the engine's rebalanced unit count."""
+    token, the decode seconds and the prefill seconds (both the maximum over ranks)."""
     from mistral_inference.cache import BufferCache
     model = build_model(params, rank, world, dev)
     a = model.args
@@ -282,14 +282,19 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
         del logits
         # ---- decode: the generate() loop body - forward(next_token, [1], cache) under the decode hipGraph context
         # (capture happens inside the warm-up steps; W >= 2 keeps it out of the timed region)
-        units_moved = None
         if world == 1 and opt.loop == "greedy":
             # generate()'s temperature-0 loop body (mistral_inference/generate.py -> Transformer.greedy_session): one
             # native call per token - argmax + log-softmax are the LM head's epilogue, the sample feeds the next step on
             # the device - replayed from a hipGraph.  Nothing of the step is skipped: logits [1, V] are written every step.
             sess = model.greedy_session(cache, nxt, graph=not opt.no_graph)
-            sess.run(max(Wm, 2))
-            sess.collect()
+            W = max(Wm, 2)
+            # W untimed steps; the health check of the first ones (collect = a device->host copy and some Python) sits
+            # BEFORE the last two, so that the GPU is still busy when the bracket's synchronisation begins: a GPU that
+            # idled for a millisecond runs its first kernel ~0.4 ms slow (clock ramp), which would be charged to the K steps
+            sess.run(W - 2)
+            if W > 2:
+                sess.collect()
+            sess.run(2)
             sync()
             dt, left = 0.0, K
             while left > 0:                      # (the session's history ring holds 1024 steps between collects)
@@ -301,7 +306,6 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
                 toks, _ = sess.collect()         # verifies that the device completed every step (and which path ran)
                 left -= n
             nxt = toks[-1]
-            units_moved = sess.units_moved
         else:
             # the sampling loop's body (temperature > 0, or pipeline stages): forward() under the decode hipGraph + torch.argmax
             ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
@@ -318,7 +322,7 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
         tmax = torch.tensor([dt, prefill_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt, prefill_s = tmax.tolist()
-    return model, cache, nxt, dt, prefill_s, units_moved
+    return model, cache, nxt, dt, prefill_s
 
 
 def main() -> None:
@@ -361,7 +365,7 @@ def main() -> None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    model, cache, nxt, dt, prefill_s, units_moved = timed_run(opt, params, rank, world, dev, T0, K, Wm, sync)
+    model, cache, nxt, dt, prefill_s = timed_run(opt, params, rank, world, dev, T0, K, Wm, sync)
 
     from mistral_inference import _hip
     engine = _hip.decode_engine_status(model._backend._workspace)
@@ -388,7 +392,6 @@ def main() -> None:
                                    f"{T0}-token prefill then batch-1 greedy decode, sliding_window={params.get('sliding_window')}",
                        "batch": 1, "prefill_tokens": T0, "context_at_timing": ctx_len,
                        "decode_launch": decode_launch_label(),
-                       "engine_w13_units_rebalanced": units_moved,
                        "parallelism": "single GPU" if world == 1 else
                        f"pp{world} (layer ranges; {type(model.pp_comm).__name__} send/recv + logits broadcast, process group "
                        f"{torch.distributed.get_backend()})"},
@@ -427,7 +430,7 @@ def main() -> None:
         mx_params = dict(PRESETS[mx_name][0])
         if opt.mixtral_layers:
             mx_params["n_layers"] = opt.mixtral_layers
-        m2, c2, _, dt2, pre2, _ = timed_run(opt, mx_params, rank, world, dev, T0, K, Wm, sync)
+        m2, c2, _, dt2, pre2 = timed_run(opt, mx_params, rank, world, dev, T0, K, Wm, sync)
         if rank == 0:
             ctx_len = T0 + Wm + K // 2
             b2 = decode_bytes_per_token(mx_params, ctx_len)

@@ -239,6 +239,12 @@ typedef struct mi_batch {
   int64_t* hist_token;          /* dev [hist_len, B] or NULL */
   float* hist_logprob;          /* dev [hist_len, B] or NULL */
   int32_t hist_len;
+  /* Consecutive decode steps in ONE call (0 / 1: one).  Needs the fused sample with input_ids == greedy_token: step i + 1
+   * consumes step i's sample.  On the persistent engine (<= 32 local layers) all of them run in ONE launch: the sample
+   * reaches the next step through a granule inside the kernel, the weight stream never stops between two tokens and there
+   * is no launch ramp or empty ring per token; every step still commits its position, its K/V rows, its history row and
+   * overwrites `logits` (the caller sees the last step's).  Elsewhere the library enqueues the steps one after another. */
+  int32_t greedy_steps;
 } mi_batch_t;
 
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);
@@ -265,14 +271,6 @@ int mi_set_decode_engine(int enabled);
  * steps that did complete is status word 5.  Timeouts AFTER the census (codes 0x100-0x600) should not exist; they poison
  * the workspace the same way but may leave a half-written step. */
 int mi_decode_engine_census(int forget);
-/* W1|W3 load balance of the engine.  That phase (54 % of a layer's bytes) ends in an all-to-all, so every workgroup waits
- * for the slowest one; part of who is slow is systematic (XCD position, single CUs).  The kernel samples, per workgroup,
- * how long it waited at that hand-off; this call (mode 0) reads the samples and moves W1|W3 units - whose outputs are not
- * tied to a workgroup - from late workgroups to early ones in the table the next launches read.  Host-side, SYNCHRONISES
- * the stream: call it where the caller synchronises anyway (GreedySession.collect does).  mode 1 restores the uniform
- * split, mode 2 installs a skewed split (tests).  *moved = units that changed owner.  Results never depend on the split. */
-int mi_decode_engine_balance(const mi_model_t* model, void* workspace, size_t workspace_bytes, int max_cache_size, int mode,
-                             int* moved, mi_stream_t stream);
 int mi_decode_engine_reset(void* workspace, mi_stream_t stream);
 /* Copies the engine's control words out of a workspace and synchronises `stream` (a health check, NOT part of the hot
  * path): status[0] = step epoch, status[1] = 0 or the code of the first bounded wait that ever timed out

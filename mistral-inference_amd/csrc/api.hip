@@ -437,21 +437,6 @@ int mi_decode_engine_reset(void* workspace, mi_stream_t stream) {
   return MI_OK;
 }
 
-int mi_decode_engine_balance(const mi_model_t* m, void* workspace, size_t workspace_bytes, int max_cache_size, int mode,
-                             int* moved, mi_stream_t stream) {
-  MI_TRY(check_model(m));
-  if (!workspace || mode < 0 || mode > 2) return fail(MI_ERR_ARG, "mi_decode_engine_balance");
-  if (moved) *moved = 0;
-  Workspace ws = carve(m, 1, 1, max_cache_size > 0 ? max_cache_size : 1, (char*)workspace);
-  if (ws.total > workspace_bytes) return fail(MI_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, ws.total);
-  if (!ws.gran_bytes || m->num_experts) return MI_OK;  // MoE: the W1|W3 split is per expert and the holders are off - nothing to balance
-  EngProblem pr;
-  memset(&pr, 0, sizeof(pr));
-  pr.D = m->dim; pr.H = m->n_heads; pr.Hkv = m->n_kv_heads; pr.F = m->hidden_dim; pr.V = m->vocab_size; pr.NB = device_cus();
-  pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes;
-  return hip_rc(decode_engine_balance(pr, mode, moved, (hipStream_t)stream), "engine balance");
-}
-
 int mi_greedy_sample(const float* logits, int ld, int B, int vocab, int64_t* token, float* logprob, mi_stream_t stream) {
   if (!logits || !token || !logprob || B <= 0 || vocab <= 0 || ld < vocab) return fail(MI_ERR_ARG, "mi_greedy_sample");
   return hip_rc(launch_greedy_rows(logits, ld, B, vocab, token, logprob, nullptr, nullptr, 0, nullptr, (hipStream_t)stream),
@@ -529,6 +514,10 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     return fail(MI_ERR_ARG, "mi_forward: greedy_token needs the DECODE branch, logits and greedy_logprob");
   if (want_greedy && bt->hist_len > 0 && (!bt->hist_token || !bt->hist_logprob))
     return fail(MI_ERR_ARG, "mi_forward: hist_len > 0 without history buffers");
+  const int steps = bt->greedy_steps > 1 ? bt->greedy_steps : 1;
+  if (steps > 1 && !(want_greedy && embed && (const void*)bt->input_ids == (const void*)bt->greedy_token))
+    return fail(MI_ERR_ARG, "mi_forward: greedy_steps > 1 needs the fused sample with input_ids aliasing greedy_token");
+  if (steps > 4096) return fail(MI_ERR_ARG, "mi_forward: greedy_steps > 4096");
 
   // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch, which also does
   // the step's bookkeeping (position, embedding row, greedy sample): nothing else is enqueued for the token
@@ -547,6 +536,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     }
     pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
     pr.E = m->num_experts; pr.top_k = m->top_k;
+    pr.n_steps = (steps > 1 && m->n_layers <= ENG_MAXL) ? steps : 1;  // all of them in ONE launch (the sample feeds the next step in-kernel)
     bool dense_ok = true;
     for (int l = 0; l < m->n_layers; ++l)
       dense_ok = dense_ok && (m->num_experts ? (m->layers[l].gate && m->layers[l].expert_w_dev)
@@ -554,14 +544,26 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
       bool declined = false;
       MI_TRY(hip_rc(launch_decode_engine(pr, s, &declined), "decode engine"));
-      if (!declined) {
+      if (!declined && pr.n_steps == steps) {
         if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        return MI_OK;
+      }
+      if (!declined && steps > 1) {  // (more layers than one launch takes) the first step is enqueued: the others follow singly
+        mi_batch_t one = *bt;
+        one.greedy_steps = 1;
+        for (int i = 1; i < steps; ++i) MI_TRY(mi_forward(m, &one, stream));
         return MI_OK;
       }
       snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail());  // informational
     }
   }
 
+  if (steps > 1) {  // launch path (MoE beyond top-2, batch > 1, shapes the engine does not take): step by step, same stream
+    mi_batch_t one = *bt;
+    one.greedy_steps = 1;
+    for (int i = 0; i < steps; ++i) MI_TRY(mi_forward(m, &one, stream));
+    return MI_OK;
+  }
   if (branch == MI_BRANCH_DECODE && embed) {
     MI_TRY(hip_rc(launch_decode_prep_embedding(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, h,
                                                m->tok_embeddings, bt->input_ids, D, m->vocab_size, engine_ctrl, s),

@@ -91,7 +91,9 @@ enum : int {
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
   C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
   C_EXPERT = 20,    // MoE: ((layer + 1) << 16) | expert A | expert B << 8 (ascending ids) once the router has decided (consumers -> loader)
-  C_RLOGIT = 24     // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
+  C_RLOGIT = 24,    // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
+  C_TOKEN = 40,     // multi-step launches: the token sampled by the previous step (consumer wave 0 -> the other waves)
+  C_TOKSTEP = 41    // ... and the step it is the input of
 };
 // global control words (workspace): [0] step epoch, [1] sticky status, [2] abort broadcast, [3] bad token id, [4] engine
 // launches completed, [5] decode steps committed (index into the greedy history ring), [6] workgroup arrivals
@@ -171,14 +173,6 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
   p.v1 = p.k1;
   slab(a.D / 2, c, a.NB, p.o0, p.o1);
   slab(a.F / 2, c, a.NB, p.f0, p.f1);
-  if (a.f_tab && a.f_tab[a.NB] == (uint16_t)(a.F / 2) && a.f_tab[0] == 0) {  // balanced split (decode_engine_balance)
-    const int t0 = a.f_tab[c], t1 = a.f_tab[c + 1];
-    if (t0 <= t1 && t1 <= a.F / 2) {
-      p.f0 = t0;
-      p.f1 = t1;
-    }
-  }
-  slab(a.H * DH / 2, c, a.NB, p.e0, p.e1);
   const int kv_len = min(pos + 1, L.W);
   p.cur_slot = pos % L.W;
   p.att = c < a.Hs * L.n_splits;
@@ -270,6 +264,20 @@ struct Loader {
     ++g;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
+  // K/V ring slices.  Inside a MULTI-STEP launch the row written at step t (by another workgroup, possibly on another XCD)
+  // is read at step t + 1 without a kernel boundary in between: the writer stores it write-through (sc1) and the read
+  // must not be served from a stale line of this XCD's L2 either - sc1 on the DMA, the granule protocol's pairing
+  // (MI355X_MICROARCH.md "Valid forms": sc1 stores AND sc1 loads).  Single-step launches keep the non-temporal policy.
+  __device__ __forceinline__ void kv_piece(const void* src_lane, bool coherent) {
+    if ((g & (FILL - 1)) == 0) fill_begin();
+    lchar* dst = slot_of(g);
+    if (coherent)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, 0, 16 /* sc1 */);
+    else
+      dma<0>(src_lane, dst);
+    ++g;
+    if ((g & (FILL - 1)) == 0) fill_end();
+  }
   // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: g % 4 == 0): one address, immediate offsets
   __device__ __forceinline__ void piece4(const void* src_lane) {
     if ((g & (FILL - 1)) == 0) fill_begin();
@@ -313,17 +321,26 @@ struct Loader {
   }
 };
 
-template <bool MOE>
-__device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
+// stage id of (step t, layer l) for the monotonic LDS progress words (C_LSTAGE, C_XREADY, C_EXPERT): unique within a launch
+__device__ __forceinline__ uint32_t stage_id(int t, int l) { return (uint32_t)(t * 64 + l + 1); }
+
+template <bool MOE, bool MULTI>
+__device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos0, int seq) {
+  const int n_steps = MULTI ? a.n_steps : 1;  // (a compile-time 1 in the single-step instantiation: no loop state to carry)
   Loader ld{sh, lane, a.ring_fills, a.thin, a.depth};
   __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
   const int PD = a.D >> 9;
+  // MULTI-STEP launches (a.n_steps > 1, GreedySession): the loader's program does not depend on the sampled tokens at all -
+  // weights and the K/V slots of position pos0 + t - so it simply continues with step t + 1's first layer while the
+  // consumers are still busy with step t's LM head and sample: no launch ramp, no cold ring between two tokens.
+  for (int t = 0; t < n_steps; ++t) {
+  const int pos = pos0 + t;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     if (sh.ctl[C_ABORT]) break;  // the consumers have given up (residency gate / a timed-out wait): nothing left to feed
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
-    const bool tr = lane == 0;
+    const bool tr = lane == 0 && t == 0;
     trace_ev(sh, c, l, TR_CONS + 0, tr);
     ld.pairs(L.wq, p.q0, p.q1, a.D);
     ld.pairs(L.wk, p.k0, p.k1, a.D);
@@ -335,14 +352,14 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       const size_t base = ((size_t)seq * L.W) * row_stride + (size_t)kv_real * DH + (lane & 15) * 8;
       for (int j = 0; j < p.n_att; ++j) {
         const int slot = min(p.s_begin + 4 * j + (lane >> 4), L.W - 1);
-        ld.piece(L.ck + base + (size_t)slot * row_stride);
-        ld.piece(L.cv + base + (size_t)slot * row_stride);
+        ld.kv_piece(L.ck + base + (size_t)slot * row_stride, MULTI);
+        ld.kv_piece(L.cv + base + (size_t)slot * row_stride, MULTI);
       }
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
-    if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
+    if (NHOLD) sh.ctl[C_LSTAGE] = stage_id(t, l);  // the latency-critical small phases are issued: holders may fetch
     if constexpr (!MOE) {
       const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
       for (int j = p.f0; j < f_ring; ++j) {
@@ -360,7 +377,7 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       ld.flush();
       ld.g = (ld.g + FILL - 1) & ~(uint32_t)(FILL - 1);
       uint32_t word = 0, spins = 0;
-      while (((word = sh.ctl[C_EXPERT]) >> 16) != (uint32_t)(l + 1))
+      while (((word = sh.ctl[C_EXPERT]) >> 16) != stage_id(t, l))
         if (!spin_ok(sh, spins, 0x100)) break;
       const void* const* tab = reinterpret_cast<const void* const*>(L.w2);  // device table [E][3] of (w1, w2, w3)
       const int ex[2] = {__builtin_amdgcn_readfirstlane((int)(word & 0xffu)), __builtin_amdgcn_readfirstlane((int)((word >> 8) & 0xffu))};
@@ -384,6 +401,7 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     slab(a.V / 2, c, a.NB, v0, v1);
     ld.pairs(a.output, v0, v1, a.D);
   }
+  }  // steps
   (void)PD;
   ld.flush();
 }
@@ -689,7 +707,7 @@ struct Cons {
 //            expert B rows with hid B; r = bf16(bf16(0 + bf16(wA yA)) + bf16(wB yB)); h = bf16(h1 + r)  (moe.py:28-32 +
 //            transformer_layers.py:168, the order of the launch path's moe_w2_kernel)
 __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons& cs, const EngLayer& L, const LayerPlan& p, int l,
-                                        int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
+                                        uint32_t stage, int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
                                         const u32x4 (&xr)[4], bool trc) {
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -773,7 +791,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
     wA = swap ? w1 : w0;
     wB = swap ? w0 : w1;
   }
-  if (w == 0 && lane == 0) sh.ctl[C_EXPERT] = ((uint32_t)(l + 1) << 16) | (uint32_t)eA | ((uint32_t)eB << 8);
+  if (w == 0 && lane == 0) sh.ctl[C_EXPERT] = (stage << 16) | (uint32_t)eA | ((uint32_t)eB << 8);
   trace_ev(sh, c, l, 13, trc);
   // ---- W1|W3 of the two experts (the loader restarts on a fill boundary behind the router edge)
   g = (g + FILL - 1) & ~(uint32_t)(FILL - 1);
@@ -831,9 +849,10 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
   }
 }
 
-template <int R, bool MOE>
-__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch,
+template <int R, bool MOE, bool MULTI>
+__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos0, int seq, uint32_t epoch0,
                                              uint32_t arrive_target) {
+  const int n_steps = MULTI ? a.n_steps : 1;
   Cons cs{sh, w, lane};
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -842,12 +861,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   const int nq = a.H * DH, nkv = a.Hkv * DH;
   uint32_t g = 0;  // first piece of the current segment
   uint32_t hold_target = 0;  // W1|W3 units the holder waves must have finished (cumulative)
-  uint32_t stat_wait = 0, stat_dur = 0, stat_n = 0;  // load-balance samples (wave 0, lane 0)
   long greedy_token = 0;     // the fused greedy sample (workgroup 0, wave 0, lane 0)
   float greedy_logprob = 0.f;
   bool greedy_valid = false;
-  auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
-
   // attention scratch inside the activation region (free between the q|k|v rows and the Wo gather)
   lu32* q_lds = xs32;                                            // R * 64 words
   lu32* kn_lds = xs32 + R * 64;                                  // 64 words
@@ -857,11 +873,19 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   lf32* sm_acc = sm_l + 4 * R;                                   // 4 R DH
   lu32* cmb_lds = reinterpret_cast<lu32*>(sm_acc + 4 * R * DH);  // split merge staging: 3 * n_splits * ne words
 
+  // One iteration = one decode step.  n_steps > 1 (GreedySession): the sample of step t is the input of step t + 1 INSIDE
+  // the launch - workgroup 0 publishes it as a granule when it commits the step, every workgroup picks it up at the top of
+  // the next one - so between two tokens there is neither a kernel boundary nor an empty ring.
+  for (int t = 0; t < n_steps; ++t) {
+  const int pos = pos0 + t;
+  const uint32_t epoch = (epoch0 + (uint32_t)t) & 0xfffffu;
+  auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
+  greedy_valid = false;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
-    const bool trc = (w == 0) && (lane == 0);
+    const bool trc = (w == 0) && (lane == 0) && (t == 0);
     trace_ev(sh, c, l, 0, trc);
 
     // ================================================================ attention_norm + q|k|v + RoPE + ring write
@@ -872,7 +896,28 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       // (transformer.py:193), or h as the previous stage / previous launch left it
       const bf16_t* hin = a.h;
       if (a.emb) {
-        long id = (long)a.ids[0];
+        long id;
+        if (t == 0) {
+          id = (long)a.ids[0];
+        } else {  // the previous step's sample: wave 0 waits for workgroup 0's granule, the other waves for wave 0
+          if (w == 0) {
+            const uint32_t want = (((epoch0 + (uint32_t)t - 1u) & 0xfffffu) << 12) | 0xfffu;
+            unsigned long long x;
+            uint32_t spins = 0;
+            for (;;) {
+              x = __hip_atomic_load(G + a.g_tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((uint32_t)(x >> 32) == want) break;
+              if (!spin_ok(sh, spins, 0x400)) break;
+            }
+            sh.ctl[C_TOKEN] = (uint32_t)x;
+            sh.ctl[C_TOKSTEP] = (uint32_t)t;
+          } else {
+            uint32_t spins = 0;
+            while (sh.ctl[C_TOKSTEP] != (uint32_t)t)
+              if (!spin_ok(sh, spins, 0x400)) break;
+          }
+          id = (long)sh.ctl[C_TOKEN];
+        }
         if (id < 0 || id >= a.V) {  // the reference's nn.Embedding raises IndexError: flagged for the host, row clamped
           if (c == 0 && w == 0 && lane == 0) atomicMax((uint32_t*)a.ctrl + G_BADID, 1u);
           id = id < 0 ? 0 : a.V - 1;
@@ -891,7 +936,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 1, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 2, trc);
-    if (l == 0) {
+    if (l == 0 && t == 0) {
       // RESIDENCY GATE.  Every hand-off below assumes that all NB workgroups run at the same time (one per CU).  Nothing
       // has been written yet - no ring row, no granule - so a launch that finds a workgroup missing (a CU masked or busy
       // with another process) gives up here WITHOUT side effects: the step can be re-run on the launch path from
@@ -944,7 +989,10 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           if (kind > 0) {  // cache.py:83-92
             const size_t slot = (size_t)seq * L.W + p.cur_slot;
             bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + r0;
-            *reinterpret_cast<uint32_t*>(ring) = packed;
+            if (MULTI)  // read again by another workgroup within this launch: write-through (Loader::kv_piece)
+              __hip_atomic_store(reinterpret_cast<uint32_t*>(ring), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+              *reinterpret_cast<uint32_t*>(ring) = packed;
           }
           const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
           cs.publish(G + a.g_qkv + gi, tag_of(l, 1), packed);
@@ -1106,10 +1154,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
     if constexpr (!MOE) {
-      uint64_t t_norm2 = 0;
-      if (a.f_stat && trc && (l & 7) == 3) t_norm2 = __builtin_amdgcn_s_memrealtime();
       const int n_hold = holder_units(a, p.f1 - p.f0);
-      if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
+      if (n_hold && w == 0) sh.ctl[C_XREADY] = stage_id(t, l);  // (rmsnorm_store ends with a barrier of the consumer waves)
       {
         const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
         for (int k = w; k < n_u; k += NCONS) {
@@ -1130,11 +1176,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
       // ================================================================ h = h1 + hid @ W2^T
       cs.cbar();
-      // load-balance statistics on every 8th layer (a clock read is an SMEM round trip: not on every layer): how long this
-      // workgroup's W1|W3 phase took and how long it then waits for the slowest workgroup's hid values
-      const bool sample = a.f_stat && trc && (l & 7) == 3;
-      uint64_t t_w13 = 0;
-      if (sample) t_w13 = __builtin_amdgcn_s_memrealtime();
       if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
         hold_target += (uint32_t)n_hold;
         uint32_t spins = 0;
@@ -1145,12 +1186,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
       cs.cbar();
       sh.ctl[C_GATHERING] = 0;
-      if (sample) {
-        const uint64_t t_hid = __builtin_amdgcn_s_memrealtime();
-        stat_wait += (uint32_t)(t_hid - t_w13);
-        stat_dur += (uint32_t)(t_w13 - t_norm2);
-        ++stat_n;
-      }
       trace_ev(sh, c, l, 15, trc);
       {
         const int n_u = p.o1 - p.o0;
@@ -1173,7 +1208,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         cs.set_done(g);
       }
     } else {
-      moe_ffn(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
+      moe_ffn(a, sh, cs, L, p, l, stage_id(t, l), c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
     }
     trace_ev(sh, c, l, 16, trc);
     cs.cbar();
@@ -1208,7 +1243,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       }
     }
     g += (uint32_t)(2 * (v1 - v0)) * PD;
-    cs.set_done(0xffffffffu);
+    cs.set_done(t == n_steps - 1 ? 0xffffffffu : g);  // (the ring is done with only after the LAST step)
     if (greedy) {
       // workgroup partial (max, FIRST index of the max, sum exp(x - max)) -> three granules -> workgroup 0 reduces them all.
       // Ties: the lower index wins at every level (torch.argmax returns the first maximal element).
@@ -1281,14 +1316,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       }
     }
   } else {
-    cs.set_done(0xffffffffu);
-  }
-
-  if (stat_n && w == 0 && lane == 0 && !sh.ctl[C_ABORT]) {  // one writer per workgroup; the host reads and zeroes (decode_engine_balance)
-    uint32_t* st = a.f_stat + 4 * c;
-    st[0] += stat_wait;
-    st[1] += stat_dur;
-    st[2] += stat_n;
+    cs.set_done(t == n_steps - 1 ? 0xffffffffu : g);
   }
 
   // ================================================================ commit (workgroup 0, one lane): the step becomes visible
@@ -1317,16 +1345,25 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     sh.ctrl[G_STEPS] = step + 1;
     sh.ctrl[G_ARRIVE] = 0;  // every workgroup of this launch has been counted and the next launch has not begun: no wrap
     __hip_atomic_store(sh.ctrl + G_EPOCH, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1 < n_steps)  // the next step of this launch starts from the sample (every workgroup waits for this granule)
+      cs.publish(G + a.g_tok, (epoch << 12) | 0xfffu, (uint32_t)greedy_token);
   }
+  if (sh.ctl[C_ABORT]) break;
+  }  // steps
 }
 
 // ------------------------------------------------------------------------------------------------ holder waves
 // Holder hi owns W1|W3 unit f1 - n_hold + hi of every layer (rows w1[2j], w3[2j], w1[2j+1], w3[2j+1]).  Same arithmetic
 // as Cons::unit_dot<4>: per row, pieces in ascending order, four dot2_bf16 per piece, then wave_sum - bit-identical.
-__device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, uint32_t epoch) {
+template <bool MULTI>
+__device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos0, uint32_t epoch0) {
+  const int n_steps = MULTI ? a.n_steps : 1;
   gu64* G = (gu64*)a.gran;
   const int PD = a.D >> 9;
   const lchar* xl = sh.xs + lane * 16;
+  for (int t = 0; t < n_steps; ++t) {
+  const int pos = pos0 + t;
+  const uint32_t epoch = (epoch0 + (uint32_t)t) & 0xfffffu;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     LayerPlan p;
@@ -1335,7 +1372,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     if (hi >= n_hold) continue;
     const int j = p.f1 - n_hold + hi;
     uint32_t spins = 0;
-    while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
+    while (sh.ctl[C_LSTAGE] < stage_id(t, l))  // not before the layer's q|k|v, K/V and Wo streams are on their way
       if (!spin_ok(sh, spins, 0x600)) return;
     const size_t r0 = (size_t)(2 * j) * a.D + lane * 8;
     const bf16_t* rows[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r0 + a.D, L.w3 + r0 + a.D};
@@ -1357,7 +1394,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       }
     }
     spins = 0;
-    while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
+    while (sh.ctl[C_XREADY] < stage_id(t, l))
       if (!spin_ok(sh, spins, 0x600)) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1383,11 +1420,13 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+  }  // steps
 }
 
 // MOE is a separate instantiation: the dense kernel must not pay registers for the router / two-expert code (it sits at
 // 247 of 256 VGPRs and spilled with the MoE path compiled in)
-template <int R, bool MOE>
+// ... and MULTI (several decode steps per launch) another one: its step loop costs the single-step kernel registers too.
+template <int R, bool MOE, bool MULTI>
 __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int c = blockIdx.x;
@@ -1414,8 +1453,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int pos = (int)a.kv_seqlens[0];
   const int seq = 0;
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
-  if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
-  else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
+  if (w == NCONS) run_loader<MOE, MULTI>(a, sh, c, lane, pos, seq);
+  else if (w > NCONS) run_holder<MULTI>(a, sh, c, w - NCONS - 1, lane, pos, epoch);
   else {
     // residency census: every workgroup counts itself in; consumers check the total before their first side effect
     uint32_t arrive_target = 0;
@@ -1427,7 +1466,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
       // test hook: wait for one workgroup more than exist - the gate fails exactly as it would with one missing
       if (__hip_atomic_load(sh.ctrl + G_SABOTAGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) arrive_target += 1u;
     }
-    run_consumer<R, MOE>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
+    run_consumer<R, MOE, MULTI>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
   }
   // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
   if (c == 0 && threadIdx.x == 0 && !sh.ctl[C_ABORT])
@@ -1439,10 +1478,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 struct GranLayout {
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, total;
-  size_t tune_off;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, g_tok, total;
 };
-constexpr size_t TUNE_TAB_BYTES = 2304, TUNE_STAT_BYTES = 1024 * 16;
 constexpr int AMAX_MAX_NB = 1024;  // workgroups the greedy-sampling edge is sized for (decode_engine_applicable: NB <= 1024)
 GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   using attn_core::DH;
@@ -1457,8 +1494,9 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   g.g_hid2 = off; off += F / 2;  // MoE: hid of the second expert
   g.g_part = off; off += (uint32_t)((size_t)Hs * max_splits * R * (DH + 2));
   g.g_amax = off; off += 4 * AMAX_MAX_NB;  // (max logit, argmax, sum exp, pad) per workgroup
+  g.g_tok = off;  off += 8;                // multi-step launches: the sample that feeds the next step
   g.total = off;
-  g.tune_off = ((size_t)off * 8 + 255) / 256 * 256;  // bytes: W1|W3 balance table (uint16 [1025], padded) then statistics
+
   return g;
 }
 }  // namespace
@@ -1466,7 +1504,7 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
 size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW) {
   if (Hkv <= 0 || H % Hkv) return 0;
   (void)maxW;  // sized for the maximum of 32 splits so that the layout depends on the model only
-  return gran_layout(D, H, Hkv, F, 32).tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES;
+  return (size_t)gran_layout(D, H, Hkv, F, 32).total * 8;
 }
 
 bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
@@ -1509,7 +1547,6 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
 namespace {
 uint64_t* g_trace = nullptr;
 int g_thin = -1, g_depth = -1, g_holders = -1;
-int g_balance_stats = -1;  // the kernel samples its W1|W3 phase for decode_engine_balance (MI_ENGINE_BALANCE=0: never)
 }
 void decode_engine_set_holders(int on) { g_holders = on; }
 void decode_engine_set_knobs(int thin, int depth) {
@@ -1612,14 +1649,8 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   a.gran = (uint64_t*)pr.granules; a.ctrl = pr.ctrl;
   const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
   a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
-  a.g_amax = gl.g_amax; a.g_hid2 = gl.g_hid2; a.E = pr.E;
-  if (gl.tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
-  a.f_tab = reinterpret_cast<const uint16_t*>((const char*)pr.granules + gl.tune_off);
-  if (g_balance_stats < 0) {
-    const char* e = getenv("MI_ENGINE_BALANCE");
-    g_balance_stats = e ? (atoi(e) != 0) : 0;  // off: balancing measured slower (GreedySession.BALANCE)
-  }
-  a.f_stat = g_balance_stats ? reinterpret_cast<uint32_t*>((char*)pr.granules + gl.tune_off + TUNE_TAB_BYTES) : nullptr;
+  a.g_amax = gl.g_amax; a.g_hid2 = gl.g_hid2; a.g_tok = gl.g_tok; a.E = pr.E;
+  if ((size_t)gl.total * 8 > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
 
   for (int l0 = 0; l0 < pr.n_layers; l0 += ENG_MAXL) {
     const int nl = pr.n_layers - l0 < ENG_MAXL ? pr.n_layers - l0 : ENG_MAXL;
@@ -1632,6 +1663,9 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
     a.commit = last;
     a.head = last && pr.logits != nullptr;
     const bool greedy = a.head && pr.greedy_tok && pr.greedy_lp;
+    // several decode steps in ONE launch: only when the whole step is this launch and it produces its own next input
+    a.n_steps = (pr.n_steps > 1 && greedy && l0 == 0 && last && a.emb && pr.ids == pr.greedy_tok) ? pr.n_steps : 1;
+    if (pr.n_steps > 1 && a.n_steps == 1) return hipErrorInvalidValue;  // (mi_forward loops single steps in that case)
     a.greedy_tok = greedy ? pr.greedy_tok : nullptr;
     a.greedy_lp = greedy ? pr.greedy_lp : nullptr;
     a.hist_tok = greedy && pr.hist_lp ? pr.hist_tok : nullptr;
@@ -1653,17 +1687,21 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
       L.chunk = attn_core::split_chunk(L.W, L.n_splits);
     }
     const void* fn = nullptr;
-    const bool moe = pr.E > 0;
+    const bool moe = pr.E > 0, multi = a.n_steps > 1;
+#define ENG_PICK(RR)                                                                                                   \
+  (moe ? (multi ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
+       : (multi ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
     switch (a.R) {
-      case 1: fn = moe ? (const void*)decode_engine_kernel<1, true> : (const void*)decode_engine_kernel<1, false>; break;
-      case 2: fn = moe ? (const void*)decode_engine_kernel<2, true> : (const void*)decode_engine_kernel<2, false>; break;
-      case 4: fn = moe ? (const void*)decode_engine_kernel<4, true> : (const void*)decode_engine_kernel<4, false>; break;
-      case 8: fn = moe ? (const void*)decode_engine_kernel<8, true> : (const void*)decode_engine_kernel<8, false>; break;
+      case 1: fn = ENG_PICK(1); break;
+      case 2: fn = ENG_PICK(2); break;
+      case 4: fn = ENG_PICK(4); break;
+      case 8: fn = ENG_PICK(8); break;
       default: return hipErrorInvalidValue;
     }
+#undef ENG_PICK
     // 160 KiB of dynamic LDS is an opt-in per function AND per device
-    static bool attr_set[64][18] = {};
-    const int slot = a.R + (moe ? 9 : 0);
+    static bool attr_set[64][36] = {};
+    const int slot = a.R + (moe ? 9 : 0) + (multi ? 18 : 0);
     if (dev < 0 || dev >= 64 || !attr_set[dev][slot]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;
@@ -1674,90 +1712,4 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
-}
-
-// ---------------------------------------------------------------------------------------------------- W1|W3 load balance
-// The W1|W3 phase is 54 % of a layer's bytes and ends in an all-to-all: every workgroup waits for the SLOWEST one's hid
-// values.  The trace shows a systematic part in who is slow (profiles/r03_*: odd XCDs ~2 us late on this phase - and only
-// this phase - on every layer; single CUs up to 2.3 us late on average) next to ~1.5 us of per-layer jitter.  W1|W3 outputs
-// are not tied to a workgroup's residual slab, so the split of its units is free: the kernel samples (every 8th layer) how
-// long each workgroup waited at the hid hand-off, and this host routine - called where the caller synchronises anyway
-// (GreedySession.collect) - moves units from the workgroups that waited least (late) to those that waited longest
-// (early), one unit (~1 us) at a time while the gap exceeds 1.5 units.  Results are bit-identical for any split.
-hipError_t decode_engine_balance(const EngProblem& pr, int mode, int* moved, hipStream_t s) {
-  if (moved) *moved = 0;
-  const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
-  if (!pr.granules || gl.tune_off + TUNE_TAB_BYTES + TUNE_STAT_BYTES > pr.granule_bytes) return hipErrorInvalidValue;
-  const int NB = pr.NB, U = pr.F / 2;
-  if (NB < 1 || NB > 1024 || U > 65535) return hipErrorInvalidValue;
-  char* tab_dev = (char*)pr.granules + gl.tune_off;
-  char* stat_dev = tab_dev + TUNE_TAB_BYTES;
-  static thread_local uint16_t tab[1025];
-  static thread_local uint32_t stat[1024 * 4];
-  hipError_t e = hipMemcpyAsync(tab, tab_dev, (NB + 1) * 2, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(stat, stat_dev, (size_t)NB * 16, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e != hipSuccess) return e;
-  int n[1024];
-  const bool valid = tab[NB] == (uint16_t)U && tab[0] == 0;
-  for (int c = 0; c < NB; ++c)
-    n[c] = valid ? (int)tab[c + 1] - (int)tab[c] : (int)((long)U * (c + 1) / NB) - (int)((long)U * c / NB);
-  int changed = 0;
-  if (mode == 1) {
-    for (int c = 0; c < NB; ++c) {
-      const int u = (int)((long)U * (c + 1) / NB) - (int)((long)U * c / NB);
-      changed += abs(u - n[c]);
-      n[c] = u;
-    }
-  } else if (mode == 2) {  // tests: a deterministic, strongly skewed split (some workgroups below the holder threshold)
-    for (int c = 0; c < NB; ++c) n[c] = (int)((long)U * (c + 1) / NB) - (int)((long)U * c / NB);
-    for (int c = 0; c + 1 < NB; c += 2) {
-      const int d = (c / 2) % 4 < n[c] ? (c / 2) % 4 : 0;
-      n[c] -= d;
-      n[c + 1] += d;
-      changed += 2 * d;
-    }
-  } else {
-    // Signal: the DURATION of the workgroup's W1|W3 phase (ffn_norm done -> last consumer wave done).  The phase begins
-    // within +-0.3 us everywhere (it follows an all-to-all), so a longer phase is a later end.  The wait at the hid
-    // hand-off was tried first and is the wrong signal - it contains the workgroup's own sweep time, which differs by XCD:
-    // balancing on it made the step 50 us SLOWER.
-    double dur[1024], mean_dur = 0;
-    int with = 0;
-    for (int c = 0; c < NB; ++c)
-      if (stat[4 * c + 2]) {
-        dur[c] = stat[4 * c + 1] / (100.0 * stat[4 * c + 2]);  // us (100 MHz clock)
-        mean_dur += dur[c];
-        ++with;
-      }
-    if (with == NB && stat[2] >= 8) {  // every workgroup has samples, and enough of them (>= 2 steps of 32 layers)
-      mean_dur /= NB;
-      const double ut = mean_dur / ((double)U / NB);  // time of one unit
-      double late[1024];
-      for (int c = 0; c < NB; ++c) late[c] = dur[c] - mean_dur;
-      const int floor_units = U / NB - 4 > 12 ? U / NB - 4 : (U / NB > 2 ? U / NB - 2 : 1);
-      for (int it = 0; it < NB; ++it) {
-        int hi = 0, lo = 0;
-        for (int c = 1; c < NB; ++c) {
-          if (late[c] > late[hi]) hi = c;
-          if (late[c] < late[lo]) lo = c;
-        }
-        if (late[hi] - late[lo] <= 1.5 * ut || n[hi] <= floor_units || n[lo] >= U / NB + 4) break;
-        --n[hi];
-        ++n[lo];
-        late[hi] -= ut;
-        late[lo] += ut;
-        changed += 2;
-      }
-    }
-  }
-  tab[0] = 0;
-  for (int c = 0; c < NB; ++c) tab[c + 1] = (uint16_t)(tab[c] + n[c]);
-  if (tab[NB] != (uint16_t)U) return hipErrorInvalidValue;  // (cannot happen: every move keeps the total)
-  memset(stat, 0, (size_t)NB * 16);
-  e = hipMemcpyAsync(tab_dev, tab, (NB + 1) * 2, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(stat_dev, stat, (size_t)NB * 16, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (moved) *moved = changed / 2;
-  return e;
 }

@@ -217,10 +217,9 @@ struct EngArgs {
   float* logits;
   uint64_t* gran;         // granule regions
   uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, g_tok;
+  int n_steps;            // decode steps run by this launch (> 1: the sample of one is the input of the next, in-kernel)
   int E;                  // experts (0: dense).  MoE layers: EngLayer.w1 = gate [E, D], .w2 = device table [E][3] of (w1, w2, w3)
-  const uint16_t* f_tab;  // [NB + 1] first W1|W3 unit of every workgroup (valid iff f_tab[NB] == F / 2), see decode_engine_balance
-  uint32_t* f_stat;       // [NB][4] per workgroup: ticks waited at the hid hand-off, ticks of the W1|W3 phase, samples, -
   unsigned long long* trace;  // optional timeline buffer (debug)
   EngLayer L[ENG_MAXL];
 };
@@ -228,6 +227,7 @@ struct EngArgs {
 struct EngProblem {
   int D, H, Hkv, F, V, n_layers, NB;
   int E, top_k;              // MoE (0, 0: dense)
+  int n_steps;               // consecutive greedy decode steps wanted (1 unless ids aliases greedy_tok)
   float eps;
   const mi_layer_t* layers;  // host
   void* const* cache_k;      // host [n_layers]
@@ -261,7 +261,5 @@ void decode_engine_forget_census();  // tests
 void decode_engine_set_trace(void* dev_buffer);  // debug: nullptr disables
 void decode_engine_set_knobs(int thin, int depth);  // debug / tuning
 void decode_engine_set_holders(int on);             // debug / A/B: -1 = environment default
-// W1|W3 load balance (decode_engine.hip): mode 0 adapt from the statistics the kernel collected, 1 uniform split, 2 a
-// deterministic skewed split (tests).  Synchronises `s`.  *moved = units that changed owner.
-hipError_t decode_engine_balance(const EngProblem& pr, int mode, int* moved, hipStream_t s);
+
 size_t decode_engine_trace_bytes(int NB);

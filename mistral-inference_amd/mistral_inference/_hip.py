@@ -52,6 +52,7 @@ class MiBatch(C.Structure):
         ("cache_sizes", C.POINTER(C.c_int32)), ("h", _vp), ("logits", _vp), ("workspace", _vp),
         ("workspace_bytes", C.c_size_t),
         ("greedy_token", _vp), ("greedy_logprob", _vp), ("hist_token", _vp), ("hist_logprob", _vp), ("hist_len", C.c_int32),
+        ("greedy_steps", C.c_int32),
     ]
 
 
@@ -88,7 +89,6 @@ _SIGS = {
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_census": (C.c_int, [C.c_int]),
     "mi_decode_engine_reset": (C.c_int, [_vp, _vp]),
-    "mi_decode_engine_balance": (C.c_int, [C.POINTER(MiModel), _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int), _vp]),
     "mi_decode_engine_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "mi_rccl_unique_id": (C.c_int, [_vp]),
     "mi_rccl_init": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),

@@ -142,18 +142,6 @@ class HipStackBackend:
             raise RuntimeError(f"persistent decode engine: status 0x{st['status']:x} - {what}.  "
                                "MI_DECODE_ENGINE=0 selects the launch path.")
 
-    def balance_engine(self, model: "Transformer", mode: int = 0) -> int:
-        """W1|W3 load balance of the persistent decode engine (include/mistral_hip.h mi_decode_engine_balance): reads the
-        hand-off waits the kernel sampled and moves units from late workgroups to early ones.  Synchronises.  Returns the
-        number of units moved (0 for MoE models / no samples)."""
-        if self._workspace is None:
-            return 0
-        moved = C.c_int(0)
-        ws = self._workspace
-        _hip.check(_hip.lib().mi_decode_engine_balance(C.byref(self.plan(model)), ws.data_ptr(), ws.numel(), 1, mode,
-                                                       C.byref(moved), _hip.stream_ptr(ws.device)), "mi_decode_engine_balance")
-        return int(moved.value)
-
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
         need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
         ws = self._workspace
@@ -166,7 +154,7 @@ class HipStackBackend:
     # -- per forward -------------------------------------------------------------------------------
     def run_stack(self, model: "Transformer", h: torch.Tensor, input_ids: Optional[torch.Tensor],
                   meta: BatchMetadata, cache: Optional[BufferCache], logits: Optional[torch.Tensor],
-                  greedy: Optional["GreedyBuffers"] = None) -> None:
+                  greedy: Optional["GreedyBuffers"] = None, greedy_steps: int = 1) -> None:
         m = self.plan(model)
         T, B = h.shape[0], len(meta.seqlens)
         bt = _hip.MiBatch()
@@ -188,6 +176,7 @@ class HipStackBackend:
             bt.greedy_token, bt.greedy_logprob = _hip.dev_ptr(greedy.tok, torch.long), _hip.dev_ptr(greedy.lp, torch.float32)
             bt.hist_token, bt.hist_logprob = _hip.dev_ptr(greedy.hist_tok, torch.long), _hip.dev_ptr(greedy.hist_lp, torch.float32)
             bt.hist_len = greedy.hist_tok.shape[0]
+            bt.greedy_steps = greedy_steps
         wsb = self._get_workspace(model, m, T, B, max_w)
         bt.workspace, bt.workspace_bytes = wsb.data_ptr(), wsb.numel()
         _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
@@ -622,9 +611,9 @@ class GreedySession:
     # decode steps per hipGraph launch.  Measured (profiles/EXPERIMENTS.md): 8 steps per graph close the ~9 us gap between two
     # graph launches, and the kernels then run ~10 us longer each (their ramp-up is no longer hidden in the gap): no gain -> 1
     GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "1"))
-    # adapt the engine's W1|W3 split at collect() time (mi_decode_engine_balance).  Measured 35-50 us per step SLOWER on two
-    # boxes, with either signal: off.  (The mechanism stays: any split is bit-identical, tests/test_gpu_engine.py.)
-    BALANCE = os.environ.get("MI_ENGINE_BALANCE", "0") != "0"
+    # decode steps per ENGINE launch (mi_batch_t.greedy_steps): the kernel carries the sample from one step to the next itself,
+    # the weight stream runs on across the token boundary (1: one launch per token, replayed from a hipGraph)
+    LAUNCH_STEPS = int(os.environ.get("MI_LAUNCH_STEPS", "32"))
 
     def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
         assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"
@@ -643,18 +632,18 @@ class GreedySession:
         self._use_graph = graph and dev.type == "cuda"
         self._graphs: dict = {}            # steps per graph -> captured hipGraph
         self._warm = False
+        self._engine = False               # the persistent engine takes this model's decode steps (known after the first one)
         self._base: Optional[int] = None   # value of the workspace's step counter when this session began
         self._pending = 0                  # steps enqueued and not yet collected
         self._n_collected = 0
-        self._balance_calls = 0
-        self.units_moved = 0               # W1|W3 units the engine's load balancer re-assigned during this session
 
     # -- one step, enqueued launch by launch
-    def _step_eager(self) -> None:
+    def _step_eager(self, steps: int = 1) -> None:
+        """`steps` consecutive decode steps in ONE native call (mi_batch_t.greedy_steps): on the persistent engine one launch."""
         m, cache = self.model, self.cache
         meta = cache.batch_metadata([1] * self.B)
         assert meta.branch == _hip.BRANCH_DECODE
-        m._backend.run_stack(m, self.h, self.buf.tok, meta, cache, self.logits, greedy=self.buf)
+        m._backend.run_stack(m, self.h, self.buf.tok, meta, cache, self.logits, greedy=self.buf, greedy_steps=steps)
 
     def _steps_now(self) -> int:
         return _hip.decode_engine_status(self.model._backend._workspace)["steps"]
@@ -664,9 +653,12 @@ class GreedySession:
         if not self._warm:  # first step eagerly: sizes the workspace, runs the engine's one-time residency census
             if m._backend._workspace is None:
                 m._backend._get_workspace(m, m._backend.plan(m), 1, self.B, max(cache.cache_sizes))
-            self._base = self._steps_now()
+            before = _hip.decode_engine_status(m._backend._workspace)
+            self._base = before["steps"]
             self._step_eager()
             self._warm = True
+            # did the persistent engine take the step?  Then several steps go into one launch from here on (no graph needed)
+            self._engine = _hip.decode_engine_status(m._backend._workspace)["engine_launches"] > before["engine_launches"]
             return
         if self._use_graph:
             g = self._captured(1)
@@ -703,6 +695,14 @@ class GreedySession:
         left = n
         while left > 0:
             k = 1
+            if self._warm and self._engine and self.LAUNCH_STEPS > 1 and left > 1:
+                # persistent engine: up to LAUNCH_STEPS tokens per launch - the sample feeds the next step inside the kernel
+                k = min(left, self.LAUNCH_STEPS)
+                self._step_eager(k)
+                cache.advance_host([k] * self.B)
+                self._pending += k
+                left -= k
+                continue
             if self._warm and self._use_graph and left >= self.GRAPH_STEPS > 1:
                 g = self._captured(self.GRAPH_STEPS)
                 if g is not None:
@@ -734,10 +734,6 @@ class GreedySession:
             self._recover(missing)
         elif done_total != issued_total:
             raise RuntimeError(f"decode steps issued {issued_total} != completed {done_total}")
-        elif self.BALANCE and self.B == 1 and self._balance_calls < 16:
-            # the stream is idle right here: let the engine re-balance its W1|W3 split from the waits it sampled
-            self._balance_calls += 1
-            self.units_moved += m._backend.balance_engine(m)
         first = self._collected()
         idx = torch.arange(first, first + n, device=m.device) + self._base
         idx = idx % self.HIST
@@ -758,6 +754,7 @@ class GreedySession:
         m, cache = self.model, self.cache
         _hip.decode_engine_reset(m._backend._workspace)
         _hip.set_decode_engine(False)
+        self._engine = False
         self._graphs = {}  # they hold engine launches
         cache._seen = [p - missing for p in cache._seen]
         for _ in range(missing):

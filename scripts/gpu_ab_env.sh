@@ -9,13 +9,14 @@ LOG=gpurun_out/ab_env.log
 run() {  # label, then env assignments, then -- bench args
   local label=$1; shift
   local envs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  env "${envs[@]}" timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline "$@" > gpurun_out/v.out 2>&1
+  local defaults="--steps 64 --warmup 8"; case " $* " in *" --steps "*) defaults="";; esac
+  env "${envs[@]}" timeout 600 python bench.py $defaults --no-cpu-baseline "$@" > gpurun_out/v.out 2>&1
   python - "$label" <<'PY' | tee -a gpurun_out/ab_env.log
 import json, sys
 try:
     d = json.loads(open('gpurun_out/v.out').read().strip().splitlines()[-1])
     r = d.get('roofline', {})
-    print(f"{sys.argv[1]:34s} ms/step {d['ms_per_step']:.4f}  tok/s {d['value']:.1f}  step frac {d['hbm_roofline_step']['frac']:.4f}  kernel us {r.get('avg_launch_us')}  moved {d['config'].get('engine_w13_units_rebalanced')}  [{d['config']['decode_launch']}]")
+    print(f"{sys.argv[1]:34s} ms/step {d['ms_per_step']:.4f}  tok/s {d['value']:.1f}  step frac {d['hbm_roofline_step']['frac']:.4f}  kernel us {r.get('avg_launch_us')}  [{d['config']['decode_launch']}]")
 except Exception as e:
     print(sys.argv[1], 'FAILED', e, open('gpurun_out/v.out').read()[-600:])
 PY

@@ -12,10 +12,12 @@ f = glob.glob("gpurun_out/prof/**/*kernel_trace.csv", recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # last complete decode step: from the last decode_prep launch to the end
-    idx = [i for i, r in enumerate(rows) if "decode_prep" in r["Kernel_Name"]]
+    # last complete decode steps: from one engine launch (or decode_prep on the launch path) to the next
+    idx = [i for i, r in enumerate(rows) if "decode_engine_kernel" in r["Kernel_Name"]] or \
+          [i for i, r in enumerate(rows) if "decode_prep" in r["Kernel_Name"]]
+    idx = idx[-4:-1] if len(idx) >= 4 else idx
     if len(idx) >= 2:
-        a, b = idx[-2], idx[-1]
+        a, b = idx[0], idx[-1]
         t0 = int(rows[a]["Start_Timestamp"])
         with open("gpurun_out/one_step_timeline.csv", "w") as o:
             o.write("start_us,duration_us,kernel,grid_x,wg_x,vgpr,lds\n")

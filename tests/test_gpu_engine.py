@@ -134,33 +134,6 @@ def test_two_launch_depth_vs_oracle_and_graph():
     assert worst < 6e-2, worst   # 34 layers of bf16 storage (the 32-layer floor of test_gpu_depth is 4.7e-2)
 
 
-@pytest.mark.parametrize("name", ["gqa4_window_wraps", "holders_mid_size"])
-def test_engine_bit_equal_for_any_w13_split(name):
-    """The W1|W3 load balancer (mi_decode_engine_balance) may hand any workgroup any number of units: results must not
-    move by a bit.  Mode 2 installs a strongly skewed split (0..3 units shifted between neighbours: at the mid size some
-    workgroups drop below the holder-wave threshold while their neighbours keep it), mode 1 the uniform one."""
-    p = SHAPES[name]
-    m, _ = _model(mo.OracleArgs(**p), seed=17)
-    prompt_len, steps = 40, 10
-    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(12)).cuda()
-    ref, ref_rings, _ = _run(m, ids, prompt_len, steps, engine=False)
-    _run(m, ids, prompt_len, 2, engine=True)             # (creates the workspace the table lives in)
-    assert m._backend.balance_engine(m, mode=2) > 0
-    got, got_rings, st = _run(m, ids, prompt_len, steps, engine=True)
-    graph, _, st2 = _run(m, ids, prompt_len, steps, engine=True, graph=True)
-    assert st["status"] == 0 and st2["status"] == 0
-    assert all(torch.equal(a, b) for a, b in zip(ref, got)) and all(torch.equal(a, b) for a, b in zip(ref, graph))
-    for (k0, v0), (k1, v1) in zip(ref_rings, got_rings):
-        assert torch.equal(k0, k1) and torch.equal(v0, v1)
-    # the adaptive mode on real samples: whatever it decides, the results stay put
-    m._backend.balance_engine(m, mode=0)
-    again, _, _ = _run(m, ids, prompt_len, steps, engine=True)
-    assert all(torch.equal(a, b) for a, b in zip(ref, again))
-    assert m._backend.balance_engine(m, mode=1) >= 0
-    back, _, _ = _run(m, ids, prompt_len, steps, engine=True)
-    assert all(torch.equal(a, b) for a, b in zip(ref, back))
-
-
 @pytest.mark.parametrize("holders", [1, 0])
 def test_holder_waves_fingerprint(holders):
     """Holder waves reduce their W1|W3 unit from REGISTERS, not from the ring: same arithmetic, same order - made visible
@@ -323,5 +296,21 @@ def test_engine_full_size_bit_equal():
     graph, _, st2 = _run(m, ids, T, steps, engine=True, graph=True)
     assert st2["status"] == 0
     assert all(torch.equal(a, b) for a, b in zip(ref, graph))
+    # several tokens per launch (mi_batch_t.greedy_steps: the sample reaches the next step inside the kernel, the K/V row of
+    # step t is read at step t + 1 without a kernel boundary in between) == one launch per token: tokens, last logits, rings
+    outs = []
+    for launch_steps in (1, 16):
+        c = _cache(m, T + 40)
+        last = m.forward(ids[:T], [T], c)[-1:]
+        sess = m.greedy_session(c, torch.argmax(last, dim=-1))
+        sess.LAUNCH_STEPS = launch_steps
+        sess.run(33)                      # 1 + 16 + 16 across the 4096-slot ring's wrap
+        toks, lps = sess.collect()
+        rings = [(c.cache_k[l][:, :40].clone(), c.cache_v[l][:, :40].clone()) for l in range(m.n_local_layers)]
+        outs.append((toks.clone(), lps.clone(), sess.logits.clone(), rings))
+    (t1, l1, g1, r1), (t2, l2, g2, r2) = outs
+    assert torch.equal(t1, t2) and torch.equal(l1, l2) and torch.equal(g1, g2), (t1[:, 0].tolist(), t2[:, 0].tolist())
+    for (k1, v1), (k2, v2) in zip(r1, r2):
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
     del m
     torch.cuda.empty_cache()
