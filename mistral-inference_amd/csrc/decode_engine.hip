@@ -173,6 +173,7 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
   p.v1 = p.k1;
   slab(a.D / 2, c, a.NB, p.o0, p.o1);
   slab(a.F / 2, c, a.NB, p.f0, p.f1);
+  slab(a.H * DH / 2, c, a.NB, p.e0, p.e1);
   const int kv_len = min(pos + 1, L.W);
   p.cur_slot = pos % L.W;
   p.att = c < a.Hs * L.n_splits;
