@@ -353,8 +353,8 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       const size_t base = ((size_t)seq * L.W) * row_stride + (size_t)kv_real * DH + (lane & 15) * 8;
       for (int j = 0; j < p.n_att; ++j) {
         const int slot = min(p.s_begin + 4 * j + (lane >> 4), L.W - 1);
-        ld.kv_piece(L.ck + base + (size_t)slot * row_stride, MULTI);
-        ld.kv_piece(L.cv + base + (size_t)slot * row_stride, MULTI);
+        ld.kv_piece(L.ck + base + (size_t)slot * row_stride, MULTI && a.kv_coherent);
+        ld.kv_piece(L.cv + base + (size_t)slot * row_stride, MULTI && a.kv_coherent);
       }
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
@@ -1651,6 +1651,14 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
   a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
   a.g_amax = gl.g_amax; a.g_hid2 = gl.g_hid2; a.g_tok = gl.g_tok; a.E = pr.E;
+  {
+    static int kvc = -1;  // MI_ENGINE_KV_SC1=0: DIAGNOSTIC ONLY - non-temporal K/V reads inside multi-step launches are not coherent
+    if (kvc < 0) {
+      const char* e = getenv("MI_ENGINE_KV_SC1");
+      kvc = e ? (atoi(e) != 0) : 1;
+    }
+    a.kv_coherent = kvc;
+  }
   if ((size_t)gl.total * 8 > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
 
   for (int l0 = 0; l0 < pr.n_layers; l0 += ENG_MAXL) {

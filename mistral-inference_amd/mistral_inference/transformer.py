@@ -613,7 +613,10 @@ class GreedySession:
     GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "1"))
     # decode steps per ENGINE launch (mi_batch_t.greedy_steps): the kernel carries the sample from one step to the next itself,
     # the weight stream runs on across the token boundary (1: one launch per token, replayed from a hipGraph)
-    LAUNCH_STEPS = int(os.environ.get("MI_LAUNCH_STEPS", "32"))
+    # MEASURED (profiles/EXPERIMENTS.md): no faster than one launch per token with non-temporal K/V reads (2.79-2.80 vs
+    # 2.78-2.82 ms), and 60-170 us per step SLOWER with the sc1 K/V reads that coherence inside one launch requires (the
+    # K/V row written at step t is read at step t + 1 by another XCD without a kernel boundary in between) -> default 1.
+    LAUNCH_STEPS = int(os.environ.get("MI_LAUNCH_STEPS", "1"))
 
     def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
         assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of engine build variants on ONE box (box-to-box spread is ~1-2 %, larger than most single changes):
-#   here:  python /tmp/build_variants.py   (build_native.build(extra_flags=..., lib='lib/variants/libmistral_hip_<name>.so'))
+#   here:  python scripts/build_variants.py
 #   then:  gpurun --timeout 900 -- 'bash scripts/gpu_ab.sh [reps] [extra bench args]'
 # Every variant in mistral-inference_amd/lib/variants/ and the main library are benchmarked `reps` times, interleaved.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

@@ -22,10 +22,10 @@ except Exception as e:
 PY
 }
 for rep in $(seq 1 $REPS); do
-  run "shipped (graph x8, balance)" X=1 --
-  run "graph x1, balance" MI_GRAPH_STEPS=1 --
-  run "graph x8, no balance" MI_ENGINE_BALANCE=0 --
-  run "graph x1, no balance" MI_GRAPH_STEPS=1 MI_ENGINE_BALANCE=0 --
+  run "shipped (1 token per launch, graph)" X=1 --
+  run "8 steps per hipGraph" MI_GRAPH_STEPS=8 --
+  run "32 tokens per engine launch" MI_LAUNCH_STEPS=32 --
+  run "driver shape: steps 20 warmup 5" X=1 -- --steps 20 --warmup 5
 done
-run "graph x32, balance" MI_GRAPH_STEPS=32 --
-run "forward() + argmax loop" MI_ENGINE_BALANCE=0 -- --loop forward
+run "forward() + torch.argmax loop" X=1 -- --loop forward
+run "launch path (engine off)" MI_DECODE_ENGINE=0 --
