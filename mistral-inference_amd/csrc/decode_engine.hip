@@ -279,7 +279,7 @@ struct Loader {
     ++g;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
-  // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: g % 4 == 0): one address, immediate offsets
+  // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: all inside one fill): one address, immediate offsets
   __device__ __forceinline__ void piece4(const void* src_lane) {
     if ((g & (FILL - 1)) == 0) fill_begin();
     lchar* dst = slot_of(g);
@@ -288,6 +288,16 @@ struct Loader {
     dma<2 * PIECE>(src_lane, dst);
     dma<3 * PIECE>(src_lane, dst);
     g += 4;
+    if ((g & (FILL - 1)) == 0) fill_end();
+  }
+  // 2 consecutive pieces (g even): the group size of rows whose piece count is 2 mod 4 (dim 5120 = 10 pieces).  Issued one
+  // by one such rows cost ~180 cycles per piece - the loader becomes the bottleneck (13 GB/s per CU at the Nemo dims).
+  __device__ __forceinline__ void piece2(const void* src_lane) {
+    if ((g & (FILL - 1)) == 0) fill_begin();
+    lchar* dst = slot_of(g);
+    dma<0>(src_lane, dst);
+    dma<PIECE>(src_lane, dst);
+    g += 2;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
   // One UNIT = NR weight rows of P pieces each that a consumer wave reduces together.  Stream order inside a unit: groups
@@ -301,8 +311,13 @@ struct Loader {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const char* src = reinterpret_cast<const char*>(rp[r]) + (size_t)p0 * PIECE + lane * 16;
-        if (G == 4 && (g & 3) == 0) {
+        // (a group may start at any piece index - phases with different group sizes follow each other, e.g. dim 5120:
+        // 10-piece rows, then 8-piece Wo rows - as long as it stays inside one 16-piece fill: contiguous ring slots,
+        // and the fill bookkeeping sees every fill begin and end)
+        if (G == 4 && (g & (FILL - 1)) <= FILL - 4) {
           piece4(src);
+        } else if (G == 2 && (g & (FILL - 1)) <= FILL - 2) {
+          piece2(src);
         } else {
           for (int i = 0; i < G; ++i) piece(src + (size_t)i * PIECE);
         }
@@ -1516,6 +1531,11 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   using attn_core::DH;
   if (pr.D % 512 || pr.F % 512 || (pr.H * DH) % 512) return no("dim / hidden_dim / n_heads*128 not a multiple of 512");
   if (pr.D > 8192) return no("dim > 8192 (fused RMSNorm holds 4 pieces per thread)");
+  // Rows of 4k + 2 pieces (dim 5120 = Mistral-Nemo: 10) stream in 2-piece groups; measured at the Nemo dims the engine then
+  // runs its W1|W3 phase at 17.6 GB/s per CU instead of 28 and the whole step is SLOWER than the launch path (6.75 vs
+  // 5.06 ms, profiles/EXPERIMENTS.md).  Until that path is as fast, such models take the launch path; small dims (the
+  // parity tests' 512 / 1024) stay on the engine, where the group size does not matter.
+  if (pr.D > 2048 && ((pr.D >> 9) & 3) != 0) return no("dim > 2048 and not a multiple of 2048: launch path is faster (Nemo dims)");
   if (pr.V % 2) return no("odd vocab");
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch

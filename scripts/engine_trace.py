@@ -28,9 +28,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--prefill", type=int, default=4096)
+    ap.add_argument("--model", default="mistral-7b", choices=sorted(bench.PRESETS))
     opt = ap.parse_args()
-    params = dict(bench.MISTRAL_7B)
-    params["n_layers"] = opt.layers
+    params = dict(bench.PRESETS[opt.model][0])
+    params["n_layers"] = min(opt.layers, 32)   # (the trace buffer holds one launch = 32 layers)
+    opt.layers = params["n_layers"]
     model = bench.build_model(params, 0, 1, "cuda")
     a = model.args
     cache = BufferCache(model.n_local_layers, 1, opt.prefill + 64, a.n_kv_heads, a.head_dim, a.sliding_window, device="cuda",
