@@ -185,7 +185,10 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
 }
 
 // pieces per group of a unit's interleaved stream (loader and consumers must agree)
-__device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P & 1) == 0 ? 2 : 1); }
+// A row of P pieces is streamed in groups of 4 pieces as long as 4 are left, then one group of 2 and / or 1 (dim 5120 = 10
+// pieces: 4 + 4 + 2).  Uniform 2-piece groups for such rows made the LOADER the bottleneck: its cost is per group (one address
+// computation, ring-slot and fill bookkeeping, ~200 cycles), not per piece - 17 GB/s per CU at the Mistral-Nemo dims.
+__device__ __forceinline__ int unit_group(int left) { return left >= 4 ? 4 : (left >= 2 ? 2 : 1); }
 
 // HOLDER waves: the last holder_units() W1|W3 units of a CU's slab never pass through the ring.  A holder wave fetches
 // its unit (4 rows x D bf16 = 32 KiB at D = 4096) straight into 128 of its VGPRs while the attention block of the layer
@@ -194,7 +197,7 @@ __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P
 constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
 __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
   const int P = a.D >> 9;
-  return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
+  return (NHOLD > 0 && a.holders && a.E == 0 && (P & 3) == 0 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ loader wave
@@ -300,14 +303,22 @@ struct Loader {
     g += 2;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
+  // Skip ring slots up to the next multiple of 4 pieces (after the K/V slices, whose count is any even number): the row groups
+  // that follow then never straddle a fill, i.e. always take the multi-piece DMA forms.  The consumers skip the same slots.
+  __device__ __forceinline__ void align4() {
+    while (g & 3u) {
+      ++g;
+      if ((g & (FILL - 1)) == 0) fill_end();
+    }
+  }
   // One UNIT = NR weight rows of P pieces each that a consumer wave reduces together.  Stream order inside a unit: groups
   // of G pieces, row after row - rows[0][0..G), rows[1][0..G), ..., rows[0][G..2G), ... - so that the consumer can start on
   // the first group while the rest is in flight and hand ring space back group by group (a unit of W2 is 56 pieces: four
   // waves each pinning a whole unit would need 14 fills of the 8-fill ring).
   template <int NR>
   __device__ __forceinline__ void unit(const bf16_t* const (&rp)[NR], int P) {
-    const int G = unit_group(P);
-    for (int p0 = 0; p0 < P; p0 += G) {
+    for (int p0 = 0, G; p0 < P; p0 += G) {
+      G = unit_group(P - p0);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const char* src = reinterpret_cast<const char*>(rp[r]) + (size_t)p0 * PIECE + lane * 16;
@@ -371,6 +382,7 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
         ld.kv_piece(L.ck + base + (size_t)slot * row_stride, MULTI && a.kv_coherent);
         ld.kv_piece(L.cv + base + (size_t)slot * row_stride, MULTI && a.kv_coherent);
       }
+      ld.align4();
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
@@ -492,10 +504,10 @@ struct Cons {
         for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(wv[r][i], xv[i], acc[r]);
     };
     // the unit arrives in groups of G pieces per row (Loader::unit): wait for a group, reduce it, hand its ring space back
-    const int G = unit_group(P);
     constexpr int S = (NR <= 2) ? 4 : 2;  // pieces per row whose LDS reads are issued together
     uint32_t gg = g0;                     // first ring piece of the current group
-    for (int p0 = 0; p0 < P; p0 += G, gg += NR * G) {
+    for (int p0 = 0, G; p0 < P; p0 += G, gg += NR * G) {
+      G = unit_group(P - p0);             // (the loader's rule: Loader::unit)
       need_fill(gg + NR * G - 1);
       if (G == 4) {
 #pragma unroll
@@ -1072,6 +1084,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         reduce_slot<R>(st, qf, kraw, vraw, valid);
       }
       g += 2 * p.n_att;
+      if (p.n_att) g = (g + 3u) & ~3u;  // (Loader::align4)
       cs.set_done(g);
       trace_ev(sh, c, l, 6, trc);
       wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
@@ -1531,11 +1544,10 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   using attn_core::DH;
   if (pr.D % 512 || pr.F % 512 || (pr.H * DH) % 512) return no("dim / hidden_dim / n_heads*128 not a multiple of 512");
   if (pr.D > 8192) return no("dim > 8192 (fused RMSNorm holds 4 pieces per thread)");
-  // Rows of 4k + 2 pieces (dim 5120 = Mistral-Nemo: 10) stream in 2-piece groups; measured at the Nemo dims the engine then
-  // runs its W1|W3 phase at 17.6 GB/s per CU instead of 28 and the whole step is SLOWER than the launch path (6.75 vs
-  // 5.06 ms, profiles/EXPERIMENTS.md).  Until that path is as fast, such models take the launch path; small dims (the
-  // parity tests' 512 / 1024) stay on the engine, where the group size does not matter.
-  if (pr.D > 2048 && ((pr.D >> 9) & 3) != 0) return no("dim > 2048 and not a multiple of 2048: launch path is faster (Nemo dims)");
+  // Large dims that are not a multiple of 2048 (Mistral-Nemo: 5120 = rows of 10 pieces, streamed 4 + 4 + 2, no holder waves):
+  // measured 5.62 ms per step on the engine against 5.00 ms on the launch path (same box; 7.96 ms before the group rework,
+  // profiles/EXPERIMENTS.md) - such models take the launch path.  Small dims (the parity tests) stay on the engine.
+  if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
   if (pr.V % 2) return no("odd vocab");
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch

@@ -98,6 +98,10 @@ SHAPES = {
                                vocab_size=1000, sliding_window=48, num_experts=8, num_experts_per_tok=2),
     "moe_4_experts_mha": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=8, n_kv_heads=8, norm_eps=1e-5,
                               vocab_size=514, sliding_window=None, num_experts=4, num_experts_per_tok=2),
+    # rows whose piece count is not a multiple of 4: dim 3072 = 6 pieces (streamed as 4 + 2), hidden 1536 = 3 (2 + 1) - the
+    # Mistral-Nemo case (dim 5120 = 4 + 4 + 2) in small; 6 kv heads x 32 splits leave a quarter of the CUs without attention work
+    "rows_of_6_and_3_pieces": dict(dim=3072, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=24, n_kv_heads=6, norm_eps=1e-5,
+                                   vocab_size=768, sliding_window=64),
     # HOLDER WAVES at a size the whole suite can afford: they need dim % 2048 == 0 and >= 11 W1|W3 units per CU
     # (decode_engine.hip holder_units): hidden_dim 5632 = 11 units x 256 CUs exactly
     "holders_mid_size": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=5632, n_heads=16, n_kv_heads=4, norm_eps=1e-5,
@@ -192,6 +196,8 @@ def test_engine_bit_equal_launch_path(name):
     W = p["sliding_window"] if isinstance(p["sliding_window"], int) else 10 ** 9
     prompt_len = 40 if W < 100 else 300  # 40 + steps crosses the 48-slot ring; 300 leaves later splits empty in a 1200 ring
     steps = 12
+    if name == "rows_of_6_and_3_pieces":
+        prompt_len = 57  # + 12 steps crosses the 64-slot ring
     if name == "two_launches_34_layers":
         prompt_len = 33  # + 12 steps crosses the 40-slot ring
     if name == "ring_longer_than_lds":
