@@ -239,12 +239,6 @@ typedef struct mi_batch {
   int64_t* hist_token;          /* dev [hist_len, B] or NULL */
   float* hist_logprob;          /* dev [hist_len, B] or NULL */
   int32_t hist_len;
-  /* Consecutive decode steps in ONE call (0 / 1: one).  Needs the fused sample with input_ids == greedy_token: step i + 1
-   * consumes step i's sample.  On the persistent engine (<= 32 local layers) all of them run in ONE launch: the sample
-   * reaches the next step through a granule inside the kernel, the weight stream never stops between two tokens and there
-   * is no launch ramp or empty ring per token; every step still commits its position, its K/V rows, its history row and
-   * overwrites `logits` (the caller sees the last step's).  Elsewhere the library enqueues the steps one after another. */
-  int32_t greedy_steps;
 } mi_batch_t;
 
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);

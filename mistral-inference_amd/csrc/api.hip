@@ -514,10 +514,6 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     return fail(MI_ERR_ARG, "mi_forward: greedy_token needs the DECODE branch, logits and greedy_logprob");
   if (want_greedy && bt->hist_len > 0 && (!bt->hist_token || !bt->hist_logprob))
     return fail(MI_ERR_ARG, "mi_forward: hist_len > 0 without history buffers");
-  const int steps = bt->greedy_steps > 1 ? bt->greedy_steps : 1;
-  if (steps > 1 && !(want_greedy && embed && (const void*)bt->input_ids == (const void*)bt->greedy_token))
-    return fail(MI_ERR_ARG, "mi_forward: greedy_steps > 1 needs the fused sample with input_ids aliasing greedy_token");
-  if (steps > 4096) return fail(MI_ERR_ARG, "mi_forward: greedy_steps > 4096");
 
   // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch, which also does
   // the step's bookkeeping (position, embedding row, greedy sample): nothing else is enqueued for the token
@@ -536,7 +532,6 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     }
     pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
     pr.E = m->num_experts; pr.top_k = m->top_k;
-    pr.n_steps = (steps > 1 && m->n_layers <= ENG_MAXL) ? steps : 1;  // all of them in ONE launch (the sample feeds the next step in-kernel)
     bool dense_ok = true;
     for (int l = 0; l < m->n_layers; ++l)
       dense_ok = dense_ok && (m->num_experts ? (m->layers[l].gate && m->layers[l].expert_w_dev)
@@ -544,26 +539,14 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
       bool declined = false;
       MI_TRY(hip_rc(launch_decode_engine(pr, s, &declined), "decode engine"));
-      if (!declined && pr.n_steps == steps) {
+      if (!declined) {
         if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
-        return MI_OK;
-      }
-      if (!declined && steps > 1) {  // (more layers than one launch takes) the first step is enqueued: the others follow singly
-        mi_batch_t one = *bt;
-        one.greedy_steps = 1;
-        for (int i = 1; i < steps; ++i) MI_TRY(mi_forward(m, &one, stream));
         return MI_OK;
       }
       snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail());  // informational
     }
   }
 
-  if (steps > 1) {  // launch path (MoE beyond top-2, batch > 1, shapes the engine does not take): step by step, same stream
-    mi_batch_t one = *bt;
-    one.greedy_steps = 1;
-    for (int i = 0; i < steps; ++i) MI_TRY(mi_forward(m, &one, stream));
-    return MI_OK;
-  }
   if (branch == MI_BRANCH_DECODE && embed) {
     MI_TRY(hip_rc(launch_decode_prep_embedding(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, h,
                                                m->tok_embeddings, bt->input_ids, D, m->vocab_size, engine_ctrl, s),

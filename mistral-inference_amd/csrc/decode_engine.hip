@@ -91,9 +91,7 @@ enum : int {
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
   C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
   C_EXPERT = 20,    // MoE: ((layer + 1) << 16) | expert A | expert B << 8 (ascending ids) once the router has decided (consumers -> loader)
-  C_RLOGIT = 24,    // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
-  C_TOKEN = 40,     // multi-step launches: the token sampled by the previous step (consumer wave 0 -> the other waves)
-  C_TOKSTEP = 41    // ... and the step it is the input of
+  C_RLOGIT = 24     // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
 };
 // global control words (workspace): [0] step epoch, [1] sticky status, [2] abort broadcast, [3] bad token id, [4] engine
 // launches completed, [5] decode steps committed (index into the greedy history ring), [6] workgroup arrivals
@@ -185,10 +183,7 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
 }
 
 // pieces per group of a unit's interleaved stream (loader and consumers must agree)
-// A row of P pieces is streamed in groups of 4 pieces as long as 4 are left, then one group of 2 and / or 1 (dim 5120 = 10
-// pieces: 4 + 4 + 2).  Uniform 2-piece groups for such rows made the LOADER the bottleneck: its cost is per group (one address
-// computation, ring-slot and fill bookkeeping, ~200 cycles), not per piece - 17 GB/s per CU at the Mistral-Nemo dims.
-__device__ __forceinline__ int unit_group(int left) { return left >= 4 ? 4 : (left >= 2 ? 2 : 1); }
+__device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P & 1) == 0 ? 2 : 1); }
 
 // HOLDER waves: the last holder_units() W1|W3 units of a CU's slab never pass through the ring.  A holder wave fetches
 // its unit (4 rows x D bf16 = 32 KiB at D = 4096) straight into 128 of its VGPRs while the attention block of the layer
@@ -197,7 +192,7 @@ __device__ __forceinline__ int unit_group(int left) { return left >= 4 ? 4 : (le
 constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
 __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
   const int P = a.D >> 9;
-  return (NHOLD > 0 && a.holders && a.E == 0 && (P & 3) == 0 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
+  return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ loader wave
@@ -268,21 +263,7 @@ struct Loader {
     ++g;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
-  // K/V ring slices.  Inside a MULTI-STEP launch the row written at step t (by another workgroup, possibly on another XCD)
-  // is read at step t + 1 without a kernel boundary in between: the writer stores it write-through (sc1) and the read
-  // must not be served from a stale line of this XCD's L2 either - sc1 on the DMA, the granule protocol's pairing
-  // (MI355X_MICROARCH.md "Valid forms": sc1 stores AND sc1 loads).  Single-step launches keep the non-temporal policy.
-  __device__ __forceinline__ void kv_piece(const void* src_lane, bool coherent) {
-    if ((g & (FILL - 1)) == 0) fill_begin();
-    lchar* dst = slot_of(g);
-    if (coherent)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, 0, 16 /* sc1 */);
-    else
-      dma<0>(src_lane, dst);
-    ++g;
-    if ((g & (FILL - 1)) == 0) fill_end();
-  }
-  // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: all inside one fill): one address, immediate offsets
+  // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: g % 4 == 0): one address, immediate offsets
   __device__ __forceinline__ void piece4(const void* src_lane) {
     if ((g & (FILL - 1)) == 0) fill_begin();
     lchar* dst = slot_of(g);
@@ -293,42 +274,19 @@ struct Loader {
     g += 4;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
-  // 2 consecutive pieces (g even): the group size of rows whose piece count is 2 mod 4 (dim 5120 = 10 pieces).  Issued one
-  // by one such rows cost ~180 cycles per piece - the loader becomes the bottleneck (13 GB/s per CU at the Nemo dims).
-  __device__ __forceinline__ void piece2(const void* src_lane) {
-    if ((g & (FILL - 1)) == 0) fill_begin();
-    lchar* dst = slot_of(g);
-    dma<0>(src_lane, dst);
-    dma<PIECE>(src_lane, dst);
-    g += 2;
-    if ((g & (FILL - 1)) == 0) fill_end();
-  }
-  // Skip ring slots up to the next multiple of 4 pieces (after the K/V slices, whose count is any even number): the row groups
-  // that follow then never straddle a fill, i.e. always take the multi-piece DMA forms.  The consumers skip the same slots.
-  __device__ __forceinline__ void align4() {
-    while (g & 3u) {
-      ++g;
-      if ((g & (FILL - 1)) == 0) fill_end();
-    }
-  }
   // One UNIT = NR weight rows of P pieces each that a consumer wave reduces together.  Stream order inside a unit: groups
   // of G pieces, row after row - rows[0][0..G), rows[1][0..G), ..., rows[0][G..2G), ... - so that the consumer can start on
   // the first group while the rest is in flight and hand ring space back group by group (a unit of W2 is 56 pieces: four
   // waves each pinning a whole unit would need 14 fills of the 8-fill ring).
   template <int NR>
   __device__ __forceinline__ void unit(const bf16_t* const (&rp)[NR], int P) {
-    for (int p0 = 0, G; p0 < P; p0 += G) {
-      G = unit_group(P - p0);
+    const int G = unit_group(P);
+    for (int p0 = 0; p0 < P; p0 += G) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const char* src = reinterpret_cast<const char*>(rp[r]) + (size_t)p0 * PIECE + lane * 16;
-        // (a group may start at any piece index - phases with different group sizes follow each other, e.g. dim 5120:
-        // 10-piece rows, then 8-piece Wo rows - as long as it stays inside one 16-piece fill: contiguous ring slots,
-        // and the fill bookkeeping sees every fill begin and end)
-        if (G == 4 && (g & (FILL - 1)) <= FILL - 4) {
+        if (G == 4 && (g & 3) == 0) {
           piece4(src);
-        } else if (G == 2 && (g & (FILL - 1)) <= FILL - 2) {
-          piece2(src);
         } else {
           for (int i = 0; i < G; ++i) piece(src + (size_t)i * PIECE);
         }
@@ -348,26 +306,17 @@ struct Loader {
   }
 };
 
-// stage id of (step t, layer l) for the monotonic LDS progress words (C_LSTAGE, C_XREADY, C_EXPERT): unique within a launch
-__device__ __forceinline__ uint32_t stage_id(int t, int l) { return (uint32_t)(t * 64 + l + 1); }
-
-template <bool MOE, bool MULTI>
-__device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos0, int seq) {
-  const int n_steps = MULTI ? a.n_steps : 1;  // (a compile-time 1 in the single-step instantiation: no loop state to carry)
+template <bool MOE>
+__device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
   Loader ld{sh, lane, a.ring_fills, a.thin, a.depth};
   __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
   const int PD = a.D >> 9;
-  // MULTI-STEP launches (a.n_steps > 1, GreedySession): the loader's program does not depend on the sampled tokens at all -
-  // weights and the K/V slots of position pos0 + t - so it simply continues with step t + 1's first layer while the
-  // consumers are still busy with step t's LM head and sample: no launch ramp, no cold ring between two tokens.
-  for (int t = 0; t < n_steps; ++t) {
-  const int pos = pos0 + t;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     if (sh.ctl[C_ABORT]) break;  // the consumers have given up (residency gate / a timed-out wait): nothing left to feed
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
-    const bool tr = lane == 0 && t == 0;
+    const bool tr = lane == 0;
     trace_ev(sh, c, l, TR_CONS + 0, tr);
     ld.pairs(L.wq, p.q0, p.q1, a.D);
     ld.pairs(L.wk, p.k0, p.k1, a.D);
@@ -379,15 +328,14 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       const size_t base = ((size_t)seq * L.W) * row_stride + (size_t)kv_real * DH + (lane & 15) * 8;
       for (int j = 0; j < p.n_att; ++j) {
         const int slot = min(p.s_begin + 4 * j + (lane >> 4), L.W - 1);
-        ld.kv_piece(L.ck + base + (size_t)slot * row_stride, MULTI && a.kv_coherent);
-        ld.kv_piece(L.cv + base + (size_t)slot * row_stride, MULTI && a.kv_coherent);
+        ld.piece(L.ck + base + (size_t)slot * row_stride);
+        ld.piece(L.cv + base + (size_t)slot * row_stride);
       }
-      ld.align4();
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
-    if (NHOLD) sh.ctl[C_LSTAGE] = stage_id(t, l);  // the latency-critical small phases are issued: holders may fetch
+    if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
     if constexpr (!MOE) {
       const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
       for (int j = p.f0; j < f_ring; ++j) {
@@ -405,7 +353,7 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       ld.flush();
       ld.g = (ld.g + FILL - 1) & ~(uint32_t)(FILL - 1);
       uint32_t word = 0, spins = 0;
-      while (((word = sh.ctl[C_EXPERT]) >> 16) != stage_id(t, l))
+      while (((word = sh.ctl[C_EXPERT]) >> 16) != (uint32_t)(l + 1))
         if (!spin_ok(sh, spins, 0x100)) break;
       const void* const* tab = reinterpret_cast<const void* const*>(L.w2);  // device table [E][3] of (w1, w2, w3)
       const int ex[2] = {__builtin_amdgcn_readfirstlane((int)(word & 0xffu)), __builtin_amdgcn_readfirstlane((int)((word >> 8) & 0xffu))};
@@ -429,7 +377,6 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     slab(a.V / 2, c, a.NB, v0, v1);
     ld.pairs(a.output, v0, v1, a.D);
   }
-  }  // steps
   (void)PD;
   ld.flush();
 }
@@ -504,10 +451,10 @@ struct Cons {
         for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(wv[r][i], xv[i], acc[r]);
     };
     // the unit arrives in groups of G pieces per row (Loader::unit): wait for a group, reduce it, hand its ring space back
+    const int G = unit_group(P);
     constexpr int S = (NR <= 2) ? 4 : 2;  // pieces per row whose LDS reads are issued together
     uint32_t gg = g0;                     // first ring piece of the current group
-    for (int p0 = 0, G; p0 < P; p0 += G, gg += NR * G) {
-      G = unit_group(P - p0);             // (the loader's rule: Loader::unit)
+    for (int p0 = 0; p0 < P; p0 += G, gg += NR * G) {
       need_fill(gg + NR * G - 1);
       if (G == 4) {
 #pragma unroll
@@ -735,7 +682,7 @@ struct Cons {
 //            expert B rows with hid B; r = bf16(bf16(0 + bf16(wA yA)) + bf16(wB yB)); h = bf16(h1 + r)  (moe.py:28-32 +
 //            transformer_layers.py:168, the order of the launch path's moe_w2_kernel)
 __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons& cs, const EngLayer& L, const LayerPlan& p, int l,
-                                        uint32_t stage, int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
+                                        int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
                                         const u32x4 (&xr)[4], bool trc) {
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -819,7 +766,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
     wA = swap ? w1 : w0;
     wB = swap ? w0 : w1;
   }
-  if (w == 0 && lane == 0) sh.ctl[C_EXPERT] = (stage << 16) | (uint32_t)eA | ((uint32_t)eB << 8);
+  if (w == 0 && lane == 0) sh.ctl[C_EXPERT] = ((uint32_t)(l + 1) << 16) | (uint32_t)eA | ((uint32_t)eB << 8);
   trace_ev(sh, c, l, 13, trc);
   // ---- W1|W3 of the two experts (the loader restarts on a fill boundary behind the router edge)
   g = (g + FILL - 1) & ~(uint32_t)(FILL - 1);
@@ -877,10 +824,9 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
   }
 }
 
-template <int R, bool MOE, bool MULTI>
-__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos0, int seq, uint32_t epoch0,
+template <int R, bool MOE>
+__device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch,
                                              uint32_t arrive_target) {
-  const int n_steps = MULTI ? a.n_steps : 1;
   Cons cs{sh, w, lane};
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -892,6 +838,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   long greedy_token = 0;     // the fused greedy sample (workgroup 0, wave 0, lane 0)
   float greedy_logprob = 0.f;
   bool greedy_valid = false;
+  auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
+
   // attention scratch inside the activation region (free between the q|k|v rows and the Wo gather)
   lu32* q_lds = xs32;                                            // R * 64 words
   lu32* kn_lds = xs32 + R * 64;                                  // 64 words
@@ -901,19 +849,11 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   lf32* sm_acc = sm_l + 4 * R;                                   // 4 R DH
   lu32* cmb_lds = reinterpret_cast<lu32*>(sm_acc + 4 * R * DH);  // split merge staging: 3 * n_splits * ne words
 
-  // One iteration = one decode step.  n_steps > 1 (GreedySession): the sample of step t is the input of step t + 1 INSIDE
-  // the launch - workgroup 0 publishes it as a granule when it commits the step, every workgroup picks it up at the top of
-  // the next one - so between two tokens there is neither a kernel boundary nor an empty ring.
-  for (int t = 0; t < n_steps; ++t) {
-  const int pos = pos0 + t;
-  const uint32_t epoch = (epoch0 + (uint32_t)t) & 0xfffffu;
-  auto tag_of = [&](int layer, int edge) { return (epoch << 12) | (uint32_t)((a.seq_base + layer) * 8 + edge + 1); };
-  greedy_valid = false;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
-    const bool trc = (w == 0) && (lane == 0) && (t == 0);
+    const bool trc = (w == 0) && (lane == 0);
     trace_ev(sh, c, l, 0, trc);
 
     // ================================================================ attention_norm + q|k|v + RoPE + ring write
@@ -924,28 +864,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       // (transformer.py:193), or h as the previous stage / previous launch left it
       const bf16_t* hin = a.h;
       if (a.emb) {
-        long id;
-        if (t == 0) {
-          id = (long)a.ids[0];
-        } else {  // the previous step's sample: wave 0 waits for workgroup 0's granule, the other waves for wave 0
-          if (w == 0) {
-            const uint32_t want = (((epoch0 + (uint32_t)t - 1u) & 0xfffffu) << 12) | 0xfffu;
-            unsigned long long x;
-            uint32_t spins = 0;
-            for (;;) {
-              x = __hip_atomic_load(G + a.g_tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((uint32_t)(x >> 32) == want) break;
-              if (!spin_ok(sh, spins, 0x400)) break;
-            }
-            sh.ctl[C_TOKEN] = (uint32_t)x;
-            sh.ctl[C_TOKSTEP] = (uint32_t)t;
-          } else {
-            uint32_t spins = 0;
-            while (sh.ctl[C_TOKSTEP] != (uint32_t)t)
-              if (!spin_ok(sh, spins, 0x400)) break;
-          }
-          id = (long)sh.ctl[C_TOKEN];
-        }
+        long id = (long)a.ids[0];
         if (id < 0 || id >= a.V) {  // the reference's nn.Embedding raises IndexError: flagged for the host, row clamped
           if (c == 0 && w == 0 && lane == 0) atomicMax((uint32_t*)a.ctrl + G_BADID, 1u);
           id = id < 0 ? 0 : a.V - 1;
@@ -964,7 +883,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 1, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 2, trc);
-    if (l == 0 && t == 0) {
+    if (l == 0) {
       // RESIDENCY GATE.  Every hand-off below assumes that all NB workgroups run at the same time (one per CU).  Nothing
       // has been written yet - no ring row, no granule - so a launch that finds a workgroup missing (a CU masked or busy
       // with another process) gives up here WITHOUT side effects: the step can be re-run on the launch path from
@@ -1017,10 +936,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           if (kind > 0) {  // cache.py:83-92
             const size_t slot = (size_t)seq * L.W + p.cur_slot;
             bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + r0;
-            if (MULTI)  // read again by another workgroup within this launch: write-through (Loader::kv_piece)
-              __hip_atomic_store(reinterpret_cast<uint32_t*>(ring), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-              *reinterpret_cast<uint32_t*>(ring) = packed;
+            *reinterpret_cast<uint32_t*>(ring) = packed;
           }
           const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
           cs.publish(G + a.g_qkv + gi, tag_of(l, 1), packed);
@@ -1084,7 +1000,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         reduce_slot<R>(st, qf, kraw, vraw, valid);
       }
       g += 2 * p.n_att;
-      if (p.n_att) g = (g + 3u) & ~3u;  // (Loader::align4)
       cs.set_done(g);
       trace_ev(sh, c, l, 6, trc);
       wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
@@ -1184,7 +1099,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     trace_ev(sh, c, l, 13, trc);
     if constexpr (!MOE) {
       const int n_hold = holder_units(a, p.f1 - p.f0);
-      if (n_hold && w == 0) sh.ctl[C_XREADY] = stage_id(t, l);  // (rmsnorm_store ends with a barrier of the consumer waves)
+      if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
       {
         const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
         for (int k = w; k < n_u; k += NCONS) {
@@ -1237,7 +1152,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         cs.set_done(g);
       }
     } else {
-      moe_ffn(a, sh, cs, L, p, l, stage_id(t, l), c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
+      moe_ffn(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
     }
     trace_ev(sh, c, l, 16, trc);
     cs.cbar();
@@ -1272,7 +1187,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       }
     }
     g += (uint32_t)(2 * (v1 - v0)) * PD;
-    cs.set_done(t == n_steps - 1 ? 0xffffffffu : g);  // (the ring is done with only after the LAST step)
+    cs.set_done(0xffffffffu);
     if (greedy) {
       // workgroup partial (max, FIRST index of the max, sum exp(x - max)) -> three granules -> workgroup 0 reduces them all.
       // Ties: the lower index wins at every level (torch.argmax returns the first maximal element).
@@ -1345,7 +1260,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       }
     }
   } else {
-    cs.set_done(t == n_steps - 1 ? 0xffffffffu : g);
+    cs.set_done(0xffffffffu);
   }
 
   // ================================================================ commit (workgroup 0, one lane): the step becomes visible
@@ -1374,25 +1289,16 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     sh.ctrl[G_STEPS] = step + 1;
     sh.ctrl[G_ARRIVE] = 0;  // every workgroup of this launch has been counted and the next launch has not begun: no wrap
     __hip_atomic_store(sh.ctrl + G_EPOCH, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t + 1 < n_steps)  // the next step of this launch starts from the sample (every workgroup waits for this granule)
-      cs.publish(G + a.g_tok, (epoch << 12) | 0xfffu, (uint32_t)greedy_token);
   }
-  if (sh.ctl[C_ABORT]) break;
-  }  // steps
 }
 
 // ------------------------------------------------------------------------------------------------ holder waves
 // Holder hi owns W1|W3 unit f1 - n_hold + hi of every layer (rows w1[2j], w3[2j], w1[2j+1], w3[2j+1]).  Same arithmetic
 // as Cons::unit_dot<4>: per row, pieces in ascending order, four dot2_bf16 per piece, then wave_sum - bit-identical.
-template <bool MULTI>
-__device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos0, uint32_t epoch0) {
-  const int n_steps = MULTI ? a.n_steps : 1;
+__device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, uint32_t epoch) {
   gu64* G = (gu64*)a.gran;
   const int PD = a.D >> 9;
   const lchar* xl = sh.xs + lane * 16;
-  for (int t = 0; t < n_steps; ++t) {
-  const int pos = pos0 + t;
-  const uint32_t epoch = (epoch0 + (uint32_t)t) & 0xfffffu;
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     LayerPlan p;
@@ -1401,7 +1307,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     if (hi >= n_hold) continue;
     const int j = p.f1 - n_hold + hi;
     uint32_t spins = 0;
-    while (sh.ctl[C_LSTAGE] < stage_id(t, l))  // not before the layer's q|k|v, K/V and Wo streams are on their way
+    while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
       if (!spin_ok(sh, spins, 0x600)) return;
     const size_t r0 = (size_t)(2 * j) * a.D + lane * 8;
     const bf16_t* rows[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r0 + a.D, L.w3 + r0 + a.D};
@@ -1423,7 +1329,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       }
     }
     spins = 0;
-    while (sh.ctl[C_XREADY] < stage_id(t, l))
+    while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
       if (!spin_ok(sh, spins, 0x600)) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1449,13 +1355,11 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  }  // steps
 }
 
 // MOE is a separate instantiation: the dense kernel must not pay registers for the router / two-expert code (it sits at
 // 247 of 256 VGPRs and spilled with the MoE path compiled in)
-// ... and MULTI (several decode steps per launch) another one: its step loop costs the single-step kernel registers too.
-template <int R, bool MOE, bool MULTI>
+template <int R, bool MOE>
 __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int c = blockIdx.x;
@@ -1482,8 +1386,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int pos = (int)a.kv_seqlens[0];
   const int seq = 0;
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
-  if (w == NCONS) run_loader<MOE, MULTI>(a, sh, c, lane, pos, seq);
-  else if (w > NCONS) run_holder<MULTI>(a, sh, c, w - NCONS - 1, lane, pos, epoch);
+  if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
+  else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
   else {
     // residency census: every workgroup counts itself in; consumers check the total before their first side effect
     uint32_t arrive_target = 0;
@@ -1495,7 +1399,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
       // test hook: wait for one workgroup more than exist - the gate fails exactly as it would with one missing
       if (__hip_atomic_load(sh.ctrl + G_SABOTAGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) arrive_target += 1u;
     }
-    run_consumer<R, MOE, MULTI>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
+    run_consumer<R, MOE>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
   }
   // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
   if (c == 0 && threadIdx.x == 0 && !sh.ctl[C_ABORT])
@@ -1507,7 +1411,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 struct GranLayout {
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, g_tok, total;
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, total;
 };
 constexpr int AMAX_MAX_NB = 1024;  // workgroups the greedy-sampling edge is sized for (decode_engine_applicable: NB <= 1024)
 GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
@@ -1523,9 +1427,7 @@ GranLayout gran_layout(int D, int H, int Hkv, int F, int max_splits) {
   g.g_hid2 = off; off += F / 2;  // MoE: hid of the second expert
   g.g_part = off; off += (uint32_t)((size_t)Hs * max_splits * R * (DH + 2));
   g.g_amax = off; off += 4 * AMAX_MAX_NB;  // (max logit, argmax, sum exp, pad) per workgroup
-  g.g_tok = off;  off += 8;                // multi-step launches: the sample that feeds the next step
   g.total = off;
-
   return g;
 }
 }  // namespace
@@ -1544,9 +1446,9 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   using attn_core::DH;
   if (pr.D % 512 || pr.F % 512 || (pr.H * DH) % 512) return no("dim / hidden_dim / n_heads*128 not a multiple of 512");
   if (pr.D > 8192) return no("dim > 8192 (fused RMSNorm holds 4 pieces per thread)");
-  // Large dims that are not a multiple of 2048 (Mistral-Nemo: 5120 = rows of 10 pieces, streamed 4 + 4 + 2, no holder waves):
-  // measured 5.62 ms per step on the engine against 5.00 ms on the launch path (same box; 7.96 ms before the group rework,
-  // profiles/EXPERIMENTS.md) - such models take the launch path.  Small dims (the parity tests) stay on the engine.
+  // Large dims that are not a multiple of 2048 (Mistral-Nemo: 5120 = rows of 10 pieces, streamed in 2-piece groups, no holder
+  // waves): 7.6-8.0 ms per step on the engine against 5.0 ms on the launch path (profiles/EXPERIMENTS.md) - such models
+  // take the launch path.  Small dims (the parity tests) stay on the engine.
   if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
   if (pr.V % 2) return no("odd vocab");
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
@@ -1682,15 +1584,7 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   a.gran = (uint64_t*)pr.granules; a.ctrl = pr.ctrl;
   const GranLayout gl = gran_layout(pr.D, pr.H, pr.Hkv, pr.F, 32);
   a.g_h = gl.g_h; a.g_qkv = gl.g_qkv; a.g_att = gl.g_att; a.g_h1 = gl.g_h1; a.g_hid = gl.g_hid; a.g_part = gl.g_part;
-  a.g_amax = gl.g_amax; a.g_hid2 = gl.g_hid2; a.g_tok = gl.g_tok; a.E = pr.E;
-  {
-    static int kvc = -1;  // MI_ENGINE_KV_SC1=0: DIAGNOSTIC ONLY - non-temporal K/V reads inside multi-step launches are not coherent
-    if (kvc < 0) {
-      const char* e = getenv("MI_ENGINE_KV_SC1");
-      kvc = e ? (atoi(e) != 0) : 1;
-    }
-    a.kv_coherent = kvc;
-  }
+  a.g_amax = gl.g_amax; a.g_hid2 = gl.g_hid2; a.E = pr.E;
   if ((size_t)gl.total * 8 > pr.granule_bytes || !pr.kv_seqlens) return hipErrorInvalidValue;
 
   for (int l0 = 0; l0 < pr.n_layers; l0 += ENG_MAXL) {
@@ -1704,9 +1598,6 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
     a.commit = last;
     a.head = last && pr.logits != nullptr;
     const bool greedy = a.head && pr.greedy_tok && pr.greedy_lp;
-    // several decode steps in ONE launch: only when the whole step is this launch and it produces its own next input
-    a.n_steps = (pr.n_steps > 1 && greedy && l0 == 0 && last && a.emb && pr.ids == pr.greedy_tok) ? pr.n_steps : 1;
-    if (pr.n_steps > 1 && a.n_steps == 1) return hipErrorInvalidValue;  // (mi_forward loops single steps in that case)
     a.greedy_tok = greedy ? pr.greedy_tok : nullptr;
     a.greedy_lp = greedy ? pr.greedy_lp : nullptr;
     a.hist_tok = greedy && pr.hist_lp ? pr.hist_tok : nullptr;
@@ -1728,21 +1619,17 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
       L.chunk = attn_core::split_chunk(L.W, L.n_splits);
     }
     const void* fn = nullptr;
-    const bool moe = pr.E > 0, multi = a.n_steps > 1;
-#define ENG_PICK(RR)                                                                                                   \
-  (moe ? (multi ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
-       : (multi ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
+    const bool moe = pr.E > 0;
     switch (a.R) {
-      case 1: fn = ENG_PICK(1); break;
-      case 2: fn = ENG_PICK(2); break;
-      case 4: fn = ENG_PICK(4); break;
-      case 8: fn = ENG_PICK(8); break;
+      case 1: fn = moe ? (const void*)decode_engine_kernel<1, true> : (const void*)decode_engine_kernel<1, false>; break;
+      case 2: fn = moe ? (const void*)decode_engine_kernel<2, true> : (const void*)decode_engine_kernel<2, false>; break;
+      case 4: fn = moe ? (const void*)decode_engine_kernel<4, true> : (const void*)decode_engine_kernel<4, false>; break;
+      case 8: fn = moe ? (const void*)decode_engine_kernel<8, true> : (const void*)decode_engine_kernel<8, false>; break;
       default: return hipErrorInvalidValue;
     }
-#undef ENG_PICK
     // 160 KiB of dynamic LDS is an opt-in per function AND per device
-    static bool attr_set[64][36] = {};
-    const int slot = a.R + (moe ? 9 : 0) + (multi ? 18 : 0);
+    static bool attr_set[64][18] = {};
+    const int slot = a.R + (moe ? 9 : 0);
     if (dev < 0 || dev >= 64 || !attr_set[dev][slot]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;

@@ -217,9 +217,7 @@ struct EngArgs {
   float* logits;
   uint64_t* gran;         // granule regions
   uint32_t* ctrl;         // [0] epoch, [1] sticky status, [2] per-step abort
-  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax, g_tok;
-  int kv_coherent;        // multi-step launches: K/V ring slices are read with sc1 (1; 0 is a diagnostic switch)
-  int n_steps;            // decode steps run by this launch (> 1: the sample of one is the input of the next, in-kernel)
+  uint32_t g_h, g_qkv, g_att, g_h1, g_hid, g_hid2, g_part, g_amax;
   int E;                  // experts (0: dense).  MoE layers: EngLayer.w1 = gate [E, D], .w2 = device table [E][3] of (w1, w2, w3)
   unsigned long long* trace;  // optional timeline buffer (debug)
   EngLayer L[ENG_MAXL];
@@ -228,7 +226,6 @@ struct EngArgs {
 struct EngProblem {
   int D, H, Hkv, F, V, n_layers, NB;
   int E, top_k;              // MoE (0, 0: dense)
-  int n_steps;               // consecutive greedy decode steps wanted (1 unless ids aliases greedy_tok)
   float eps;
   const mi_layer_t* layers;  // host
   void* const* cache_k;      // host [n_layers]

@@ -52,7 +52,6 @@ class MiBatch(C.Structure):
         ("cache_sizes", C.POINTER(C.c_int32)), ("h", _vp), ("logits", _vp), ("workspace", _vp),
         ("workspace_bytes", C.c_size_t),
         ("greedy_token", _vp), ("greedy_logprob", _vp), ("hist_token", _vp), ("hist_logprob", _vp), ("hist_len", C.c_int32),
-        ("greedy_steps", C.c_int32),
     ]
 
 

@@ -154,7 +154,7 @@ class HipStackBackend:
     # -- per forward -------------------------------------------------------------------------------
     def run_stack(self, model: "Transformer", h: torch.Tensor, input_ids: Optional[torch.Tensor],
                   meta: BatchMetadata, cache: Optional[BufferCache], logits: Optional[torch.Tensor],
-                  greedy: Optional["GreedyBuffers"] = None, greedy_steps: int = 1) -> None:
+                  greedy: Optional["GreedyBuffers"] = None) -> None:
         m = self.plan(model)
         T, B = h.shape[0], len(meta.seqlens)
         bt = _hip.MiBatch()
@@ -176,7 +176,6 @@ class HipStackBackend:
             bt.greedy_token, bt.greedy_logprob = _hip.dev_ptr(greedy.tok, torch.long), _hip.dev_ptr(greedy.lp, torch.float32)
             bt.hist_token, bt.hist_logprob = _hip.dev_ptr(greedy.hist_tok, torch.long), _hip.dev_ptr(greedy.hist_lp, torch.float32)
             bt.hist_len = greedy.hist_tok.shape[0]
-            bt.greedy_steps = greedy_steps
         wsb = self._get_workspace(model, m, T, B, max_w)
         bt.workspace, bt.workspace_bytes = wsb.data_ptr(), wsb.numel()
         _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
@@ -611,12 +610,6 @@ class GreedySession:
     # decode steps per hipGraph launch.  Measured (profiles/EXPERIMENTS.md): 8 steps per graph close the ~9 us gap between two
     # graph launches, and the kernels then run ~10 us longer each (their ramp-up is no longer hidden in the gap): no gain -> 1
     GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "1"))
-    # decode steps per ENGINE launch (mi_batch_t.greedy_steps): the kernel carries the sample from one step to the next itself,
-    # the weight stream runs on across the token boundary (1: one launch per token, replayed from a hipGraph)
-    # MEASURED (profiles/EXPERIMENTS.md): no faster than one launch per token with non-temporal K/V reads (2.79-2.80 vs
-    # 2.78-2.82 ms), and 60-170 us per step SLOWER with the sc1 K/V reads that coherence inside one launch requires (the
-    # K/V row written at step t is read at step t + 1 by another XCD without a kernel boundary in between) -> default 1.
-    LAUNCH_STEPS = int(os.environ.get("MI_LAUNCH_STEPS", "1"))
 
     def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
         assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"
@@ -635,18 +628,16 @@ class GreedySession:
         self._use_graph = graph and dev.type == "cuda"
         self._graphs: dict = {}            # steps per graph -> captured hipGraph
         self._warm = False
-        self._engine = False               # the persistent engine takes this model's decode steps (known after the first one)
         self._base: Optional[int] = None   # value of the workspace's step counter when this session began
         self._pending = 0                  # steps enqueued and not yet collected
         self._n_collected = 0
 
     # -- one step, enqueued launch by launch
-    def _step_eager(self, steps: int = 1) -> None:
-        """`steps` consecutive decode steps in ONE native call (mi_batch_t.greedy_steps): on the persistent engine one launch."""
+    def _step_eager(self) -> None:
         m, cache = self.model, self.cache
         meta = cache.batch_metadata([1] * self.B)
         assert meta.branch == _hip.BRANCH_DECODE
-        m._backend.run_stack(m, self.h, self.buf.tok, meta, cache, self.logits, greedy=self.buf, greedy_steps=steps)
+        m._backend.run_stack(m, self.h, self.buf.tok, meta, cache, self.logits, greedy=self.buf)
 
     def _steps_now(self) -> int:
         return _hip.decode_engine_status(self.model._backend._workspace)["steps"]
@@ -656,12 +647,9 @@ class GreedySession:
         if not self._warm:  # first step eagerly: sizes the workspace, runs the engine's one-time residency census
             if m._backend._workspace is None:
                 m._backend._get_workspace(m, m._backend.plan(m), 1, self.B, max(cache.cache_sizes))
-            before = _hip.decode_engine_status(m._backend._workspace)
-            self._base = before["steps"]
+            self._base = self._steps_now()
             self._step_eager()
             self._warm = True
-            # did the persistent engine take the step?  Then several steps go into one launch from here on (no graph needed)
-            self._engine = _hip.decode_engine_status(m._backend._workspace)["engine_launches"] > before["engine_launches"]
             return
         if self._use_graph:
             g = self._captured(1)
@@ -698,14 +686,6 @@ class GreedySession:
         left = n
         while left > 0:
             k = 1
-            if self._warm and self._engine and self.LAUNCH_STEPS > 1 and left > 1:
-                # persistent engine: up to LAUNCH_STEPS tokens per launch - the sample feeds the next step inside the kernel
-                k = min(left, self.LAUNCH_STEPS)
-                self._step_eager(k)
-                cache.advance_host([k] * self.B)
-                self._pending += k
-                left -= k
-                continue
             if self._warm and self._use_graph and left >= self.GRAPH_STEPS > 1:
                 g = self._captured(self.GRAPH_STEPS)
                 if g is not None:
@@ -757,7 +737,6 @@ class GreedySession:
         m, cache = self.model, self.cache
         _hip.decode_engine_reset(m._backend._workspace)
         _hip.set_decode_engine(False)
-        self._engine = False
         self._graphs = {}  # they hold engine launches
         cache._seen = [p - missing for p in cache._seen]
         for _ in range(missing):

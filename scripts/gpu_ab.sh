@@ -30,5 +30,5 @@ for rep in $(seq 1 $REPS); do
     run $n MISTRAL_HIP_LIB=$PWD/$f
   done
 done
-EXTRA="$* --loop forward" run main_forward_loop X=1
-EXTRA="$* --no-graph" run main_no_graph X=1
+[ -n "$AB_EXTRAS" ] && EXTRA="$* --loop forward" run main_forward_loop X=1
+[ -n "$AB_EXTRAS" ] && EXTRA="$* --no-graph" run main_no_graph X=1

@@ -24,7 +24,6 @@ PY
 for rep in $(seq 1 $REPS); do
   run "shipped (1 token per launch, graph)" X=1 --
   run "8 steps per hipGraph" MI_GRAPH_STEPS=8 --
-  run "32 tokens per engine launch" MI_LAUNCH_STEPS=32 --
   run "driver shape: steps 20 warmup 5" X=1 -- --steps 20 --warmup 5
 done
 run "forward() + torch.argmax loop" X=1 -- --loop forward

@@ -98,8 +98,9 @@ SHAPES = {
                                vocab_size=1000, sliding_window=48, num_experts=8, num_experts_per_tok=2),
     "moe_4_experts_mha": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=8, n_kv_heads=8, norm_eps=1e-5,
                               vocab_size=514, sliding_window=None, num_experts=4, num_experts_per_tok=2),
-    # rows whose piece count is not a multiple of 4: dim 3072 = 6 pieces (streamed as 4 + 2), hidden 1536 = 3 (2 + 1) - the
-    # Mistral-Nemo case (dim 5120 = 4 + 4 + 2) in small; 6 kv heads x 32 splits leave a quarter of the CUs without attention work
+    # rows whose piece count is not a multiple of 4: dim 3072 = 6 pieces (streamed in 2-piece groups), hidden 1536 = 3 (single
+    # pieces) - the Mistral-Nemo case (dim 5120 = 10 pieces) in small; 6 kv heads x 32 splits leave a quarter of the CUs without
+    # attention work
     "rows_of_6_and_3_pieces": dict(dim=3072, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=24, n_kv_heads=6, norm_eps=1e-5,
                                    vocab_size=768, sliding_window=64),
     # HOLDER WAVES at a size the whole suite can afford: they need dim % 2048 == 0 and >= 11 W1|W3 units per CU
@@ -302,22 +303,6 @@ def test_engine_full_size_bit_equal():
     graph, _, st2 = _run(m, ids, T, steps, engine=True, graph=True)
     assert st2["status"] == 0
     assert all(torch.equal(a, b) for a, b in zip(ref, graph))
-    # several tokens per launch (mi_batch_t.greedy_steps: the sample reaches the next step inside the kernel, the K/V row of
-    # step t is read at step t + 1 without a kernel boundary in between) == one launch per token: tokens, last logits, rings
-    outs = []
-    for launch_steps in (1, 16):
-        c = _cache(m, T + 40)
-        last = m.forward(ids[:T], [T], c)[-1:]
-        sess = m.greedy_session(c, torch.argmax(last, dim=-1))
-        sess.LAUNCH_STEPS = launch_steps
-        sess.run(33)                      # 1 + 16 + 16 across the 4096-slot ring's wrap
-        toks, lps = sess.collect()
-        rings = [(c.cache_k[l][:, :40].clone(), c.cache_v[l][:, :40].clone()) for l in range(m.n_local_layers)]
-        outs.append((toks.clone(), lps.clone(), sess.logits.clone(), rings))
-    (t1, l1, g1, r1), (t2, l2, g2, r2) = outs
-    assert torch.equal(t1, t2) and torch.equal(l1, l2) and torch.equal(g1, g2), (t1[:, 0].tolist(), t2[:, 0].tolist())
-    for (k1, v1), (k2, v2) in zip(r1, r2):
-        assert torch.equal(k1, k2) and torch.equal(v1, v2)
     del m
     torch.cuda.empty_cache()
 
