@@ -50,6 +50,22 @@ constexpr int NCONS = 4;
 #ifndef ENG_LEAN_BARRIERS
 #define ENG_LEAN_BARRIERS 0  // 1: waves 1-3 start the attn sweep while wave 0 still merges the splits (+45 us per step)
 #endif
+// ENG_TRACE = 1 (shipped): the phase-timeline stamp sites (mi_debug_set_engine_trace, scripts/engine_trace.py) stay in the
+// production kernel although they cost a test of a null pointer each.  MEASURED: compiling them out makes the step 17 % SLOWER
+// (3.17-3.19 vs 2.70-2.71 ms, same box, profiles/EXPERIMENTS.md) - the 26 sites per layer pin the compiler's placement of loads
+// and waits at the phase boundaries; without them hipcc moves memory operations across phases.  ENG_TRACE = 2 replaces the
+// stamps by bare compiler barriers (experiment).
+#ifndef ENG_TRACE
+#define ENG_TRACE 1
+#endif
+// ENG_ALL4: instantiations whose weight rows are all multiples of 4 pieces (dim, n_heads*128 and hidden_dim multiples of
+// 2048 - every BASELINE model but Nemo) drop the generic-group path from the five row loops of the consumers.
+#ifndef ENG_ALL4
+#define ENG_ALL4 1
+#endif
+#ifndef ENG_ASM_DMA
+#define ENG_ASM_DMA 0  // 1: the loader's LDS-DMA from inline asm (Loader::dma_n).  Measured 20-30 us per step slower than the builtin.
+#endif
 #ifndef ENG_CBAR_FLAGS
 #define ENG_CBAR_FLAGS 0  // 1: consumer barrier on per-wave flag words polled without sleeping (+10..20 us per step)
 #endif
@@ -116,7 +132,12 @@ struct Shared {
 };
 
 __device__ __forceinline__ void trace_ev(const Shared& sh, int c, int layer, int ev, bool who) {
+#if ENG_TRACE == 1
   if (sh.trace && who) sh.trace[((size_t)c * ENG_MAXL + layer) * TR_EVENTS + ev] = __builtin_amdgcn_s_memrealtime();
+#elif ENG_TRACE == 2
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 __device__ __forceinline__ void raise_abort(const Shared& sh, uint32_t code) {
@@ -250,6 +271,35 @@ struct Loader {
       if (f >= 2) publish(f - 2);
     }
   }
+  // The DMA itself.  ENG_ASM_DMA = 1 (experiment, off): issued from inline asm (cdna_hip_programming.md section 5.7 recipe: M0
+  // is written in the statement that reads it and restored), which keeps the DMA out of hipcc's s_waitcnt bookkeeping - in
+  // some builds hipcc puts an `s_waitcnt vmcnt(0)` into the per-unit loop of every weight segment.  It removes those waits
+  // (checked in the ISA) and is nevertheless 20-30 us per step slower than the builtin form (profiles/EXPERIMENTS.md).
+  template <int N>
+  __device__ __forceinline__ void dma_n(const void* src_lane, lchar* dst) {
+#if ENG_ASM_DMA
+    unsigned keep;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<size_t>(dst);
+    if constexpr (N == 1)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off nt\n\t"
+                   "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src_lane), "s"(lds_addr) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off nt\n\t"
+                   "global_load_lds_dwordx4 %1, off offset:1024 nt\n\t"
+                   "global_load_lds_dwordx4 %1, off offset:2048 nt\n\t"
+                   "global_load_lds_dwordx4 %1, off offset:3072 nt\n\t"
+                   "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src_lane), "s"(lds_addr) : "memory");
+#else
+    dma<0>(src_lane, dst);
+    if constexpr (N == 4) {
+      dma<PIECE>(src_lane, dst);
+      dma<2 * PIECE>(src_lane, dst);
+      dma<3 * PIECE>(src_lane, dst);
+    }
+#endif
+  }
   template <int OFF>
   __device__ __forceinline__ void dma(const void* src_lane, lchar* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, OFF, 2 /* nt */);
@@ -259,18 +309,14 @@ struct Loader {
   }
   __device__ __forceinline__ void piece(const void* src_lane) {
     if ((g & (FILL - 1)) == 0) fill_begin();
-    dma<0>(src_lane, slot_of(g));
+    dma_n<1>(src_lane, slot_of(g));
     ++g;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
   // 4 consecutive pieces (4 KiB contiguous in memory AND in the ring: g % 4 == 0): one address, immediate offsets
   __device__ __forceinline__ void piece4(const void* src_lane) {
     if ((g & (FILL - 1)) == 0) fill_begin();
-    lchar* dst = slot_of(g);
-    dma<0>(src_lane, dst);
-    dma<PIECE>(src_lane, dst);
-    dma<2 * PIECE>(src_lane, dst);
-    dma<3 * PIECE>(src_lane, dst);
+    dma_n<4>(src_lane, slot_of(g));
     g += 4;
     if ((g & (FILL - 1)) == 0) fill_end();
   }
@@ -370,7 +416,9 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       for (int q = 0; q < 2; ++q) ld.pairs(reinterpret_cast<const bf16_t*>(tab[ex[q] * 3 + 1]), p.o0, p.o1, a.F);
     }
     trace_ev(sh, c, l, TR_CONS + 5, tr);
+#if ENG_TRACE == 1
     if (sh.trace && tr) sh.trace[((size_t)c * ENG_MAXL + l) * TR_EVENTS + TR_CONS + 6] = ld.stalls;
+#endif
   }
   if (a.head) {
     int v0, v1;
@@ -437,7 +485,8 @@ struct Cons {
   // in LDS.  Lane owns elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p and accumulates them pairwise
   // (dot2_bf16) in ascending order - the launch path's order per row.  The NR rows advance in lockstep: NR independent
   // accumulation chains (a single chain is latency-bound: 28 GB/s per CU measured, below the HBM stream).
-  template <int NR>
+  // A4: every row of this instantiation has a multiple of 4 pieces - the generic-group path is not compiled
+  template <int NR, bool A4>
   __device__ __forceinline__ void unit_dot(uint32_t g0, int P, const lbf16* xs, float (&out)[NR]) {
     float acc[NR];
 #pragma unroll
@@ -451,12 +500,12 @@ struct Cons {
         for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(wv[r][i], xv[i], acc[r]);
     };
     // the unit arrives in groups of G pieces per row (Loader::unit): wait for a group, reduce it, hand its ring space back
-    const int G = unit_group(P);
+    const int G = A4 ? 4 : unit_group(P);
     constexpr int S = (NR <= 2) ? 4 : 2;  // pieces per row whose LDS reads are issued together
     uint32_t gg = g0;                     // first ring piece of the current group
     for (int p0 = 0; p0 < P; p0 += G, gg += NR * G) {
       need_fill(gg + NR * G - 1);
-      if (G == 4) {
+      if (A4 || G == 4) {
 #pragma unroll
         for (int h = 0; h < 4; h += S) {
           u32x4 xv[S], wv[S][NR];
@@ -681,6 +730,7 @@ struct Cons {
 //   W2       expert A rows with hid A (gathered long after its last producer finished: the sweep is one pass), then
 //            expert B rows with hid B; r = bf16(bf16(0 + bf16(wA yA)) + bf16(wB yB)); h = bf16(h1 + r)  (moe.py:28-32 +
 //            transformer_layers.py:168, the order of the launch path's moe_w2_kernel)
+template <bool ALL4>
 __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons& cs, const EngLayer& L, const LayerPlan& p, int l,
                                         int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
                                         const u32x4 (&xr)[4], bool trc) {
@@ -776,7 +826,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
       const uint32_t ga = g + (uint32_t)(4 * k) * PD;
       cs.set_done(ga);
       float vv[4];
-      cs.template unit_dot<4>(ga, PD, xs, vv);
+      cs.template unit_dot<4, ALL4>(ga, PD, xs, vv);
       if (lane == 0) {
         const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(vv[0], vv[1])) | ((uint32_t)f_to_bf(swiglu_bf(vv[2], vv[3])) << 16);
         const int q = k >= n_u, j = k - q * n_u;
@@ -803,7 +853,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
       const uint32_t ga = g + (uint32_t)(2 * k) * PF;
       cs.set_done(ga);
       float vv[2];
-      cs.template unit_dot<2>(ga, PF, xs, vv);
+      cs.template unit_dot<2, ALL4>(ga, PF, xs, vv);
       if (lane == 0) {
         const float t0 = bf_round(wq * bf_round(vv[0])), t1 = bf_round(wq * bf_round(vv[1]));
         if (q == 0) {
@@ -824,7 +874,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
   }
 }
 
-template <int R, bool MOE>
+template <int R, bool MOE, bool ALL4>
 __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch,
                                              uint32_t arrive_target) {
   Cons cs{sh, w, lane};
@@ -923,7 +973,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         // the rotary entry is fetched BEFORE the dot products (an L2 round trip otherwise sits in every unit's tail)
         const float2 cs2 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + ((r0 % DH) >> 1)) * 2);
         float v[2];
-        cs.template unit_dot<2>(ga, PD, xs, v);
+        cs.template unit_dot<2, ALL4>(ga, PD, xs, v);
         if (lane == 0) {
           float y0 = bf_round(v[0]), y1 = bf_round(v[1]);
           if (kind < 2) {  // rope.py:13-23 on the adjacent pair
@@ -1074,7 +1124,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         const uint32_t ga = g + (uint32_t)(2 * k) * PA;
         cs.set_done(ga);
         float vv[2];
-        cs.template unit_dot<2>(ga, PA, xs, vv);
+        cs.template unit_dot<2, ALL4>(ga, PA, xs, vv);
         const float v0 = vv[0], v1 = vv[1];
         if (lane == 0) {
           const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
@@ -1106,7 +1156,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           const uint32_t ga = g + (uint32_t)(4 * k) * PD;
           cs.set_done(ga);
           float vv[4];
-          cs.template unit_dot<4>(ga, PD, xs, vv);
+          cs.template unit_dot<4, ALL4>(ga, PD, xs, vv);
           const float a0 = vv[0], b0 = vv[1], a1 = vv[2], b1 = vv[3];
           if (lane == 0) {
             const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(a0, b0)) | ((uint32_t)f_to_bf(swiglu_bf(a1, b1)) << 16);
@@ -1138,7 +1188,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           const uint32_t ga = g + (uint32_t)(2 * k) * PF;
           cs.set_done(ga);
           float vv[2];
-          cs.template unit_dot<2>(ga, PF, xs, vv);
+          cs.template unit_dot<2, ALL4>(ga, PF, xs, vv);
           const float v0 = vv[0], v1 = vv[1];
           if (lane == 0) {
             const uint32_t rs = *reinterpret_cast<const lu32*>(sh.res + 2 * k);
@@ -1152,7 +1202,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         cs.set_done(g);
       }
     } else {
-      moe_ffn(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
+      moe_ffn<ALL4>(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
     }
     trace_ev(sh, c, l, 16, trc);
     cs.cbar();
@@ -1179,7 +1229,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       const uint32_t ga = g + (uint32_t)(2 * k) * PD;
       cs.set_done(ga);
       float vv[2];
-      cs.template unit_dot<2>(ga, PD, xs, vv);
+      cs.template unit_dot<2, ALL4>(ga, PD, xs, vv);
       if (lane == 0) {
         const float y0 = bf_round(vv[0]), y1 = bf_round(vv[1]);
         *reinterpret_cast<float2*>(a.logits + 2 * (size_t)(v0 + k)) = make_float2(y0, y1);
@@ -1359,7 +1409,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
 
 // MOE is a separate instantiation: the dense kernel must not pay registers for the router / two-expert code (it sits at
 // 247 of 256 VGPRs and spilled with the MoE path compiled in)
-template <int R, bool MOE>
+template <int R, bool MOE, bool ALL4>
 __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int c = blockIdx.x;
@@ -1399,7 +1449,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
       // test hook: wait for one workgroup more than exist - the gate fails exactly as it would with one missing
       if (__hip_atomic_load(sh.ctrl + G_SABOTAGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) arrive_target += 1u;
     }
-    run_consumer<R, MOE>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
+    run_consumer<R, MOE, ALL4>(a, sh, c, w, lane, pos, seq, epoch, arrive_target);
   }
   // launches completed by the engine (one per <= 32 layers of a step): how a caller tells which path ran
   if (c == 0 && threadIdx.x == 0 && !sh.ctl[C_ABORT])
@@ -1620,16 +1670,21 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
     }
     const void* fn = nullptr;
     const bool moe = pr.E > 0;
+    const bool all4 = ENG_ALL4 && pr.D % 2048 == 0 && (pr.H * attn_core::DH) % 2048 == 0 && pr.F % 2048 == 0;
+#define ENG_PICK(RR)                                                                                                       \
+  (moe ? (all4 ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
+       : (all4 ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
     switch (a.R) {
-      case 1: fn = moe ? (const void*)decode_engine_kernel<1, true> : (const void*)decode_engine_kernel<1, false>; break;
-      case 2: fn = moe ? (const void*)decode_engine_kernel<2, true> : (const void*)decode_engine_kernel<2, false>; break;
-      case 4: fn = moe ? (const void*)decode_engine_kernel<4, true> : (const void*)decode_engine_kernel<4, false>; break;
-      case 8: fn = moe ? (const void*)decode_engine_kernel<8, true> : (const void*)decode_engine_kernel<8, false>; break;
+      case 1: fn = ENG_PICK(1); break;
+      case 2: fn = ENG_PICK(2); break;
+      case 4: fn = ENG_PICK(4); break;
+      case 8: fn = ENG_PICK(8); break;
       default: return hipErrorInvalidValue;
     }
+#undef ENG_PICK
     // 160 KiB of dynamic LDS is an opt-in per function AND per device
-    static bool attr_set[64][18] = {};
-    const int slot = a.R + (moe ? 9 : 0);
+    static bool attr_set[64][36] = {};
+    const int slot = a.R + (moe ? 9 : 0) + (all4 ? 18 : 0);
     if (dev < 0 || dev >= 64 || !attr_set[dev][slot]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;

@@ -14,6 +14,10 @@ sys.path.insert(0, ROOT)
 import build_native as b  # noqa: E402
 
 VARIANTS = {
+    "asm_dma0": ("-DENG_ASM_DMA=0",),             # the loader's DMA through the builtin (hipcc then decides where vmcnt waits go)
+    "trace0": ("-DENG_TRACE=0",),                 # no stamp sites: measured 17 % SLOWER (they pin the compiler's scheduling)
+    "trace2": ("-DENG_TRACE=2",),                 # stamp sites replaced by bare compiler / scheduling barriers
+    "all4_0": ("-DENG_ALL4=0",),                  # the generic-group path compiled into every instantiation (round-2 form)
     "cbar_flags": ("-DENG_CBAR_FLAGS=1",),        # consumer barrier on per-wave flag words (measured +10..20 us per step)
     "sparse_poll": ("-DENG_SPARSE_POLL=1",),      # re-poll only the granules that were missing (+25 us)
     "lean_barriers": ("-DENG_LEAN_BARRIERS=1",),  # attn sweep starts while wave 0 still merges (+45 us)

@@ -1,5 +1,4 @@
 #!/bin/bash
-# Engine + greedy tests, then main vs every library in lib/variants (same box), then one sample of the other headline numbers.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests/test_gpu_engine.py tests/test_gpu_greedy.py -q -x > gpurun_out/pytest_engine.log 2>&1
