@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import build_native as b  # noqa: E402
 
 VARIANTS = {
-    "asm_dma0": ("-DENG_ASM_DMA=0",),             # the loader's DMA through the builtin (hipcc then decides where vmcnt waits go)
+    "asm_dma1": ("-DENG_ASM_DMA=1",),             # the loader's DMA through the builtin (hipcc then decides where vmcnt waits go)
     "trace0": ("-DENG_TRACE=0",),                 # no stamp sites: measured 17 % SLOWER (they pin the compiler's scheduling)
     "trace2": ("-DENG_TRACE=2",),                 # stamp sites replaced by bare compiler / scheduling barriers
     "all4_0": ("-DENG_ALL4=0",),                  # the generic-group path compiled into every instantiation (round-2 form)
@@ -22,6 +22,13 @@ VARIANTS = {
     "sparse_poll": ("-DENG_SPARSE_POLL=1",),      # re-poll only the granules that were missing (+25 us)
     "lean_barriers": ("-DENG_LEAN_BARRIERS=1",),  # attn sweep starts while wave 0 still merges (+45 us)
     "holders0": ("-DENG_HOLDERS=0",),             # no holder waves (5-wave workgroups)
+    # compiler-flag lottery (the kernel's speed is a chaotic function of its code: profiles/EXPERIMENTS.md)
+    # (the shipped engine build uses -amdgpu-sched-strategy=max-memory-clause: build_native.PER_FILE_FLAGS; set
+    #  MI_ENGINE_FLAGS="" in the environment of this script to get the default strategy as the baseline of such an A/B)
+    "O2": ("-O2",),
+    "maxilp": ("-mllvm", "-amdgpu-sched-strategy=max-ilp"),
+    "nopostmisched": ("-mllvm", "-enable-post-misched=0"),
+    "noslp": ("-fno-slp-vectorize",),
 }
 
 if __name__ == "__main__":
