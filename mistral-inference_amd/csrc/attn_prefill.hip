@@ -26,6 +26,10 @@
 #include "common.cuh"
 #include "kernels.h"
 
+#ifndef ATT_PRIO
+#define ATT_PRIO 0  // experiment switch: 1 = s_setprio(1) around the two MFMA clusters, 2 = static priority 1 for waves 4..7
+#endif
+
 namespace {
 
 constexpr int DH = 128;
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
   gload(0);
   lstore(smem);
   __syncthreads();
+  if (ATT_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(1);
   for (int it = 0; it < n_tiles; ++it) {
     if (it + 1 < n_tiles) gload(it + 1);
     const char* Ks = smem + (it & 1) * BUF_BYTES;
@@ -212,11 +217,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
                 bf16x8, *reinterpret_cast<const u32x4*>(Ks + key * (DH * 2) + ((slot ^ (key & 15)) << 4)));
           }
         __builtin_amdgcn_sched_barrier(0);  // keep the 8 reads ahead of the MFMAs (hipcc sinks them back otherwise)
+        if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb)
             st[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k4][mb], qf[kh * 4 + k4], st[mb], 0, 0, 0);
+        if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       }
       // ---- mask, online softmax (this lane: query ql, keys of its half).  Scores stay RAW (unscaled): the
       // 1/sqrt(d) * log2(e) factor is folded into the exponent's fma, p = exp2(s * sc - m * sc).
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
           pb[mb][r >> 3][(r & 7) >> 1] = cvt_pk_bf16(p0, p1);
         }
       l_run = l_run * alpha + psum;
+      if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(1);
       // ---- O^T += V^T . P^T  (left to hipcc's scheduler, which overlaps the second key half's exponentials with the
       // first half's MFMAs; hand-pipelining the V^T fragment reads one group ahead measured no better)
 #pragma unroll
@@ -287,6 +295,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
             acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, acc[dt], 0, 0, 0);
           }
         }
+      if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
     if (it + 1 < n_tiles) lstore(smem + ((it + 1) & 1) * BUF_BYTES);
     __syncthreads();

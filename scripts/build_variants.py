@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Build A/B variants of libmistral_hip.so for scripts/gpu_ab.sh (compile-time switches of the decode engine).
 
-    python scripts/build_variants.py                 # the three round-3 experiments, each switched ON, next to the shipped build
+    python scripts/build_variants.py engine          # every engine variant below (or name the ones wanted)
     gpurun --timeout 900 -- 'bash scripts/gpu_ab.sh 2'
+    python scripts/build_variants.py gemm            # the prefill-GEMM variants (FILE_VARIANTS; only gemm256.o differs)
+    gpurun --timeout 900 -- 'python scripts/prefill_probe.py'
 
 A variant is `name: (extra hipcc flags...)`; objects go to /tmp/obj_<name>, the library to
 mistral-inference_amd/lib/variants/libmistral_hip_<name>.so (git-ignored; travels to the GPU box with gpurun)."""
@@ -31,11 +33,66 @@ VARIANTS = {
     "noslp": ("-fno-slp-vectorize",),
 }
 
+# Variants of ONE source file: only that object is rebuilt, the rest is linked from the main build.
+# (gemm256.hip switches: G256_PRIO, G256_BAL, G256_DMA_AFTER, G256_ABL - see the top of that file)
+FILE_VARIANTS = {
+    "g_prio1": ("gemm256.hip", ("-DG256_PRIO=1",)),
+    "g_prio2": ("gemm256.hip", ("-DG256_PRIO=2",)),
+    "g_dma_after": ("gemm256.hip", ("-DG256_DMA_AFTER=1",)),
+    "g_bal": ("gemm256.hip", ("-DG256_BAL=1",)),
+    "g_bal_prio1": ("gemm256.hip", ("-DG256_BAL=1", "-DG256_PRIO=1")),
+    "g_bal_prio2": ("gemm256.hip", ("-DG256_BAL=1", "-DG256_PRIO=2")),
+    "g_bal_after": ("gemm256.hip", ("-DG256_BAL=1", "-DG256_DMA_AFTER=1")),
+    "g_bal_after_prio1": ("gemm256.hip", ("-DG256_BAL=1", "-DG256_DMA_AFTER=1", "-DG256_PRIO=1")),
+    "g_bal2": ("gemm256.hip", ("-DG256_BAL=2",)),            # + the DMAs only in the two light read segments
+    "g_bal2_prio1": ("gemm256.hip", ("-DG256_BAL=2", "-DG256_PRIO=1")),
+    "g_bal2_after": ("gemm256.hip", ("-DG256_BAL=2", "-DG256_DMA_AFTER=1")),
+    "g_bal2_after_prio1": ("gemm256.hip", ("-DG256_BAL=2", "-DG256_DMA_AFTER=1", "-DG256_PRIO=1")),
+    "g_pipe1": ("gemm256.hip", ("-DG256_PIPE=1",)),          # software-pipelined loop, one barrier per K tile
+    "g_pipe2": ("gemm256.hip", ("-DG256_PIPE=2",)),
+    "g_pipe1_prio2": ("gemm256.hip", ("-DG256_PIPE=1", "-DG256_PRIO=2")),
+    "a_prio1": ("attn_prefill.hip", ("-DATT_PRIO=1",)),
+    "a_prio2": ("attn_prefill.hip", ("-DATT_PRIO=2",)),
+    "g_abl_nodma": ("gemm256.hip", ("-DG256_ABL=1",)),      # timing ablations: WRONG results by construction
+    "g_abl_noreads": ("gemm256.hip", ("-DG256_ABL=2",)),
+    "g_abl_nomfma": ("gemm256.hip", ("-DG256_ABL=3",)),
+    "g_abl_mfmaonly": ("gemm256.hip", ("-DG256_ABL=4",)),
+    "g_abl_mfmaonly32": ("gemm256.hip", ("-DG256_ABL=5",)),
+    "g_clk": ("gemm256.hip", ("-DG256_CLK=1",)),              # + shader clock measured across block 0's main loop
+    "g_clk_abl_mfmaonly": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_ABL=4")),
+    "g_clk_abl_nomfma": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_ABL=3")),
+    "g_clk_abl_dmaonly": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_ABL=7")),
+    "g_clk_abl_readsonly": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_ABL=8")),
+    "g_clk_dma_after": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_DMA_AFTER=1")),
+    "g_clk_pipe2": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_PIPE=2")),
+    "g_clk_split": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_SPLIT=1")),
+    "g_clk_bal_after": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_BAL=1", "-DG256_DMA_AFTER=1")),
+    "g_clk_bal2_after": ("gemm256.hip", ("-DG256_CLK=1", "-DG256_BAL=2", "-DG256_DMA_AFTER=1")),
+    "g_abl_mfmaonly32x8": ("gemm256.hip", ("-DG256_ABL=6",)),
+}
+
+
+def build_file_variant(name, src, flags):
+    import subprocess
+    obj_dir = f"/tmp/obj_{name}"
+    os.makedirs(obj_dir, exist_ok=True)
+    o = os.path.join(obj_dir, src.replace(".hip", ".o"))
+    hipcc = b._hipcc()
+    subprocess.run([hipcc, *b.FLAGS, *b.PER_FILE_FLAGS.get(src, []), *flags, "-c", os.path.join(b.CSRC, src), "-o", o], check=True)
+    objs = [o if s == src else os.path.join(b.OBJ, s.replace(".hip", ".o")) for s in b.SOURCES]
+    lib = os.path.join(ROOT, "lib", "variants", f"libmistral_hip_{name}.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", lib], check=True)
+    return lib
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "lib", "variants"), exist_ok=True)
     b.build(verbose=False)
+    for name, (src, flags) in FILE_VARIANTS.items():
+        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_"):
+            print(name, build_file_variant(name, src, flags), flush=True)
     for name, flags in VARIANTS.items():
-        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        if name not in sys.argv[1:] and "engine" not in sys.argv[1:]:
             continue
         print(name, b.build(verbose=False, extra_flags=flags, obj_dir=f"/tmp/obj_{name}",
                             lib=os.path.join(ROOT, "lib", "variants", f"libmistral_hip_{name}.so")), flush=True)
