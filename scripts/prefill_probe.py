@@ -52,6 +52,34 @@ def worker():
         "w2": (lambda: _hip.linear(hid, (w2,), _hip.EPI_RESIDUAL, residual=res), 2.0 * T * F * D),
         "attn": (lambda: _hip.attn_prefill(qkv_in, H, KV, DH, None, None, 4096, q_start, kv_before, 1, T), 4.0 * T * T * H * DH / 2),
     }
+    if os.environ.get("PROBE_POWER"):  # board power / clocks while one op loops (rocm-smi sampled from a thread)
+        import threading, time
+        samples, stop = [], False
+
+        def sampler():
+            while not stop:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True)
+                try:
+                    c = json.loads(r.stdout)["card0"]
+                    samples.append({k: v for k, v in c.items() if "ower" in k or "sclk" in k or "mclk" in k})
+                except Exception as e:
+                    samples.append({"error": str(e)[:80], "out": r.stdout[:200]})
+                time.sleep(0.05)
+
+        for name in os.environ["PROBE_POWER"].split(","):
+            fn = ops[name][0]
+            stop, samples = False, []
+            th = threading.Thread(target=sampler)
+            th.start()
+            t0 = time.time()
+            while time.time() - t0 < 3.0:
+                for _ in range(50):
+                    fn()
+                torch.cuda.synchronize()
+            stop = True
+            th.join()
+            print("POWER " + name + " " + json.dumps(samples[len(samples) // 2:][:6]), flush=True)
+        return
     out = {}
     if os.environ.get("PROBE_CHECK"):  # independent sanity of the library under test (fp32 torch matmul, bf16-rounded)
         ref = (x.float() @ torch.cat([wq, wk, wv]).float().T).to(torch.bfloat16).float()
@@ -89,6 +117,14 @@ def worker():
 
 def main():
     args = sys.argv[1:]
+    if args and args[0] == "--power":  # python scripts/prefill_probe.py --power w13,attn [zeros]
+        env = dict(os.environ, PROBE_POWER=args[1] if len(args) > 1 else "w13")
+        for zeros in ([False, True] if "zeros" in args else [False]):
+            if zeros:
+                env["PROBE_ZERO"] = "1"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"], env=env, capture_output=True, text=True, timeout=300)
+            print(("zero operands: " if zeros else "random operands: ") + "\n".join(l for l in r.stdout.splitlines() if l.startswith("POWER")) + r.stderr[-300:], flush=True)
+        return
     reps = int(args[0]) if args and args[0].isdigit() else 2
     filt = [a for a in args if not a.isdigit()]
     libs = [("main", None, {})]
