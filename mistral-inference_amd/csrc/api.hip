@@ -56,6 +56,16 @@ int engine_mode() {
   return g_engine_mode;
 }
 
+// MI_FUSE_ROPE=0: RoPE as a separate pass after the prefill q|k|v GEMM instead of in its epilogue (A/B testing)
+bool fuse_rope_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MI_FUSE_ROPE");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+
 struct Workspace {
   int32_t* tickets;
   bf16_t* xn;       // [T, D]
@@ -583,8 +593,12 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       g.epi = GEMM_STORE; g.M = T; g.N = qkv_cols; g.K = D; g.a = ws.xn; g.lda = D;
       g.w0 = (const bf16_t*)L.wq; g.w1 = (const bf16_t*)L.wk; g.w2 = (const bf16_t*)L.wv; g.n0 = nq; g.n1 = nq + nkv;
       g.out = ws.qkv; g.ldo = qkv_cols;
+      // RoPE rides on the GEMM's epilogue (same arithmetic as rope_kernel on the same bf16-rounded values; it was a
+      // separate 20 us pass over q|k per layer at 4096 tokens).  Heads of a size the epilogues do not take: separate pass.
+      const bool fused_rope = fuse_rope_enabled() && Dh % 16 == 0;
+      if (fused_rope) { g.rope_cs = m->rope_cs; g.tok_pos = bt->tok_pos; g.rope_cols = nq + nkv; g.rope_dh = Dh; }
       MI_TRY(hip_rc(launch_gemm(g, s), "qkv gemm"));
-      MI_TRY(hip_rc(launch_rope(ws.qkv, qkv_cols, T, H, Hkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
+      if (!fused_rope) MI_TRY(hip_rc(launch_rope(ws.qkv, qkv_cols, T, H, Hkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
       // decode branch with more than 8 sequences: the ring write that the GEMV epilogue does otherwise; it must
       // precede the attention (cache.py:83-92 `update` then read, transformer_layers.py:77-81)
       if (branch == MI_BRANCH_DECODE)

@@ -178,6 +178,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue.  acc[mt][nt][r] is tile row wm*64 + mt*16 + (lane>>4)*4 + r, column (lane & 15) of its 16x16 tile
+  const bool rope = EPI == GEMM_STORE && g.rope_cs != nullptr;
+  int tpos[4][4];
+  if (rope) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tpos[mt][r] = g.tok_pos[row0 + min(wm * 64 + mt * 16 + (lane >> 4) * 4 + r, rows_valid - 1)];
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -197,7 +205,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int nt = 0; nt < 4; ++nt) {
           const int n = n_tile * BN + wn * 64 + nt * 16 + (lane & 15);
           if (n >= g.N) continue;
-          const float y = bf_round(acc[mt][nt][r]);
+          float y = bf_round(acc[mt][nt][r]);
+          if (EPI == GEMM_STORE && rope) {
+            // the pair's other half is in the neighbouring lane (column n ^ 1): both lanes form the rotation, each keeps
+            // its own component.  (Uniform per 16x16 tile: rope_cols is a multiple of 16, so the exchange is not divergent.)
+            const float other = __shfl_xor(y, 1, 64);
+            if (n < g.rope_cols) {
+              const int i0 = ((n + g.rope_col0) % g.rope_dh) >> 1;
+              const float2 cs = *reinterpret_cast<const float2*>(g.rope_cs + ((size_t)tpos[mt][r] * (g.rope_dh >> 1) + i0) * 2);
+              float re, im;
+              if (n & 1) {
+                rope_pair(other, y, cs.x, cs.y, re, im);
+                y = bf_round(im);
+              } else {
+                rope_pair(y, other, cs.x, cs.y, re, im);
+                y = bf_round(re);
+              }
+            }
+          }
           if (EPI == GEMM_LOGITS) {
             reinterpret_cast<float*>(g.out)[orow * g.ldo + n] = y;
           } else if (EPI == GEMM_RESIDUAL) {
@@ -249,6 +274,10 @@ GemmArgs column_slice(const GemmArgs& g, int c0, int c1) {
   const size_t esz = (g.epi == GEMM_LOGITS) ? 4 : 2;
   r.out = reinterpret_cast<char*>(g.out) + (size_t)c0 * esz;
   if (g.residual) r.residual = g.residual + c0;
+  if (g.rope_cs) {  // (slices start on tile boundaries: multiples of 128, hence of the head size)
+    r.rope_col0 = g.rope_col0 + c0;
+    r.rope_cols = g.rope_cols - c0 < 0 ? 0 : (g.rope_cols - c0 > r.N ? r.N : g.rope_cols - c0);
+  }
   if (g.epi == GEMM_SWIGLU) {  // w0 = W1, w1 = W3, both [N, K]
     r.w0 = g.w0 + (size_t)c0 * g.K;
     r.w1 = g.w1 + (size_t)c0 * g.K;

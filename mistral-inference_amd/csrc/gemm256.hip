@@ -666,6 +666,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   // (lane >> 4)*4 + r - four CONSECUTIVE output columns per lane, so results (and the residual) move as 8-byte
   // (bf16) / 16-byte (fp32 logits) accesses instead of 2-byte ones.
   const int cq = (lane >> 4) * 4;
+  const bool rope = EPI == GEMM_STORE && g.rope_cs != nullptr;
   const bool wide_ok = (g.ldo & 3) == 0 && (reinterpret_cast<size_t>(g.out) & 15) == 0 &&
                        (EPI != GEMM_RESIDUAL || (reinterpret_cast<size_t>(g.residual) & 7) == 0);
 #pragma unroll
@@ -676,6 +677,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
       if (rl >= rows_valid) continue;
       const int row = row0 + rl;
       const size_t ob = (size_t)row * g.ldo;
+      const int tp = rope ? g.tok_pos[row] : 0;
       if (EPI == GEMM_SWIGLU) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -703,6 +705,17 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = bf_round(acc[ha][hb][i][j][r]);
+            if (EPI == GEMM_STORE && rope && n < g.rope_cols) {
+              // rotary embedding on the bf16-rounded projection (transformer_layers.py:66-70): this lane's four columns
+              // are two (re, im) pairs of one head; their (cos, sin) entries are 16 contiguous bytes of the table
+              const int i0 = ((n + g.rope_col0) % g.rope_dh) >> 1;
+              const f32x4 cs = *reinterpret_cast<const f32x4*>(g.rope_cs + ((size_t)tp * (g.rope_dh >> 1) + i0) * 2);
+              float re, im;
+              rope_pair(y[0], y[1], cs[0], cs[1], re, im);
+              y[0] = bf_round(re); y[1] = bf_round(im);
+              rope_pair(y[2], y[3], cs[2], cs[3], re, im);
+              y[2] = bf_round(re); y[3] = bf_round(im);
+            }
             if (EPI == GEMM_LOGITS) {
               float* o = reinterpret_cast<float*>(g.out) + ob + n;
               if (full) {

@@ -86,6 +86,13 @@ struct GemmArgs {
   const int32_t* lp_target;       // device [M], -1: none
   float2* lp_partial;             // device [M][ceil(N / 256)]
   float* lp_tgt;                  // device [M]
+  // GEMM_STORE only: rotary embedding in the epilogue (transformer_layers.py:70 apply_rotary_emb on the bf16 q, k).  Output
+  // columns n < rope_cols are (re, im) pairs of heads of rope_dh columns; pair i of a head is turned by the table entry
+  // rope_cs[tok_pos[row]][i] = (cos, sin), exactly as rope_kernel does in a separate pass.  nullptr: plain store.
+  const float* rope_cs;           // device fp32 [rope_len][rope_dh / 2][2]
+  const int32_t* tok_pos;         // device [M]
+  int rope_cols, rope_dh;         // rope_cols % rope_dh == 0, rope_dh % 4 == 0
+  int rope_col0;                  // column of the whole problem at which this (column-sliced) launch starts (% rope_dh == 0)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 bool gemm256_applicable(const GemmArgs& g);  // gemm256.hip: 256x256 tile for the large prefill shapes

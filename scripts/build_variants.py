@@ -51,6 +51,16 @@ FILE_VARIANTS = {
     "g_pipe1": ("gemm256.hip", ("-DG256_PIPE=1",)),          # software-pipelined loop, one barrier per K tile
     "g_pipe2": ("gemm256.hip", ("-DG256_PIPE=2",)),
     "g_pipe1_prio2": ("gemm256.hip", ("-DG256_PIPE=1", "-DG256_PRIO=2")),
+    # engine: more tickets in the compiler-flag lottery, each ON TOP of the shipped max-memory-clause strategy
+    "e_nocluster": ("decode_engine.hip", ("-mllvm", "-misched-cluster=0")),
+    "e_trackers": ("decode_engine.hip", ("-mllvm", "-amdgpu-use-amdgpu-trackers=1")),
+    "e_prera_topdown": ("decode_engine.hip", ("-mllvm", "-misched-prera-direction=topdown")),
+    "e_prera_bottomup": ("decode_engine.hip", ("-mllvm", "-misched-prera-direction=bottomup")),
+    "e_postra_bottomup": ("decode_engine.hip", ("-mllvm", "-misched-postra-direction=bottomup")),
+    "e_nopostmisched": ("decode_engine.hip", ("-mllvm", "-enable-post-misched=0")),
+    "e_noslp": ("decode_engine.hip", ("-fno-slp-vectorize",)),
+    "e_nounroll": ("decode_engine.hip", ("-fno-unroll-loops",)),
+    "e_relaxed_occ": ("decode_engine.hip", ("-mllvm", "-amdgpu-schedule-relaxed-occupancy=1")),
     "a_prio1": ("attn_prefill.hip", ("-DATT_PRIO=1",)),
     "a_prio2": ("attn_prefill.hip", ("-DATT_PRIO=2",)),
     "g_abl_nodma": ("gemm256.hip", ("-DG256_ABL=1",)),      # timing ablations: WRONG results by construction
@@ -89,7 +99,7 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "lib", "variants"), exist_ok=True)
     b.build(verbose=False)
     for name, (src, flags) in FILE_VARIANTS.items():
-        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_"):
+        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_") or "engine_flags" in sys.argv[1:] and name.startswith("e_"):
             print(name, build_file_variant(name, src, flags), flush=True)
     for name, flags in VARIANTS.items():
         if name not in sys.argv[1:] and "engine" not in sys.argv[1:]:
