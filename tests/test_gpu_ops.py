@@ -492,3 +492,27 @@ def test_moe_layer_general_route_any_expert_count_and_topk(E, k, T):
     assert clear.any()
     assert float((out.float() - ref.float())[clear].abs().max()) <= tol
     assert float((gen.float() - ref.float())[clear].abs().max()) <= tol
+
+
+@pytest.mark.gpu
+def test_fused_rope_epilogue_bit_equal_to_separate_pass(tmp_path):
+    """RoPE as the q|k|v GEMM's epilogue (csrc/gemm256.hip, csrc/gemm.hip; transformer_layers.py:66-70) == RoPE as the separate
+    pass it replaced (MI_FUSE_ROPE=0), bit for bit: prefill logits of every chunk and the K/V rings, on the 128-tile kernel
+    alone (ragged 3-sequence batch) and on the 256-tile kernel + tail-round split (Mistral-7B dims, 1000 + 300 tokens)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    dumps = []
+    for fuse in ("1", "0"):
+        out = tmp_path / f"fuse{fuse}.pt"
+        env = dict(os.environ, MI_FUSE_ROPE=fuse)
+        r = subprocess.run([sys.executable, os.path.join(here, "fused_rope_util.py"), str(out)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        dumps.append(torch.load(out))
+    a, b = dumps
+    assert a.keys() == b.keys() and len(a) > 10
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
