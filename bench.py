@@ -202,6 +202,17 @@ def cpu_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
     if ref is not None:
         ref["port_value"] = port["value"]
         return ref
+    # The GPU box has no reference source.  The unmodified reference was timed once, on the build container, with the same
+    # bounded sample (Mistral-7B dims): carried along so that the record holds both numbers.
+    stored = os.path.join(ROOT, "profiles", "r02_cpu_baseline_reference_vs_port.json")
+    if params.get("dim") == 4096 and params.get("n_layers") == 32 and not params.get("moe") and os.path.exists(stored):
+        try:
+            r = json.load(open(stored))["reference"]
+            port["reference_container_value"] = r["value"]
+            port["reference_container_cores"] = r["cores"]
+            port["reference_container_source"] = "profiles/r02_cpu_baseline_reference_vs_port.json (build container, no GPU)"
+        except (KeyError, ValueError, OSError):
+            pass
     return port
 
 

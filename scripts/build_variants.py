@@ -61,6 +61,10 @@ FILE_VARIANTS = {
     "e_noslp": ("decode_engine.hip", ("-fno-slp-vectorize",)),
     "e_nounroll": ("decode_engine.hip", ("-fno-unroll-loops",)),
     "e_relaxed_occ": ("decode_engine.hip", ("-mllvm", "-amdgpu-schedule-relaxed-occupancy=1")),
+    # launch path (Nemo dims, batch > 1): the same strategy for the GEMV / decode-attention sources
+    "l_gemv_mmc": ("gemv.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
+    "l_attn_mmc": ("attn_decode.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
+    "l_gemv_ilp": ("gemv.hip", ("-mllvm", "-amdgpu-sched-strategy=max-ilp")),
     "a_prio1": ("attn_prefill.hip", ("-DATT_PRIO=1",)),
     "a_prio2": ("attn_prefill.hip", ("-DATT_PRIO=2",)),
     "g_abl_nodma": ("gemm256.hip", ("-DG256_ABL=1",)),      # timing ablations: WRONG results by construction
@@ -99,7 +103,7 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "lib", "variants"), exist_ok=True)
     b.build(verbose=False)
     for name, (src, flags) in FILE_VARIANTS.items():
-        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_") or "engine_flags" in sys.argv[1:] and name.startswith("e_"):
+        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_") or "engine_flags" in sys.argv[1:] and name.startswith("e_") or "launch_flags" in sys.argv[1:] and name.startswith("l_"):
             print(name, build_file_variant(name, src, flags), flush=True)
     for name, flags in VARIANTS.items():
         if name not in sys.argv[1:] and "engine" not in sys.argv[1:]:
