@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
 SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "gemm256.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip",
            "decode_engine.hip", "rccl_api.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
-           os.path.join(CSRC, "attn_decode_core.cuh"),
+           os.path.join(CSRC, "attn_decode_core.cuh"), os.path.join(CSRC, "gemm256_experiments.inc"),
            os.path.join(HERE, "..", "include", "mistral_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  The persistent decode engine is built with the max-memory-clause scheduling strategy: measured 1.3-1.5 % faster

@@ -15,8 +15,8 @@
 //     i.e. four 64x32 quadrants (ha, hb), 16 MFMA 16x16x32 each per K tile;
 //   * LDS = 2 stages x {A0, A1, B0, B1} x 16 KiB half tiles (128 rows x 128 B, 16-byte slot XOR-swizzled by row & 7,
 //     the swizzle applied on the DMA's SOURCE address);
-//   * one K tile = 4 phases, one quadrant each.  A phase (a) re-stages ONE half tile whose last reader finished a
-//     phase earlier (2 `global_load_lds_dwordx4` per lane), (b) reads the fragments it is missing, (c) lgkmcnt(0) +
+//   * one K tile = 4 phases, one quadrant each.  A phase (a) reads the fragments it is missing, (b) re-stages ONE
+//     half tile whose last reader finished a phase earlier (2 `global_load_lds_dwordx4` per lane), (c) lgkmcnt(0) +
 //     raw s_barrier, (d) 16 MFMAs.  The DMAs are never drained inside the loop: the single `s_waitcnt vmcnt(6)` per
 //     K tile (phase 4) retires the NEXT tile's four halves and leaves the three halves issued after them in flight
 //     across the barrier.
@@ -28,28 +28,27 @@
 #include "common.cuh"
 #include "kernels.h"
 
-// Build-time experiment switches (scripts/build_variants.py; profiles/EXPERIMENTS.md has the measurements):
+// Build-time experiment switches (all off in the shipped build; the experimental main loops live in gemm256_experiments.inc):
 #ifndef G256_PRIO
-#define G256_PRIO 0        // 1: s_setprio(1) around every MFMA cluster; 2: static priority 1 for the younger wave group
+#define G256_PRIO 0
 #endif
 #ifndef G256_BAL
-#define G256_BAL 0         // 1: fragment reads balanced 8/4/8/4 over the four phases (B half 0 fetched a phase early)
+#define G256_BAL 0
 #endif
 #ifndef G256_DMA_AFTER
-#define G256_DMA_AFTER 1   // 1 (shipped): a read segment issues its fragment reads before its half-tile DMA (0: DMA first)
+#define G256_DMA_AFTER 1   // 1 (shipped): a read segment issues its fragment reads before its half-tile DMA
 #endif
 #ifndef G256_SPLIT
-#define G256_SPLIT 0       // 1: a half tile's second DMA piece is issued in the middle of the MFMA segment
+#define G256_SPLIT 0
 #endif
 #ifndef G256_PIPE
-#define G256_PIPE 0        // 1: software-pipelined main loop, one barrier per K tile, no wave roles (see the loop)
+#define G256_PIPE 0
+#endif
+#ifndef G256_ABL
+#define G256_ABL 0
 #endif
 #ifndef G256_CLK
 #define G256_CLK 0         // 1: block 0 records shader-clock and 100 MHz ticks across its main loop (mi_debug_gemm_clock)
-#endif
-#ifndef G256_ABL
-#define G256_ABL 0         // timing ablations, WRONG results: inside the main loop 1 no DMA, 2 no fragment reads, 3 no MFMA,
-                           // 4 MFMA only, 5 / 6 MFMA only in the 32x32x16 shape, 7 DMA only, 8 fragment reads only
 #endif
 
 #if G256_CLK
@@ -174,214 +173,43 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if G256_PIPE
-  // ---- Software-pipelined main loop, every wave in the same role, ONE barrier per K tile.
-  // A K tile is four blocks of 16 MFMAs, G(ks, ha) = k step ks x A half ha x both B halves.  The fragments of the NEXT block
-  // are read (double-buffered registers aF / bF) while this block's MFMAs issue, and the next tiles' half-tile DMAs are
-  // issued between MFMAs as well, so a wave never stops to load; the two waves of a SIMD drift apart and fill each
-  // other's gaps.  Per tile T (stage S):
-  //   G0 = (0, 0): reads A(0, 1) -> aF[1]          | DMA pieces 3, 4, 5 of tile T + 1
-  //   G1 = (0, 1): reads A(1, 0) -> aF[0], B(1) -> bF[1] | DMA pieces 6, 7 of tile T + 1
-  //   G2 = (1, 0): reads A(1, 1) -> aF[1]; then vmcnt(0) (tile T + 1 landed), lgkmcnt(0) (tile T read), s_barrier
-  //   G3 = (1, 1): reads A(0, 0), B(0) of tile T + 1  | DMA pieces 0, 1, 2 of tile T + 2 (stage S is free: barrier)
-  // RAW: tile T + 1 is read after the barrier that follows every wave's vmcnt(0).  WAR: stage S is overwritten after the
-  // barrier that follows every wave's last read of it.
-  bf16x8 aF[2][4], bF[2][2][2];
-#define LDS_FRAG(ADDR) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ADDR))
-#define RD_A(BUF, KS, HA, SB)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-    aF[BUF][i] = LDS_FRAG((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + ((KS) ? sw1 : sw0));
-#define RD_B(BUF, KS, SB)                                                                         \
-  _Pragma("unroll") for (int hb = 0; hb < 2; ++hb)                                                \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-    bF[BUF][hb][j] = LDS_FRAG((SB) + hb * HALF_BYTES + b_off + j * 2048 + ((KS) ? sw1 : sw0));
-#define MFMA_BLK(BB, AB, HA)                                                                      \
-  _Pragma("unroll") for (int hb = 0; hb < 2; ++hb)                                                \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-    acc[HA][hb][i][j] = kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[BB][hb][j], aF[AB][i], acc[HA][hb][i][j], 0, 0, 0) \
-                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[AB][i], bF[BB][hb][j], acc[HA][hb][i][j], 0, 0, 0);
-  // piece D (0..7) of a tile: half D >> 1 in the order A0 B0 B1 A1, 1-KiB piece D & 1
-#define PIECE(D, KT, STAGE)                                                                       \
-  do {                                                                                            \
-    constexpr int half_ = ((D) >> 1) == 0 ? 0 : ((D) >> 1) == 1 ? 2 : ((D) >> 1) == 2 ? 3 : 1;    \
-    dma16(src[half_][(D) & 1] + (size_t)(KT) * BK, my_piece + (STAGE) * STAGE_BYTES + half_ * HALF_BYTES + ((D) & 1) * 1024); \
-  } while (0)
-  // the scheduler's order inside a block: one MFMA, then at most one LDS read, a DMA after MFMAs 2 / 7 / 12
-#define INTERLEAVE(NREADS, NDMA)                                                                  \
-  _Pragma("unroll") for (int n = 0; n < 16; ++n) {                                                \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-    if (n < (NREADS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
-    if ((NDMA) == 4 ? (n & 3) == 1 : ((n == 2 && (NDMA) > 0) || (n == 7 && (NDMA) > 1) || (n == 12 && (NDMA) > 2))) \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
-  }
-#define TILE(T, S, MORE1, MORE2)                                                                  \
-  {                                                                                               \
-    const char* sb = smem + (S) * STAGE_BYTES;                                                    \
-    const char* sn = smem + ((S) ^ 1) * STAGE_BYTES;                                              \
-    /* G0 */                                                                                      \
-    RD_A(1, 0, 1, sb)                                                                             \
-    if (MORE1) { if (G256_PIPE == 2) PIECE(7, (T) + 1, (S) ^ 1); else PIECE(3, (T) + 1, (S) ^ 1);                     \
-                 PIECE(4, (T) + 1, (S) ^ 1); PIECE(5, (T) + 1, (S) ^ 1); if (G256_PIPE == 2) PIECE(6, (T) + 1, (S) ^ 1); } \
-    MFMA_BLK(0, 0, 0)                                                                             \
-    INTERLEAVE(4, (MORE1) ? (G256_PIPE == 2 ? 4 : 3) : 0)                                         \
-    /* G1 */                                                                                      \
-    RD_A(0, 1, 0, sb)                                                                             \
-    RD_B(1, 1, sb)                                                                                \
-    if (MORE1 && G256_PIPE != 2) { PIECE(6, (T) + 1, (S) ^ 1); PIECE(7, (T) + 1, (S) ^ 1); }      \
-    MFMA_BLK(0, 1, 1)                                                                             \
-    INTERLEAVE(8, (MORE1 && G256_PIPE != 2) ? 2 : 0)                                              \
-    /* G2 */                                                                                      \
-    RD_A(1, 1, 1, sb)                                                                             \
-    MFMA_BLK(1, 0, 0)                                                                             \
-    INTERLEAVE(4, 0)                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (MORE1) {                                                                                  \
-      wait_vm<0>();                                                                               \
-      lds_reads_done_then_barrier();                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                          \
-      /* G3, with the next tile's first fragments */                                              \
-      RD_A(0, 0, 0, sn)                                                                           \
-      RD_B(0, 0, sn)                                                                              \
-      if (MORE2) { PIECE(0, (T) + 2, (S)); PIECE(1, (T) + 2, (S)); PIECE(2, (T) + 2, (S));        \
-                   if (G256_PIPE == 2) PIECE(3, (T) + 2, (S)); }                                  \
-    }                                                                                             \
-    MFMA_BLK(1, 1, 1)                                                                             \
-    INTERLEAVE((MORE1) ? 8 : 0, (MORE2) ? (G256_PIPE == 2 ? 4 : 3) : 0)                           \
-  }
-
-  const int nk = g.K / BK;  // >= 2 (gemm256_applicable)
-  // ---- prologue: all of tile 0, pieces 0..2 of tile 1; tile 0's first fragments
-#pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    const int half_ = (d >> 1) == 0 ? 0 : (d >> 1) == 1 ? 2 : (d >> 1) == 2 ? 3 : 1;
-    dma16(src[half_][d & 1], my_piece + half_ * HALF_BYTES + (d & 1) * 1024);
-  }
-  PIECE(0, 1, 1);
-  PIECE(1, 1, 1);
-  PIECE(2, 1, 1);
-  if (G256_PIPE == 2) {  // (variant: four pieces in G3, four in G0, none in G1 - a block more for the last ones to land)
-    PIECE(3, 1, 1);
-    wait_vm<4>();
-  } else {
-    wait_vm<3>();
-  }
-  raw_barrier();
-  RD_A(0, 0, 0, smem)
-  RD_B(0, 0, smem)
-  if (G256_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(1);
-  int t = 0;
-  for (; t + 2 < nk; ++t) TILE(t, t & 1, true, true)
-  TILE(t, t & 1, true, false)
-  ++t;
-  TILE(t, t & 1, false, false)
-  if (G256_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(0);
-#undef RD_A
-#undef RD_B
-#undef MFMA_BLK
-#undef PIECE
-#undef INTERLEAVE
-#undef TILE
-#undef LDS_FRAG
-#undef STAGE_HALF
+#if G256_PIPE || G256_BAL || G256_SPLIT || G256_ABL || G256_PRIO || !G256_DMA_AFTER
+#include "gemm256_experiments.inc"
 #else
-  bf16x8 af[2][4];                  // [k step][row fragment] of the A half in use
-  bf16x8 b0x[2][2], b1[2][2];       // [k step][column fragment] of B half 0 / 1
-#if G256_BAL
-  bf16x8 b0y[2][2];                 // B half 0 of the NEXT K tile (fetched while this tile's last quadrant still uses b0x)
-#endif
-
+  bf16x8 af[2][4];             // [k step][row fragment] of the A half in use
+  bf16x8 b0x[2][2], b1[2][2];  // [k step][column fragment] of B half 0 / 1
 #define LDS_FRAG(ADDR) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ADDR))
 #define READ_A(HA, SB)                                                               \
-  if (!((G256_ABL == 2 || (G256_ABL >= 4 && G256_ABL != 8)) && abl_skip)) {                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
-      af[0][i] = LDS_FRAG((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + sw0);        \
-      af[1][i] = LDS_FRAG((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + sw1);        \
-    }                                                                                \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+    af[0][i] = LDS_FRAG((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + sw0);          \
+    af[1][i] = LDS_FRAG((SB) + (HA) * HALF_BYTES + a_off + i * 2048 + sw1);          \
   }
 #define READ_B(DST, HB, SB)                                                          \
-  if (!((G256_ABL == 2 || (G256_ABL >= 4 && G256_ABL != 8)) && abl_skip)) {                                                \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                  \
-      DST[0][j] = LDS_FRAG((SB) + (HB) * HALF_BYTES + b_off + j * 2048 + sw0);       \
-      DST[1][j] = LDS_FRAG((SB) + (HB) * HALF_BYTES + b_off + j * 2048 + sw1);       \
-    }                                                                                \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                    \
+    DST[0][j] = LDS_FRAG((SB) + (HB) * HALF_BYTES + b_off + j * 2048 + sw0);         \
+    DST[1][j] = LDS_FRAG((SB) + (HB) * HALF_BYTES + b_off + j * 2048 + sw1);         \
   }
-#define STAGE_IN_LOOP(HALF, KT, STAGE)                       \
-  do {                                                       \
-    if (!((G256_ABL == 1 || (G256_ABL >= 4 && G256_ABL != 7)) && abl_skip)) STAGE_HALF(HALF, KT, STAGE); \
-  } while (0)
-// one read segment: a half tile's DMA and this phase's fragment reads, in either order (G256_DMA_AFTER)
-#if G256_DMA_AFTER
-#define READ_SEGMENT(DMA, READS) READS DMA
-#else
-#define READ_SEGMENT(DMA, READS) DMA READS
-#endif
 #define SEGMENT_END()                          \
   do {                                         \
     lds_reads_done_then_barrier();             \
     __builtin_amdgcn_sched_barrier(0);         \
-    if (G256_PRIO == 1) __builtin_amdgcn_s_setprio(1); \
   } while (0)
 #define MFMA_END()                             \
   do {                                         \
-    if (G256_PRIO == 1) __builtin_amdgcn_s_setprio(0); \
     if (STAGGER) {                             \
       __builtin_amdgcn_sched_barrier(0);       \
       raw_barrier();                           \
       __builtin_amdgcn_sched_barrier(0);       \
     }                                          \
   } while (0)
-#if G256_ABL == 5
-  // MFMA-only timing with the 32x32x16 shape: the same flops per quadrant as 8 instructions on 2 accumulators
-  f32x16 acc32[2][2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc32[a][b][j][r] = 0.f;
 #define MFMA_QUAD(HA, HB, BF)                                                                                   \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-    acc32[HA][HB][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks][j], af[ks][i * 2 + j], acc32[HA][HB][j], 0, 0, 0);
-#elif G256_ABL == 6
-  // the same with 8 independent accumulators per quadrant-time (what a 4 x 2 layout of 32x32 tiles per wave would give)
-  f32x16 acc32[2][2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc32[a][b][j][r] = 0.f;
-#define MFMA_QUAD(HA, HB, BF)                                                                                   \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-    acc32[ks][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks][j], af[ks][i * 2 + j], acc32[ks][i][j], 0, 0, 0);
-#else
-#define MFMA_QUAD(HA, HB, BF)                                                                                   \
-  if (!((G256_ABL == 3 || G256_ABL >= 7) && abl_skip)) {                                                                           \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
     acc[HA][HB][i][j] = kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ks][j], af[ks][i], acc[HA][HB][i][j], 0, 0, 0) \
-                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[HA][HB][i][j], 0, 0, 0); \
-  }
-#endif
+                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[HA][HB][i][j], 0, 0, 0);
 
   const int nk = g.K / BK;
-#if G256_ABL
-  // timing ablations (results are WRONG): one class of instructions is skipped inside the main loop behind a condition the
-  // compiler cannot fold; the fragments / stages keep the prologue's data
-  const bool abl_skip = g.M != -12345;
-#else
-  constexpr bool abl_skip = false;
-#endif
   // ---- prologue: all of tile 0, then A0 B0 B1 of tile 1 (its A1 is staged by phase 1 of tile 0)
   STAGE_HALF(0, 0, 0);
   STAGE_HALF(2, 0, 0);
@@ -391,170 +219,46 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
     STAGE_HALF(0, 1, 1);
     STAGE_HALF(2, 1, 1);
     STAGE_HALF(3, 1, 1);
-#if G256_BAL == 2
-    STAGE_HALF(1, 1, 1);
-    wait_vm<8>();
-#else
     wait_vm<6>();
-#endif
   } else {
     wait_vm<0>();
   }
   raw_barrier();
-#if G256_ABL
-  {
-    constexpr bool abl_skip = false;  // (shadows: the ablated loops start from real fragments)
-    READ_A(0, smem)
-    READ_B(b0x, 0, smem)
-    READ_B(b1, 1, smem)
-  }
-#endif
-#if G256_BAL
-  READ_B(b0x, 0, smem)  // tile 0's B half 0; later tiles' are fetched in the previous tile's phase 4
-#endif
-  // Every phase is two segments, [stage + fragment reads] | barrier | [16 MFMAs] | barrier.  The wr = 1 waves run one
-  // barrier behind the wr = 0 waves (each SIMD hosts one wave of either group), so while one wave of a SIMD issues
-  // its MFMAs the other one does its LDS reads, and the matrix pipe never waits for a read segment.  The hazard
-  // rules of the header still hold with one barrier of slack less: a half tile is re-staged in the read segment after
-  // the one (two barriers earlier for the same wave, one for the other group) in which it was last read, and tile
-  // t + 1 is waited for in phase 4's first segment and read two barriers later.
-  if (G256_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise
+  // Every phase is two segments, [fragment reads + one half tile's DMA] | barrier | [16 MFMAs] | barrier.  The wr = 1 waves
+  // run one barrier behind the wr = 0 waves (each SIMD hosts one wave of either group), so while one wave of a SIMD issues
+  // its MFMAs the other one does its LDS reads, and the matrix pipe never waits for a read segment.  The hazard rules of
+  // the header still hold with one barrier of slack less: a half tile is re-staged in the read segment after the one (two
+  // barriers earlier for the same wave, one for the other group) in which it was last read, and tile t + 1 is waited for
+  // in phase 4's first segment and read two barriers later.  Inside a read segment the fragment reads come FIRST: their
+  // latency then runs under the ~120 cycles that the DMA's issue takes (the group's four waves queue their 1-KiB pieces
+  // on the CU's one vector-memory path right after the barrier): -9 % cycles per K tile, profiles/EXPERIMENTS.md.
   if (STAGGER && wr == 1) raw_barrier();
-
-#if G256_BAL
-  // Balanced read segments: 8 / 4 / 8 / 4 fragment reads per phase instead of 12 / 4 / 8 / 0.  The B half 0 of tile T + 1
-  // is read in phase 4 of tile T into the other b0 register set; for that, its DMAs (issued a whole tile earlier, in phase
-  // 3 of tile T - 1) are retired by the counted wait of phase 3 - two barriers before any wave reads them, as the
-  // staggered groups need (group 1 waits one barrier later than group 0 and reads one barrier later).
-  //   issue order of a wave's DMAs: ... B0(T+1) | B1(T+1) A1(T+1) A0(T+2) B0(T+2)  -> vmcnt(8) in phase 3 retires B0(T+1)
-  //   (and A0(T+1) before it); vmcnt(6) in phase 4 retires B1(T+1), A1(T+1) as before.
-#if G256_BAL == 2
-  // DMAs only in the two light read segments (4 fragment reads each): phase 2 stages A0, B0 and phase 4 B1, A1 of tile
-  // T + 2 - four 1-KiB pieces each - so that the 8-read segments of phases 1 and 3 carry none.  Issue order
-  //   ... A0(T+1) B0(T+1) | B1(T+1) A1(T+1) | A0(T+2) B0(T+2) | B1(T+2) A1(T+2): vmcnt(8) in phase 3 (after phase 2's
-  // issues) retires A0, B0 of T + 1; vmcnt(8) in phase 4 (after its own issues) retires B1, A1 of T + 1.
-#define TILE(T, S, BCUR, BNEXT)                                                                   \
-  {                                                                                               \
-    const char* sb = smem + (S) * STAGE_BYTES;                                                    \
-    const char* sn = smem + ((S) ^ 1) * STAGE_BYTES;                                              \
-    const bool more1 = (T) + 1 < nk, more2 = (T) + 2 < nk;                                        \
-    READ_A(0, sb)                                                                                 \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(0, 0, BCUR)                                                                         \
-    MFMA_END();                                                                                   \
-    READ_SEGMENT(if (more2) { STAGE_IN_LOOP(0, (T) + 2, (S)); STAGE_IN_LOOP(2, (T) + 2, (S)); }, READ_B(b1, 1, sb)) \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(0, 1, b1)                                                                           \
-    MFMA_END();                                                                                   \
-    READ_A(1, sb)                                                                                 \
-    if (more2) wait_vm<8>(); else wait_vm<4>();                                                   \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(1, 1, b1)                                                                           \
-    MFMA_END();                                                                                   \
-    READ_SEGMENT(if (more2) { STAGE_IN_LOOP(3, (T) + 2, (S)); STAGE_IN_LOOP(1, (T) + 2, (S)); }, if (more1) { READ_B(BNEXT, 0, sn) }) \
-    if (more2) wait_vm<8>(); else wait_vm<0>();                                                   \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(1, 0, BCUR)                                                                         \
-    MFMA_END();                                                                                   \
-  }
-#else
-#define TILE(T, S, BCUR, BNEXT)                                                                   \
-  {                                                                                               \
-    const char* sb = smem + (S) * STAGE_BYTES;                                                    \
-    const char* sn = smem + ((S) ^ 1) * STAGE_BYTES;                                              \
-    const bool more1 = (T) + 1 < nk, more2 = (T) + 2 < nk;                                        \
-    /* phase 1: quadrant (0, 0) */                                                                \
-    READ_SEGMENT(if (more1) STAGE_IN_LOOP(1, (T) + 1, (S) ^ 1);, READ_A(0, sb))                   \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(0, 0, BCUR)                                                                         \
-    MFMA_END();                                                                                   \
-    /* phase 2: quadrant (0, 1) */                                                                \
-    READ_SEGMENT(if (more2) STAGE_IN_LOOP(0, (T) + 2, (S));, READ_B(b1, 1, sb))                   \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(0, 1, b1)                                                                           \
-    MFMA_END();                                                                                   \
-    /* phase 3: quadrant (1, 1); retire A0 and B0 of tile T + 1 */                                \
-    READ_SEGMENT(if (more2) STAGE_IN_LOOP(2, (T) + 2, (S));, READ_A(1, sb))                       \
-    if (more2) wait_vm<8>(); else wait_vm<4>();                                                   \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(1, 1, b1)                                                                           \
-    MFMA_END();                                                                                   \
-    /* phase 4: quadrant (1, 0); retire the rest of tile T + 1; fetch its B half 0 */             \
-    READ_SEGMENT(if (more2) STAGE_IN_LOOP(3, (T) + 2, (S));, if (more1) { READ_B(BNEXT, 0, sn) }) \
-    if (more2) wait_vm<6>(); else wait_vm<0>();                                                   \
-    SEGMENT_END();                                                                                \
-    MFMA_QUAD(1, 0, BCUR)                                                                         \
-    MFMA_END();                                                                                   \
-  }
-#endif
-  for (int t = 0; t < nk; ++t) {
-    const int s = t & 1;
-    TILE(t, s, b0x, b0y)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b0x[ks][j] = b0y[ks][j];  // 16 register moves per K tile (an unrolled-by-2 loop spills)
-  }
-#undef TILE
-#elif G256_SPLIT
-  // A half tile's two DMA pieces in different segments: piece 0 at the end of the read segment, piece 1 between the two
-  // k steps of the MFMA segment - half the burst each time the four waves of a group come out of a barrier together (the
-  // CU's vector memory path takes one 1-KiB piece per ~16 clk; a wave stands still until its piece is accepted).
-  // Issue order per wave: ... A1(t+1).0 .1 | A0(t+2).0 .1 | B0(t+2).0 .1 | B1(t+2).0 <wait> .1: vmcnt(5) retires tile t + 1.
-#define PIECE1(HALF, J, KT, STAGE) \
-  dma16(src[HALF][J] + (size_t)(KT) * BK, my_piece + (STAGE) * STAGE_BYTES + (HALF) * HALF_BYTES + (J) * 1024)
-#define MFMA_KS(HA, HB, BF, KS)                                                                                 \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-    acc[HA][HB][i][j] = kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[KS][j], af[KS][i], acc[HA][HB][i][j], 0, 0, 0) \
-                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[KS][i], BF[KS][j], acc[HA][HB][i][j], 0, 0, 0);
-#define PHASE(READS, COND, HALF, KT, STAGE, WAIT, HA, HB, BF)   \
-  READS                                                         \
-  if (COND) PIECE1(HALF, 0, KT, STAGE);                         \
-  WAIT                                                          \
-  SEGMENT_END();                                                \
-  MFMA_KS(HA, HB, BF, 0)                                        \
-  __builtin_amdgcn_sched_barrier(0);                            \
-  if (COND) PIECE1(HALF, 1, KT, STAGE);                         \
-  __builtin_amdgcn_sched_barrier(0);                            \
-  MFMA_KS(HA, HB, BF, 1)                                        \
-  MFMA_END();
-  for (int t = 0; t < nk; ++t) {
-    const int s = t & 1;
-    const char* sb = smem + s * STAGE_BYTES;
-    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
-    PHASE(READ_B(b0x, 0, sb) READ_A(0, sb), more1, 1, t + 1, s ^ 1, , 0, 0, b0x)
-    PHASE(READ_B(b1, 1, sb), more2, 0, t + 2, s, , 0, 1, b1)
-    PHASE(READ_A(1, sb), more2, 2, t + 2, s, , 1, 1, b1)
-    PHASE(, more2, 3, t + 2, s, if (more2) wait_vm<5>(); else wait_vm<0>();, 1, 0, b0x)
-  }
-#undef PIECE1
-#undef MFMA_KS
-#undef PHASE
-#else
   for (int t = 0; t < nk; ++t) {
     const int s = t & 1;
     const char* sb = smem + s * STAGE_BYTES;
     const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
     // phase 1: quadrant (0, 0)
-    READ_SEGMENT(if (more1) STAGE_IN_LOOP(1, t + 1, s ^ 1);,  // A1 of the other stage: last read in phase 3 of tile t - 1
-                 READ_B(b0x, 0, sb) READ_A(0, sb))
+    READ_B(b0x, 0, sb)
+    READ_A(0, sb)
+    if (more1) STAGE_HALF(1, t + 1, s ^ 1);  // A1 of the other stage: last read in phase 3 of tile t - 1
     SEGMENT_END();
     MFMA_QUAD(0, 0, b0x)
     MFMA_END();
     // phase 2: quadrant (0, 1)
-    READ_SEGMENT(if (more2) STAGE_IN_LOOP(0, t + 2, s);, READ_B(b1, 1, sb))  // A0: read in phase 1
+    READ_B(b1, 1, sb)
+    if (more2) STAGE_HALF(0, t + 2, s);  // A0: read in phase 1
     SEGMENT_END();
     MFMA_QUAD(0, 1, b1)
     MFMA_END();
     // phase 3: quadrant (1, 1)
-    READ_SEGMENT(if (more2) STAGE_IN_LOOP(2, t + 2, s);, READ_A(1, sb))  // B0: read in phase 1
+    READ_A(1, sb)
+    if (more2) STAGE_HALF(2, t + 2, s);  // B0: read in phase 1
     SEGMENT_END();
     MFMA_QUAD(1, 1, b1)
     MFMA_END();
     // phase 4: quadrant (1, 0); retire tile t + 1 (everything issued before the last three halves)
     if (more2) {
-      STAGE_IN_LOOP(3, t + 2, s);  // B1: read in phase 2
+      STAGE_HALF(3, t + 2, s);  // B1: read in phase 2
       wait_vm<6>();
     } else {
       wait_vm<0>();
@@ -563,35 +267,21 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
     MFMA_QUAD(1, 0, b0x)
     MFMA_END();
   }
-#endif
-  if (G256_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(0);
   if (STAGGER && wr == 0) raw_barrier();
 #undef STAGE_HALF
-#undef STAGE_IN_LOOP
-#undef READ_SEGMENT
 #undef READ_A
 #undef READ_B
 #undef LDS_FRAG
 #undef MFMA_QUAD
 #undef SEGMENT_END
 #undef MFMA_END
-#endif  // G256_PIPE
 #if G256_CLK
   if (blockIdx.x == 0 && tid == 0) {
     g256_clk[0] = __builtin_readcyclecounter() - clk_c0;
     g256_clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
   }
 #endif
-#if G256_ABL == 5 || G256_ABL == 6
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r & 3][j][r >> 2] = acc32[a][b][j][r];
-#endif
+#endif  // experiments
 
   if constexpr (EPI == GEMM_LOGPROB) {
     // Log-softmax pieces of this tile, nothing stored (transformer.py:235-242 + generate.py:101-118: the LM head's
