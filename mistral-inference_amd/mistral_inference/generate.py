@@ -114,7 +114,8 @@ def generate(
     gen_lp: List[torch.Tensor] = []
     is_finished = torch.zeros(B, dtype=torch.bool, device=dev)
     assert last_token_prelogits is not None
-    fused_greedy = (temperature == 0 and max_tokens > 0 and hasattr(model, "greedy_session") and dev.type == "cuda"
+    fused_greedy = (temperature == 0 and max_tokens > 0 and hasattr(model, "greedy_session")
+                    and (dev.type == "cuda" or getattr(model, "greedy_session_any_device", False))  # (CPU stand-ins: tests)
                     and getattr(model, "num_pipeline_ranks", 1) == 1 and getattr(model, "softmax_fp32", True)
                     and getattr(model, "fused_greedy", True))  # (model.fused_greedy = False: the loop below, for A/B)
     if fused_greedy:

@@ -147,6 +147,74 @@ def test_generate_eos_and_sampling():
     assert all(len(t) == 3 for t in toks) and all(x <= 0 for l in lps for x in l)
 
 
+@pytest.mark.parametrize("name", ["dense_fp32", "swa_chunk_fp32"])
+def test_generate_fused_greedy_bookkeeping(name):
+    """generate()'s temperature-0 route through a greedy session (first sample from the prompt's last logits, then chunks of
+    session steps read back at once, EOS cut inside a chunk) with a CPU stand-in for `GreedySession`: tokens and logprobs
+    must equal the reference's, with and without an eos_id, for every cut position."""
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.generate import generate
+    from mistral_inference.transformer import Transformer
+
+    class CpuSession:
+        HIST = 1024
+
+        def __init__(self, model, cache, first):
+            self.m, self.cache, self.tok, self.out = model, cache, first.clone(), []
+
+        def run(self, n):
+            for _ in range(n):
+                logits = self.m.forward(self.tok, [1] * self.tok.numel(), self.cache)
+                self.tok = torch.argmax(logits, dim=-1)
+                lp = torch.log_softmax(logits, dim=-1).gather(1, self.tok[:, None])[:, 0]
+                self.out.append((self.tok.clone(), lp))
+
+        def collect(self, n):
+            got, self.out = self.out[:n], self.out[n:]
+            assert len(got) == n
+            return torch.stack([t for t, _ in got]), torch.stack([l for _, l in got])
+
+    class CpuGreedy(Transformer):
+        greedy_session_any_device = True
+        sessions = 0
+
+        def greedy_session(self, cache, first_tokens, graph=True):
+            CpuGreedy.sessions += 1
+            return CpuSession(self, cache, first_tokens)
+
+    case = Case(name)
+    a = TransformerArgs.from_dict(case.params)
+    a.max_batch_size = case.max_batch_size
+    m = CpuGreedy(a, backend=OracleStackBackend())
+    m.load_state_dict(case.weights(), assign=True)
+    toks, lps = generate(case.prompts, m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size)
+    assert CpuGreedy.sessions >= 1 and toks == case.tokens()
+    for x, y in zip(lps, case.logprobs()):
+        assert len(x) == len(y) and max(abs(p - q) for p, q in zip(x, y)) < 2e-5
+    # EOS: the reference stops BEFORE the step at which every sequence has produced eos (generate.py:128-132); with one
+    # sequence that is the position of the first eos, whichever token of the run is declared eos
+    ref = case.tokens()[0]
+    for cut in range(len(ref)):
+        eos = ref[cut]
+        first = ref.index(eos)
+        t1, l1 = generate(case.prompts[:1], m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size, eos_id=eos)
+        assert t1 == ([ref[:first]] if first else []), (cut, t1)
+        assert len(l1[0]) == len(case.prompts[0]) - 1 + first
+    # several sequences: generation continues until ALL have hit eos - same tokens and logprobs as the host loop
+    seen = sorted({t for r in case.tokens() for t in r})
+    for eos in seen[:6]:
+        m.fused_greedy = True
+        tf, lf = generate(case.prompts, m, max_tokens=case.max_tokens + 2, temperature=0.0, chunk_size=case.chunk_size, eos_id=eos)
+        m.fused_greedy = False
+        th, lh = generate(case.prompts, m, max_tokens=case.max_tokens + 2, temperature=0.0, chunk_size=case.chunk_size, eos_id=eos)
+        assert tf == th, (eos, tf, th)
+        assert all(len(x) == len(y) and max([abs(p - q) for p, q in zip(x, y)] + [0]) < 2e-5 for x, y in zip(lf, lh))
+    m.fused_greedy = True
+    # one token asked for: the session is created but never stepped
+    t0, _ = generate(case.prompts, m, max_tokens=1, temperature=0.0, chunk_size=case.chunk_size)
+    assert t0 == [r[:1] for r in case.tokens()]
+
+
 def test_interleave_kv_and_unrotate_semantics():
     """CacheView.interleave_kv (reference cache.py:94-117): per sequence its cached tokens in position order (ring
     unrotated, at most W of them) followed by its new tokens; rings that have not wrapped, wrapped exactly, and wrapped
