@@ -24,3 +24,20 @@ def test_prefill_flops_matches_survey_table():
     assert abs(f7 / 1e12 - 62.7) < 0.4                        # 57.2 (layers) + 1.1 (LM head) + 4.4 (attention)
     mix = bench.prefill_flops(dict(bench.PRESETS["mixtral-8x7b"][0]), 4096)
     assert abs(mix / 1e12 - 108.9) < 1.5
+
+
+def test_cpu_baseline_carries_the_stored_reference_number(monkeypatch):
+    """On a box without the reference source (the GPU lease) the baseline is the oracle port's, and - for the headline dims
+    only - the unmodified reference's number measured once on the build container rides along in the same object."""
+    port = {"value": 2.0, "unit": "tokens/s", "cores": 8, "kind": "port", "sample": "stub"}
+    monkeypatch.setattr(bench, "reference_baseline", lambda *a, **k: None)
+    monkeypatch.setattr(bench, "port_baseline", lambda *a, **k: dict(port))
+    out = bench.cpu_baseline(dict(bench.MISTRAL_7B), 4096)
+    assert out["kind"] == "port" and out["value"] == 2.0
+    assert out["reference_container_value"] == 0.739 and out["reference_container_cores"] == 8
+    other = bench.cpu_baseline(dict(bench.PRESETS["mixtral-8x7b"][0]), 4096)
+    assert "reference_container_value" not in other
+    # where the reference can be timed it IS the baseline, with the port's number alongside
+    monkeypatch.setattr(bench, "reference_baseline", lambda *a, **k: {"value": 0.7, "kind": "reference", "cores": 8})
+    ref = bench.cpu_baseline(dict(bench.MISTRAL_7B), 4096)
+    assert ref["kind"] == "reference" and ref["port_value"] == 2.0
