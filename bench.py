@@ -309,7 +309,7 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
             sync()
             dt, left = 0.0, K
             while left > 0:                      # (the session's history ring holds 1024 steps between collects)
-                n = min(left, sess.HIST)
+                n = min(left, sess.HIST - sess._pending)  # (the two warm-up steps above are still uncollected)
                 t0 = time.perf_counter()
                 sess.run(n)
                 sync()
