@@ -137,7 +137,7 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
     group = model.args.n_heads // model.args.n_kv_heads
     return {"bound": "hbm", "kernel": f"decode_engine_kernel<{group}> (persistent: all layers + LM head + sample of one decode step in one launch)",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch,
+            "traffic": traffic, "traffic_static": True, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(us, 2), "launches_timed": iters}
 
 
@@ -172,7 +172,7 @@ def dominant_kernel_roofline(model, iters: int) -> dict:
     traffic, traffic_src = _pmc_traffic("gemv_kernel", (a.dim, a.hidden_dim) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"]))
     return {"bound": "hbm", "kernel": "gemv_kernel<1,SWIGLU> (RMSNorm + W1|W3 GEMV + SiLU*mul)", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
+            "traffic_static": True, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
             "launches_timed": n}
 
 
@@ -283,14 +283,17 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
         # reset cache; includes the [T, V] fp32 LM head the API contract requires
         logits = model.forward(prompt, [T0], cache)
         del logits
-        cache.reset()
-        sync()
-        t0 = time.perf_counter()
-        logits = model.forward(prompt, [T0], cache)
-        sync()
-        prefill_s = time.perf_counter() - t0
-        nxt = torch.argmax(logits[-1:], dim=-1)
-        del logits
+        prefill_all = []
+        for _ in range(3):  # three timed passes, the MEDIAN is reported (a single sample of a power-capped quantity is noise)
+            cache.reset()
+            sync()
+            t0 = time.perf_counter()
+            logits = model.forward(prompt, [T0], cache)
+            sync()
+            prefill_all.append(time.perf_counter() - t0)
+            nxt = torch.argmax(logits[-1:], dim=-1)
+            del logits
+        prefill_s = sorted(prefill_all)[1]
         # ---- decode: the generate() loop body - forward(next_token, [1], cache) under the decode hipGraph context
         # (capture happens inside the warm-up steps; W >= 2 keeps it out of the timed region)
         if world == 1 and opt.loop == "greedy":
@@ -307,16 +310,19 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
                 sess.collect()
             sess.run(2)
             sync()
-            dt, left = 0.0, K
+            dt, left, collect_s = 0.0, K, 0.0
             while left > 0:                      # (the session's history ring holds 1024 steps between collects)
                 n = min(left, sess.HIST - sess._pending)  # (the two warm-up steps above are still uncollected)
                 t0 = time.perf_counter()
                 sess.run(n)
                 sync()
-                dt += time.perf_counter() - t0
+                t1 = time.perf_counter()
+                dt += t1 - t0
                 toks, _ = sess.collect()         # verifies that the device completed every step (and which path ran)
+                collect_s += time.perf_counter() - t1   # generate() pays this once per chunk (32 steps with an eos_id, else 1024)
                 left -= n
             nxt = toks[-1]
+            timed_run.collect_s = collect_s
         else:
             # the sampling loop's body (temperature > 0, or pipeline stages): forward() under the decode hipGraph + torch.argmax
             ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
@@ -333,7 +339,20 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
         tmax = torch.tensor([dt, prefill_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt, prefill_s = tmax.tolist()
+    timed_run.prefill_all = prefill_all
     return model, cache, nxt, dt, prefill_s
+
+
+def respawn_under_torchrun(n: int) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface (the container hostname may not resolve)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main() -> None:
@@ -351,6 +370,11 @@ def main() -> None:
     ap.add_argument("--no-mixtral", action="store_true", help="N > 1: skip the Mixtral sub-measurement")
     ap.add_argument("--mixtral-layers", type=int, default=None, help="debug only: layers of the N > 1 Mixtral sub-measurement")
     opt = ap.parse_args()
+
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, RCCL over xGMI) exactly as the
+        # documented torch.distributed.run line would, and let rank 0 of that job print the JSON line
+        sys.exit(respawn_under_torchrun(opt.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -408,10 +432,15 @@ def main() -> None:
                        f"{torch.distributed.get_backend()})"},
             "hbm_roofline_step": {"bytes_per_token": step_bytes, "achieved_GBs": round(step_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                                   "frac": round(step_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_6290": round(step_gbs / 6290.0, 4)},
-            "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "tokens_per_s": round(T0 / prefill_s, 1),
+            "prefill": {"tokens": T0, "seconds": round(prefill_s, 4), "timing": "median of 3 timed passes",
+                        "seconds_all": [round(x, 4) for x in getattr(timed_run, "prefill_all", [])],
+                        "tokens_per_s": round(T0 / prefill_s, 1),
                         "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
                         "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
         }
+        if world == 1 and opt.loop == "greedy":
+            # not inside the K-step bracket: the once-per-chunk read-back of the samples (status copy + host sync + gather)
+            out["collect_ms_per_chunk"] = round(getattr(timed_run, "collect_s", 0.0) * 1e3, 3)
         # the dominant kernel is timed on this rank's own layers (any N)
         if engine["engine_launches"] > 0 and world == 1:
             with torch.inference_mode():

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
@@ -98,6 +98,19 @@ int mi_lm_head_logprobs(float* logprob, const void* x, int ldx, int M, int K, co
  * (torch.argmax), logprob[b] = log_softmax(row)[token[b]] - one block per row.  mi_forward fuses the same reduction
  * behind its LM head (mi_batch_t.greedy_token). */
 int mi_greedy_sample(const float* logits, int ld, int B, int vocab, int64_t* token, float* logprob, mi_stream_t stream);
+
+/* generate.py:151-170 `sample` / `sample_top_p` at temperature > 0 for B rows of fp32 logits [B, ld], ONE launch (the
+ * reference: softmax, a sort of the whole vocabulary, cumsum, masked fill, renormalise, torch.multinomial, gathers):
+ *   probs = softmax(row / temperature); the tokens kept are the prefix of the descending order whose mass BEFORE the token
+ *   is <= top_p (generate.py:165-167; ties in probability are ordered by ascending index - torch.sort leaves them
+ *   unspecified); token[b] is drawn from the renormalised kept masses by inverse CDF in that order;
+ *   logprob[b] = log_softmax(row)[token[b]] of the UNSCALED logits (generate.py:134-136).
+ * The uniform variate is Philox4x32-10(seed; counter = offset, row b) unless `uniforms` (device fp32 [B], each in [0, 1))
+ * is given - which is how tests pin a draw.  Masses are 40-bit fixed point: the result is bit-reproducible for a given
+ * seed/offset (torch.multinomial's own stream cannot be reproduced; parity is distributional, tests/test_gpu_sampling.py).
+ * mi_forward fuses the same kernel behind its LM head (mi_batch_t.sample_temperature > 0). */
+int mi_sample_top_p(const float* logits, int ld, int B, int vocab, float temperature, float top_p, uint64_t seed,
+                    uint64_t offset, const float* uniforms, int64_t* token, float* logprob, mi_stream_t stream);
 
 /* Decode-branch attention (transformer_layers.py:77-89 with the mask of cache.py:249-254):
  * one query per sequence, keys = ring slots [0, min(pos+1, W)) of its row, GQA by kv = h / (H/Hkv)
@@ -239,6 +252,17 @@ typedef struct mi_batch {
   int64_t* hist_token;          /* dev [hist_len, B] or NULL */
   float* hist_logprob;          /* dev [hist_len, B] or NULL */
   int32_t hist_len;
+  /* ABI v5 - nucleus sampling instead of the argmax (generate.py:126 `sample(logits, temperature, top_p=0.8)`): with
+   * sample_temperature > 0 the token written to greedy_token / the history ring is DRAWN as mi_sample_top_p describes
+   * (one more small kernel behind the LM head, inside the same captured step), greedy_logprob is its log-probability under
+   * the unscaled logits.  The variate of a step, row b is Philox(sample_seed; sample_offset + n, b) with n = the workspace's
+   * decode-step counter (mi_decode_engine_status word 5) - a device value, so hipGraph replays draw fresh numbers; a caller
+   * that wants the stream of a generation to start at the same point every time passes sample_offset = -(counter at its
+   * start).  sample_temperature == 0: the ABI v4 behaviour (argmax). */
+  float sample_temperature;
+  float sample_top_p;
+  uint64_t sample_seed;
+  uint64_t sample_offset;
 } mi_batch_t;
 
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);
@@ -276,23 +300,8 @@ int mi_decode_engine_reset(void* workspace, mi_stream_t stream);
  * status[5] = decode steps run on this workspace (engine: completed; launch path: started) = next row of the greedy
  * history ring, status[6] = workgroup arrivals of the current engine step, status[7] reserved. */
 int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t status[8]);
-/* Debug timeline of the engine (scripts/engine_trace.py): while a zero-filled device buffer of
- * mi_debug_engine_trace_bytes() bytes is registered, consumer wave 0 and the loader wave of every workgroup stamp a
- * 100 MHz clock at each phase boundary of each layer: trace[cu][layer (32)][event (26)] uint64.  NULL unregisters. */
-size_t mi_debug_engine_trace_bytes(void);
-int mi_debug_set_engine_trace(void* dev_buffer);
-/* Tuning knobs of the engine's loader wave (results never depend on them): while the workgroup's consumers
- * sweep hand-off granules the loader wave stops (thin = 2, shipped), keeps one 16 KiB fill outstanding (1) or streams on
- * (0); depth = fills in flight otherwise (2 or 3).
- * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults.  MI_ENGINE_HOLDERS=0 (environment, read
- * once) runs the engine without its holder waves. */
-int mi_debug_set_engine_knobs(int thin, int depth);
-/* holder waves on (1) / off (0) / environment default (-1); results never depend on it (bit-identical either way) */
-int mi_debug_set_engine_holders(int on);
-/* Test hook: the next `launches` engine launches on this workspace (hipGraph replays included: the count lives in the
- * workspace) wait for one workgroup more than exist, i.e. fail their residency gate after its ~50 ms bound exactly as a
- * launch with a missing workgroup would (status 0x700, nothing written).  Synchronises the stream. */
-int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream);
+/* Engine diagnostics (timeline trace, loader knobs, residency-gate test hook) are NOT part of the product boundary:
+ * include/mistral_hip_debug.h. */
 
 /* ------------------------------------------------------------------------------------------------
  * Pipeline-parallel exchange steps over RCCL (xGMI between the GPUs of a node)

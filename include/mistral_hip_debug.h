@@ -1,0 +1,38 @@
+/*
+ * mistral_hip_debug.h -- diagnostics of libmistral_hip.so's persistent decode engine.
+ *
+ * NOT part of the drop-in boundary (include/mistral_hip.h): nothing a caller of the hot path needs, no reference
+ * counterpart.  Used by scripts/engine_trace.py (phase timeline), the A/B scripts (loader knobs) and
+ * tests/test_gpu_greedy.py (residency-gate sabotage).  Results of mi_forward never depend on any of these.
+ */
+#ifndef MISTRAL_HIP_DEBUG_H
+#define MISTRAL_HIP_DEBUG_H
+
+#include "mistral_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Debug timeline of the engine (scripts/engine_trace.py): while a zero-filled device buffer of
+ * mi_debug_engine_trace_bytes() bytes is registered, consumer wave 0 and the loader wave of every workgroup stamp a
+ * 100 MHz clock at each phase boundary of each layer: trace[cu][layer (32)][event (26)] uint64.  NULL unregisters. */
+size_t mi_debug_engine_trace_bytes(void);
+int mi_debug_set_engine_trace(void* dev_buffer);
+/* Tuning knobs of the engine's loader wave (results never depend on them): while the workgroup's consumers
+ * sweep hand-off granules the loader wave stops (thin = 2, shipped), keeps one 16 KiB fill outstanding (1) or streams on
+ * (0); depth = fills in flight otherwise (2 or 3).
+ * Initial values: MI_ENGINE_THIN / MI_ENGINE_DEPTH, else the shipped defaults.  MI_ENGINE_HOLDERS=0 (environment, read
+ * once) runs the engine without its holder waves. */
+int mi_debug_set_engine_knobs(int thin, int depth);
+/* holder waves on (1) / off (0) / environment default (-1); results never depend on it (bit-identical either way) */
+int mi_debug_set_engine_holders(int on);
+/* Test hook: the next `launches` engine launches on this workspace (hipGraph replays included: the count lives in the
+ * workspace) wait for one workgroup more than exist, i.e. fail their residency gate after its ~50 ms bound exactly as a
+ * launch with a missing workgroup would (status 0x700, nothing written).  Synchronises the stream. */
+int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISTRAL_HIP_DEBUG_H */

@@ -13,10 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
 SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "gemm256.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip",
-           "decode_engine.hip", "rccl_api.hip"]
+           "decode_engine.hip", "sampling.hip", "rccl_api.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
-           os.path.join(CSRC, "attn_decode_core.cuh"), os.path.join(CSRC, "gemm256_experiments.inc"),
-           os.path.join(HERE, "..", "include", "mistral_hip.h")]
+           os.path.join(CSRC, "attn_decode_core.cuh"), os.path.join(HERE, "..", "scripts", "probes", "gemm256_experiments.inc"),
+           os.path.join(HERE, "..", "include", "mistral_hip.h"), os.path.join(HERE, "..", "include", "mistral_hip_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  The persistent decode engine is built with the max-memory-clause scheduling strategy: measured 1.3-1.5 % faster
 # on a good lease and 3 % on a slow one than the default strategy (same-box A/B of five flag variants, profiles/EXPERIMENTS.md) -
@@ -35,7 +35,7 @@ def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
 def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = LIB) -> str:

@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "../../include/mistral_hip.h"
+#include "../../include/mistral_hip_debug.h"
 #include "kernels.h"
 
 namespace {
@@ -453,6 +454,17 @@ int mi_greedy_sample(const float* logits, int ld, int B, int vocab, int64_t* tok
                 "greedy sample");
 }
 
+int mi_sample_top_p(const float* logits, int ld, int B, int vocab, float temperature, float top_p, uint64_t seed,
+                    uint64_t offset, const float* uniforms, int64_t* token, float* logprob, mi_stream_t stream) {
+  if (!logits || !token || !logprob || B <= 0 || vocab <= 0 || ld < vocab) return fail(MI_ERR_ARG, "mi_sample_top_p");
+  if (!(temperature > 0.f) || !(top_p >= 0.f && top_p <= 1.f))
+    return fail(MI_ERR_ARG, "mi_sample_top_p: temperature %g must be > 0 and top_p %g in [0, 1] (generate.py:163)", (double)temperature,
+                (double)top_p);
+  return hip_rc(launch_sample_top_p(logits, ld, B, vocab, temperature, top_p, seed, offset, uniforms, token, logprob, nullptr,
+                                    nullptr, 0, nullptr, (hipStream_t)stream),
+                "top-p sample");
+}
+
 int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream) {
   if (!workspace || launches < 0) return fail(MI_ERR_ARG, "mi_debug_engine_sabotage");
   static thread_local uint32_t v;
@@ -524,6 +536,18 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     return fail(MI_ERR_ARG, "mi_forward: greedy_token needs the DECODE branch, logits and greedy_logprob");
   if (want_greedy && bt->hist_len > 0 && (!bt->hist_token || !bt->hist_logprob))
     return fail(MI_ERR_ARG, "mi_forward: hist_len > 0 without history buffers");
+  // ABI v5: the step's sample is a nucleus draw instead of the argmax (generate.py:126 at temperature > 0)
+  const bool want_topp = want_greedy && bt->sample_temperature > 0.f;
+  if (bt->sample_temperature < 0.f || (want_topp && !(bt->sample_top_p >= 0.f && bt->sample_top_p <= 1.f)))
+    return fail(MI_ERR_ARG, "mi_forward: sample_temperature %g / sample_top_p %g", (double)bt->sample_temperature, (double)bt->sample_top_p);
+  auto sample_step = [&]() -> int {  // behind the LM head of either decode path; reads the step counter the step advanced
+    if (want_topp)
+      return hip_rc(launch_sample_top_p(bt->logits, m->vocab_size, B, m->vocab_size, bt->sample_temperature, bt->sample_top_p,
+                                        bt->sample_seed, bt->sample_offset, nullptr, bt->greedy_token, bt->greedy_logprob, bt->hist_token,
+                                        bt->hist_logprob, bt->hist_len, engine_ctrl, s), "top-p sample");
+    return hip_rc(launch_greedy_rows(bt->logits, m->vocab_size, B, m->vocab_size, bt->greedy_token, bt->greedy_logprob,
+                                     bt->hist_token, bt->hist_logprob, bt->hist_len, engine_ctrl, s), "greedy sample");
+  };
 
   // ---- batch-1 decode step of a dense model: every layer (and the LM head) in ONE persistent launch, which also does
   // the step's bookkeeping (position, embedding row, greedy sample): nothing else is enqueued for the token
@@ -536,7 +560,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     pr.emb = embed ? m->tok_embeddings : nullptr; pr.ids = bt->input_ids; pr.kv_seqlens = bt->kv_seqlens;
     pr.q_start = bt->q_start; pr.kv_before = bt->kv_before; pr.tok_seq = bt->tok_seq; pr.tok_pos = bt->tok_pos;
     pr.final_norm = m->final_norm; pr.output = m->output; pr.logits = bt->logits;
-    if (want_greedy) {
+    if (want_greedy && !want_topp) {  // (a nucleus draw is its own small kernel behind the engine launch, below)
       pr.greedy_tok = bt->greedy_token; pr.greedy_lp = bt->greedy_logprob;
       pr.hist_tok = bt->hist_token; pr.hist_lp = bt->hist_logprob; pr.hist_len = bt->hist_len;
     }
@@ -551,6 +575,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       MI_TRY(hip_rc(launch_decode_engine(pr, s, &declined), "decode engine"));
       if (!declined) {
         if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        if (want_topp) MI_TRY(sample_step());
         return MI_OK;
       }
       snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail());  // informational
@@ -718,8 +743,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
         a.w0 = (const bf16_t*)m->output; a.n0 = a.n1 = m->vocab_size; a.out = bt->logits; a.ldo = m->vocab_size;
         MI_TRY(gemv_passes(a, T, s, "lm head gemv"));
         if (want_greedy)  // generate.py:124-136 at temperature 0, fused behind the LM head (one block per sequence)
-          MI_TRY(hip_rc(launch_greedy_rows(bt->logits, m->vocab_size, B, m->vocab_size, bt->greedy_token, bt->greedy_logprob,
-                                           bt->hist_token, bt->hist_logprob, bt->hist_len, engine_ctrl, s), "greedy sample"));
+          MI_TRY(sample_step());
       } else {
         MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
         GemmArgs g;
@@ -728,8 +752,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
         g.w0 = (const bf16_t*)m->output; g.n0 = g.n1 = m->vocab_size; g.out = bt->logits; g.ldo = m->vocab_size;
         MI_TRY(hip_rc(launch_gemm(g, s), "lm head gemm"));
         if (want_greedy)
-          MI_TRY(hip_rc(launch_greedy_rows(bt->logits, m->vocab_size, B, m->vocab_size, bt->greedy_token, bt->greedy_logprob,
-                                           bt->hist_token, bt->hist_logprob, bt->hist_len, engine_ctrl, s), "greedy sample"));
+          MI_TRY(sample_step());
       }
     } else {
       MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));

@@ -28,7 +28,7 @@
 #include "common.cuh"
 #include "kernels.h"
 
-// Build-time experiment switches (all off in the shipped build; the experimental main loops live in gemm256_experiments.inc):
+// Build-time experiment switches (all off in the shipped build; the experimental main loops live OUTSIDE the product tree, in scripts/probes/gemm256_experiments.inc):
 #ifndef G256_PRIO
 #define G256_PRIO 0
 #endif
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if G256_PIPE || G256_BAL || G256_SPLIT || G256_ABL || G256_PRIO || !G256_DMA_AFTER
-#include "gemm256_experiments.inc"
+#include "../../scripts/probes/gemm256_experiments.inc"  // probe builds only (scripts/build_variants.py gemm): never part of the shipped library
 #else
   bf16x8 af[2][4];             // [k step][row fragment] of the A half in use
   bf16x8 b0x[2][2], b1[2][2];  // [k step][column fragment] of B half 0 / 1

@@ -172,6 +172,12 @@ hipError_t launch_add_rows(void* out, const void* a, const void* b, size_t n, hi
 // history rings when given (ctrl[5] = decode steps started on this workspace, advanced by decode_prep).
 hipError_t launch_greedy_rows(const float* logits, int ld, int B, int V, int64_t* tok, float* lp, int64_t* hist_tok,
                               float* hist_lp, int hist_len, const uint32_t* ctrl, hipStream_t s);
+// Nucleus sampling of B logits rows (generate.py:151-170 + the logprob of :134-136), csrc/sampling.hip: tok[b] drawn from
+// softmax(row / temperature) restricted to the top-p prefix; uniforms (nullable): u[b] in [0, 1) instead of the Philox draw
+// keyed by (seed; offset + ctrl[5], b); history rings as launch_greedy_rows.
+hipError_t launch_sample_top_p(const float* logits, int ld, int B, int V, float temperature, float top_p, uint64_t seed,
+                               uint64_t offset, const float* uniforms, int64_t* tok, float* lp, int64_t* hist_tok, float* hist_lp,
+                               int hist_len, const uint32_t* ctrl, hipStream_t s);
 // control words of a workspace after a raised engine status: status / abort / arrivals cleared, epoch advanced
 hipError_t launch_engine_ctrl_reset(uint32_t* ctrl, hipStream_t s);
 

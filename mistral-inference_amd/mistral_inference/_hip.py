@@ -21,7 +21,7 @@ def _default_lib() -> str:
 
 LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", _default_lib())
 
-MI_ABI_VERSION = 4
+MI_ABI_VERSION = 5
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
 BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
 GEMV_MAX_T = 8
@@ -52,6 +52,7 @@ class MiBatch(C.Structure):
         ("cache_sizes", C.POINTER(C.c_int32)), ("h", _vp), ("logits", _vp), ("workspace", _vp),
         ("workspace_bytes", C.c_size_t),
         ("greedy_token", _vp), ("greedy_logprob", _vp), ("hist_token", _vp), ("hist_logprob", _vp), ("hist_len", C.c_int32),
+        ("sample_temperature", C.c_float), ("sample_top_p", C.c_float), ("sample_seed", C.c_uint64), ("sample_offset", C.c_uint64),  # ABI v5
     ]
 
 
@@ -73,6 +74,7 @@ _SIGS = {
                                   _vp, C.c_int, C.c_float, _vp]),
     "mi_gelu": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "mi_greedy_sample": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mi_sample_top_p": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
     "mi_lm_head_logprobs_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mi_lm_head_logprobs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
@@ -275,6 +277,23 @@ def greedy_sample(logits: torch.Tensor):
     lp = torch.empty(B, dtype=torch.float32, device=logits.device)
     check(lib().mi_greedy_sample(dev_ptr(logits, torch.float32), logits.stride(0), B, V, dev_ptr(tok, torch.long),
                                  dev_ptr(lp, torch.float32), stream_ptr(logits.device)), "mi_greedy_sample")
+    return tok, lp
+
+
+def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: int = 0, offset: int = 0,
+                 uniforms: Optional[torch.Tensor] = None):
+    """(token int64 [B], logprob fp32 [B]): one nucleus draw per fp32 logits row (reference generate.py:151-170) in ONE launch;
+    logprob = log_softmax(row)[token] of the unscaled logits.  `uniforms` (fp32 [B] in [0, 1)) replaces the Philox variate."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    B, V = logits.shape
+    tok = torch.empty(B, dtype=torch.long, device=logits.device)
+    lp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if uniforms is not None:
+        uniforms = uniforms.to(device=logits.device, dtype=torch.float32).contiguous()
+        assert uniforms.numel() == B
+    check(lib().mi_sample_top_p(dev_ptr(logits, torch.float32), logits.stride(0), B, V, float(temperature), float(top_p),
+                                int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), dev_ptr(uniforms, torch.float32),
+                                dev_ptr(tok, torch.long), dev_ptr(lp, torch.float32), stream_ptr(logits.device)), "mi_sample_top_p")
     return tok, lp
 
 

@@ -114,23 +114,33 @@ def generate(
     gen_lp: List[torch.Tensor] = []
     is_finished = torch.zeros(B, dtype=torch.bool, device=dev)
     assert last_token_prelogits is not None
-    fused_greedy = (temperature == 0 and max_tokens > 0 and hasattr(model, "greedy_session")
-                    and (dev.type == "cuda" or getattr(model, "greedy_session_any_device", False))  # (CPU stand-ins: tests)
+    fused_greedy = (max_tokens > 0 and hasattr(model, "greedy_session")
+                    and (dev.type == "cuda" or (temperature == 0 and getattr(model, "greedy_session_any_device", False)))  # (CPU stand-ins: tests)
                     and getattr(model, "num_pipeline_ranks", 1) == 1 and getattr(model, "softmax_fp32", True)
                     and getattr(model, "fused_greedy", True))  # (model.fused_greedy = False: the loop below, for A/B)
     if fused_greedy:
-        # Temperature 0 on one HIP stage: argmax and log-softmax ride on the LM head inside the step (GreedySession), the
-        # sample feeds the next step on the device, and the tokens come back in one copy per CHUNK steps.  Same values
-        # as the loop below: token i+1 = first argmax of the logits after token i; its logprob = log_softmax at it.
-        next_token = sample(last_token_prelogits, temperature=0.0, top_p=0.8)
-        lsm = torch.log_softmax(last_token_prelogits, dim=-1)
-        first_lp = lsm.gather(1, next_token[:, None])[:, 0]
+        # One HIP stage: the sample rides on the LM head inside the step (GreedySession) - argmax + log-softmax at temperature
+        # 0, the native nucleus draw (csrc/sampling.hip, generate.py:151-170 in one kernel) otherwise - it feeds the next step
+        # on the device, and the tokens come back in one copy per CHUNK steps.  Temperature 0: same values as the loop below
+        # (token i+1 = first argmax of the logits after token i; its logprob = log_softmax at it).  Temperature > 0: the same
+        # distribution as the loop below, drawn from a Philox stream seeded from torch's default generator (torch.manual_seed
+        # makes a generation reproducible; torch.multinomial's own stream cannot be reproduced by any other sampler).
+        seed = 0
+        if temperature > 0:
+            from . import _hip
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            next_token, first_lp = _hip.sample_top_p(last_token_prelogits.contiguous(), temperature, 0.8, seed=seed, offset=1 << 63)
+        else:
+            next_token = sample(last_token_prelogits, temperature=0.0, top_p=0.8)
+            lsm = torch.log_softmax(last_token_prelogits, dim=-1)
+            first_lp = lsm.gather(1, next_token[:, None])[:, 0]
         if eos_id is not None:
             is_finished = is_finished | (next_token == eos_id)
         if not (eos_id is not None and bool(is_finished.all())):
             generated.append(next_token)
             gen_lp.append(first_lp)
-            sess = model.greedy_session(cache, next_token)
+            sess = (model.greedy_session(cache, next_token, temperature=temperature, top_p=0.8, seed=seed) if temperature > 0
+                    else model.greedy_session(cache, next_token))
             need = max_tokens - 1            # (the reference's last forward only feeds a sample nobody draws)
             chunk = 32 if eos_id is not None else sess.HIST
             stop = False
@@ -193,7 +203,12 @@ def generate(
 
 
 def sample(logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
-    """Greedy for temperature 0, else nucleus sampling (reference generate.py:151-159)."""
+    """Greedy for temperature 0, else nucleus sampling (reference generate.py:151-159).  fp32 logits on a HIP device: ONE
+    native launch (mi_sample_top_p: no sort of the vocabulary, no host sync), seeded from torch's default generator."""
+    if temperature > 0 and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2:
+        from . import _hip
+        tok, _ = _hip.sample_top_p(logits.contiguous(), temperature, top_p, seed=int(torch.randint(0, 2 ** 62, (1,)).item()))
+        return tok.reshape(-1)
     if temperature > 0:
         probs = torch.softmax(logits / temperature, dim=-1)
         next_token = sample_top_p(probs, top_p)

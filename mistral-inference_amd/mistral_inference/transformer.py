@@ -59,6 +59,10 @@ class GreedyBuffers:
     lp: torch.Tensor        # fp32 [B]
     hist_tok: torch.Tensor  # int64 [hist_len, B]: row (decode steps run on the workspace) % hist_len
     hist_lp: torch.Tensor   # fp32 [hist_len, B]
+    temperature: float = 0.0  # > 0: the step's sample is a nucleus draw (mi_batch_t ABI v5) instead of the argmax
+    top_p: float = 0.8
+    seed: int = 0
+    offset: int = 0           # added to the workspace's step counter: the session's draws start at Philox counter 1
 
 
 class HipStackBackend:
@@ -176,6 +180,9 @@ class HipStackBackend:
             bt.greedy_token, bt.greedy_logprob = _hip.dev_ptr(greedy.tok, torch.long), _hip.dev_ptr(greedy.lp, torch.float32)
             bt.hist_token, bt.hist_logprob = _hip.dev_ptr(greedy.hist_tok, torch.long), _hip.dev_ptr(greedy.hist_lp, torch.float32)
             bt.hist_len = greedy.hist_tok.shape[0]
+            bt.sample_temperature, bt.sample_top_p = float(greedy.temperature), float(greedy.top_p)
+            bt.sample_seed = int(greedy.seed) & (2 ** 64 - 1)
+            bt.sample_offset = int(greedy.offset) & (2 ** 64 - 1)
         wsb = self._get_workspace(model, m, T, B, max_w)
         bt.workspace, bt.workspace_bytes = wsb.data_ptr(), wsb.numel()
         _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
@@ -372,10 +379,11 @@ class Transformer(ModelBase):
             self._graphed = None
 
     # ---- greedy decoding with the sample fused into the step ------------------------------------------
-    def greedy_session(self, cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True) -> "GreedySession":
-        """Decode loop of `generate()` at temperature 0 (reference generate.py:120-140) with nothing but the model's own
-        launches per token: see GreedySession."""
-        return GreedySession(self, cache, first_tokens, graph)
+    def greedy_session(self, cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True, temperature: float = 0.0,
+                       top_p: float = 0.8, seed: int = 0) -> "GreedySession":
+        """Decode loop of `generate()` (reference generate.py:120-140) with nothing but the model's own launches per token:
+        see GreedySession.  temperature 0: argmax; temperature > 0: the nucleus draw of generate.py:151-170 on the device."""
+        return GreedySession(self, cache, first_tokens, graph, temperature=temperature, top_p=top_p, seed=seed)
 
     def _logits(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
                 images: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
@@ -604,14 +612,19 @@ class GreedySession:
       0x700, include/mistral_hip.h) wrote nothing, so the missing steps are re-run on the launch path.
 
     The [B, vocab] fp32 logits of every step are still produced (`self.logits`): the work of `forward()` is unchanged,
-    only what is done with its result moved onto the device."""
+    only what is done with its result moved onto the device.
+
+    temperature > 0 (`mistral-chat`'s default, reference main.py:105 + generate.py:126,151-170): the same session with the
+    argmax replaced by the native nucleus draw (csrc/sampling.hip: one more small kernel behind the LM head inside the same
+    captured step, Philox variate keyed by the seed and the workspace's step counter) - still one native call per token."""
 
     HIST = 1024
     # decode steps per hipGraph launch.  Measured (profiles/EXPERIMENTS.md): 8 steps per graph close the ~9 us gap between two
     # graph launches, and the kernels then run ~10 us longer each (their ramp-up is no longer hidden in the gap): no gain -> 1
     GRAPH_STEPS = int(os.environ.get("MI_GRAPH_STEPS", "1"))
 
-    def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True):
+    def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True,
+                 temperature: float = 0.0, top_p: float = 0.8, seed: int = 0):
         assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"
         assert isinstance(model._backend, HipStackBackend), "the fused greedy step needs the HIP backend"
         dev = model.device
@@ -622,7 +635,8 @@ class GreedySession:
         self.buf = GreedyBuffers(tok=first_tokens.to(device=dev, dtype=torch.long).reshape(B).clone(),
                                  lp=torch.zeros(B, dtype=torch.float32, device=dev),
                                  hist_tok=torch.zeros((self.HIST, B), dtype=torch.long, device=dev),
-                                 hist_lp=torch.zeros((self.HIST, B), dtype=torch.float32, device=dev))
+                                 hist_lp=torch.zeros((self.HIST, B), dtype=torch.float32, device=dev),
+                                 temperature=float(temperature), top_p=float(top_p), seed=int(seed))
         self.logits = torch.empty((B, model.vocab_size), dtype=torch.float32, device=dev)
         self.h = torch.empty((B, model.args.dim), dtype=model.dtype, device=dev)
         self._use_graph = graph and dev.type == "cuda"
@@ -645,9 +659,11 @@ class GreedySession:
     def _one_step(self) -> None:
         m, cache = self.model, self.cache
         if not self._warm:  # first step eagerly: sizes the workspace, runs the engine's one-time residency census
-            if m._backend._workspace is None:
-                m._backend._get_workspace(m, m._backend.plan(m), 1, self.B, max(cache.cache_sizes))
+            # size the workspace exactly as run_stack will BEFORE reading its step counter: a re-allocation inside the first
+            # step would restart the counter at zero and collect() would index the wrong history rows
+            m._backend._get_workspace(m, m._backend.plan(m), 1, self.B, max(cache.cache_sizes))
             self._base = self._steps_now()
+            self.buf.offset = -self._base  # (mod 2^64) a generation's variates do not depend on what ran on the workspace before
             self._step_eager()
             self._warm = True
             return
@@ -711,7 +727,16 @@ class GreedySession:
         if st["status"] != 0:
             missing = issued_total - done_total
             if st["status"] != 0x700:
-                raise RuntimeError(f"persistent decode engine: bounded wait 0x{st['status']:x} timed out (workspace poisoned)")
+                # a bounded wait timed out mid-step: the step's outputs are undefined and a raised status word makes every
+                # later engine launch on this workspace leave at once.  Leave the process usable: clear the word, switch to
+                # the launch path, drop the graphs that hold engine launches - the NEXT generate() runs launch by launch.
+                _hip.decode_engine_reset(ws)
+                _hip.set_decode_engine(False)
+                self._graphs = {}
+                self._use_graph = False
+                raise RuntimeError(f"persistent decode engine: bounded wait 0x{st['status']:x} timed out; this generation is "
+                                   "lost (its cache is undefined), the engine is now off for this process and later calls "
+                                   "take the launch path")
             logging.warning("persistent decode engine: %d of the GPU's workgroups were not resident together; %d step(s) "
                             "re-run on the launch path (engine off for this process)", st["arrivals"], missing)
             self._recover(missing)
@@ -721,6 +746,10 @@ class GreedySession:
         idx = torch.arange(first, first + n, device=m.device) + self._base
         idx = idx % self.HIST
         toks, lps = self.buf.hist_tok[idx], self.buf.hist_lp[idx]
+        if bool((toks == 0x7FFFFFFF).any()):
+            # the argmax reductions start from "no index yet" and a row of NaN logits never replaces it (torch.argmax would
+            # return the NaN's position): report what happened instead of the IndexError the next step's embedding raises
+            raise FloatingPointError("greedy sample over a logits row without a maximum (NaN logits?)")
         self._pending -= n
         self._n_collected = first + n
         return toks, lps

@@ -364,6 +364,30 @@ def generate(prompts: List[List[int]], model: OracleModel, *, max_tokens: int, m
 # --------------------------------------------------------------------------------------------
 # synthetic checkpoints (the reference tests' own init, tests/test_generate.py:37-51)
 # --------------------------------------------------------------------------------------------
+def top_p_distribution(logits: torch.Tensor, temperature: float, p: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """What the reference's `sample` hands to torch.multinomial (generate.py:151-167), for ONE fp32 logits row [V]:
+    (order [V] long, kept [V] float64) - `order` = token ids by descending probability of softmax(logits / temperature)
+    (ties by ascending id: a STABLE sort; torch.sort leaves tie order unspecified), `kept` = the sorted probabilities with
+    every position whose mass BEFORE it exceeds p zeroed, renormalised to sum 1.  The arithmetic follows the reference in
+    fp32 (softmax, cumsum, the `probs_sum - probs_sort > p` mask) and only the final renormalisation is widened."""
+    probs = torch.softmax(logits.float() / temperature, dim=-1)
+    probs_sort, order = torch.sort(probs, dim=-1, descending=True, stable=True)
+    probs_sum = torch.cumsum(probs_sort, dim=-1)
+    mask = probs_sum - probs_sort > p
+    kept = probs_sort.double().masked_fill(mask, 0.0)
+    return order, kept / kept.sum()
+
+
+def top_p_inverse_cdf(order: torch.Tensor, kept: torch.Tensor, u: float) -> int:
+    """The token an inverse-CDF draw with the uniform variate u in [0, 1) picks from `top_p_distribution`'s output: the first
+    sorted position whose cumulative kept mass exceeds u (torch.multinomial draws from the same distribution with its own
+    stream, generate.py:168-169)."""
+    cdf = torch.cumsum(kept, dim=-1)
+    pos = int(torch.searchsorted(cdf, torch.tensor(u, dtype=cdf.dtype), right=True))
+    last = int((kept > 0).nonzero()[-1])
+    return int(order[min(pos, last)])
+
+
 def synth_weights(args: OracleArgs, seed: int = 42, dtype: torch.dtype = torch.bfloat16) -> Dict[str, torch.Tensor]:
     """nn.Linear-style U(+-1/sqrt(fan_in)), N(0,1) embeddings, norm weights slightly off 1 so the
     weight multiply is exercised; generated per tensor from a seeded generator, then cast."""

@@ -1,4 +1,5 @@
-"""The C-ABI library builds, loads without a GPU and exports every symbol include/mistral_hip.h declares."""
+"""The C-ABI library builds, loads without a GPU and exports every symbol include/*.h declares (mistral_hip.h: the product
+boundary; mistral_hip_debug.h: engine diagnostics)."""
 import ctypes
 import os
 import re
@@ -8,10 +9,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "mistral_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+def _declared(header=None):
+    names = set()
+    for h in ([header] if header else sorted(os.listdir(os.path.join(ROOT, "include")))):
+        if not h.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_debug_entry_points_live_in_their_own_header():
+    """Diagnostics (trace, knobs, sabotage) are not part of the boundary a maintainer binds."""
+    assert not [n for n in _declared("mistral_hip.h") if n.startswith("mi_debug_")]
+    assert all(n.startswith("mi_debug_") for n in _declared("mistral_hip_debug.h"))
 
 
 def test_header_symbols_exported():

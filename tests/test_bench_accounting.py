@@ -41,3 +41,25 @@ def test_cpu_baseline_carries_the_stored_reference_number(monkeypatch):
     monkeypatch.setattr(bench, "reference_baseline", lambda *a, **k: {"value": 0.7, "kind": "reference", "cores": 8})
     ref = bench.cpu_baseline(dict(bench.MISTRAL_7B), 4096)
     assert ref["kind"] == "reference" and ref["port_value"] == 2.0
+
+
+def test_plain_multi_gpu_invocation_re_executes_under_torchrun(monkeypatch):
+    """`python bench.py --gpus 4` without a torchrun environment must not die on a WORLD_SIZE assertion: it re-executes
+    itself as the documented torch.distributed.run line (one process per GPU, loopback rendezvous)."""
+    import subprocess
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5"])
+    assert bench.respawn_under_torchrun(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

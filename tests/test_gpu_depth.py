@@ -307,3 +307,147 @@ def test_mixtral_8x7b_dims_one_layer_vs_oracle():
         if clear.any():
             assert float((gl[clear] - rl[clear]).abs().max()) <= 4e-2
     assert kept >= 0.8 * (T + steps)
+
+
+def test_nemo_12b_dims_4_layers_8300_token_chunked_prompt_vs_oracle():
+    """BASELINE configs[2] beyond one layer (round 3 pinned Nemo by ONE layer at vocab 1024 and 300 tokens): 4 layers of the
+    Mistral-Nemo-12B dims (dim 5120 != n_heads * 128 = 4096, hidden 14336) with the REAL vocabulary (131072: the LM-head
+    GEMM at prefill, the LM-head GEMV / engine rows at decode), an 8300-token prompt fed in chunks of 2048 (no sliding window:
+    later chunks attend to every cached key, the ring is 8306 slots - more than 8192) and 4 teacher-forced decode steps,
+    against the layer-major oracle in bf16 AND fp32 (the three-number criterion of the 32-layer test).  The oracle's LM head
+    is evaluated on a subset of the prompt rows (all rows of the last chunk, a stride over the rest) and on every decode row."""
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    p = dict(dim=5120, n_layers=4, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+             vocab_size=131072, rope_theta=1e6)
+    L, V, D = p["n_layers"], p["vocab_size"], p["dim"]
+    T, steps, chunk = 8300, 4, 2048
+    oargs = mo.OracleArgs.from_params(p)
+    ta = TransformerArgs.from_dict(p)
+    ta.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(ta)
+    model = model.to(BF).to_empty(device="cuda").eval()
+    sd = dict(model.named_parameters())
+    g = torch.Generator().manual_seed(777)
+    emb = torch.randn(V, D, generator=g).to(BF)
+    final_norm = (1 + 0.1 * torch.randn(D, generator=g)).to(BF)
+    out_w = _lin(V, D, g)
+    with torch.no_grad():
+        sd["tok_embeddings.weight"].copy_(emb)
+        sd["norm.weight"].copy_(final_norm)
+        sd["output.weight"].copy_(out_w)
+    ids = torch.randint(0, V, (T + steps,), generator=torch.Generator().manual_seed(778))
+    starts = list(range(0, T, chunk))
+    dtypes = {"bf16": BF, "fp32": torch.float32}
+    acts = {d: ([None] * len(starts), [None] * steps) for d in dtypes}
+    t0 = time.time()
+    for l in range(L):
+        w = _layer_weights(l, p, g)
+        with torch.no_grad():
+            for k, t in w.items():
+                sd[k].copy_(t)
+        extra = {}
+        if l == 0:
+            extra["tok_embeddings.weight"] = emb
+        if l == L - 1:
+            extra["norm.weight"] = final_norm
+        for dn, dt in dtypes.items():
+            wl = {k: t.to(dt) for k, t in {**w, **extra}.items()}
+            om = mo.OracleModel(oargs, wl, pipeline_rank=l, num_pipeline_ranks=L)
+            oc = mo.OracleCache(1, 1, T + steps + 2, p["n_kv_heads"], p["head_dim"], None, dtype=dt)
+            h_pre, h_dec = acts[dn]
+            h_pre = [om.forward_partial(ids[s:min(s + chunk, T)], [min(s + chunk, T) - s], oc, h_in=h_pre[i])
+                     for i, s in enumerate(starts)]
+            h_dec = [om.forward_partial(ids[T + s:T + s + 1], [1], oc, h_in=h_dec[s]) for s in range(steps)]
+            acts[dn] = (h_pre, h_dec)
+        del w
+    oracle_s = time.time() - t0
+    model._weights_changed()
+    cache = BufferCache(L, 1, T + steps + 2, p["n_kv_heads"], p["head_dim"], None, device="cuda", dtype=BF)
+    cache.reset()
+    sel = torch.cat([torch.arange(0, starts[-1], 29), torch.arange(starts[-1], T)])   # stride + the whole last chunk
+    hip = []
+    with torch.inference_mode():
+        for s in starts:
+            e = min(s + chunk, T)
+            lg = model.forward(ids[s:e].cuda(), [e - s], cache)       # [e - s, 131072] fp32: the contractual forward()
+            rows = sel[(sel >= s) & (sel < e)] - s
+            hip.append(lg[rows.cuda()].cpu())
+            del lg
+        hip += [model.forward(ids[T + s:T + s + 1].cuda(), [1], cache).cpu() for s in range(steps)]
+    hip = torch.cat(hip)
+    ref = {}
+    for dn, dt in dtypes.items():
+        h_pre, h_dec = acts[dn]
+        ref[dn] = F.linear(torch.cat([torch.cat(h_pre)[sel]] + h_dec), out_w.to(dt)).float()
+    e_hip, e_o16, d = (hip - ref["fp32"]).abs(), (ref["bf16"] - ref["fp32"]).abs(), (hip - ref["bf16"]).abs()
+    print(f"\nNemo-12B dims x 4 layers, V = 131072, {T}-token prompt in chunks of {chunk} + {steps} decode steps (oracle: "
+          f"{oracle_s:.0f} s on the host): max|HIP-fp32| {float(e_hip.max()):.4f}  max|oracle_bf16-fp32| {float(e_o16.max()):.4f}  "
+          f"max|HIP-oracle_bf16| {float(d.max()):.4f}  means {float(e_hip.mean()):.5f} / {float(e_o16.mean()):.5f} / "
+          f"{float(d.mean()):.5f}  decode rows: max|HIP-fp32| {float(e_hip[-steps:].max()):.4f} vs {float(e_o16[-steps:].max()):.4f}  "
+          f"|logit|max {float(ref['fp32'].abs().max()):.2f}")
+    from mistral_inference import _hip
+    st = _hip.decode_engine_status(model._backend._workspace)
+    assert st["status"] == 0 and st["bad_id"] == 0, st
+    assert float(e_hip.max()) <= 1.25 * float(e_o16.max()), (float(e_hip.max()), float(e_o16.max()))
+    assert float(e_hip.mean()) <= 1.10 * float(e_o16.mean())
+    assert float(e_hip[-steps:].max()) <= 1.5 * float(e_o16.max())
+    agree_hip = float((hip.argmax(1) == ref["fp32"].argmax(1)).float().mean())
+    agree_o16 = float((ref["bf16"].argmax(1) == ref["fp32"].argmax(1)).float().mean())
+    assert agree_hip >= agree_o16 - 0.02, (agree_hip, agree_o16)
+    # the fused prompt log-probabilities (GEMM_LOGPROB epilogue at V = 131072) against forward() + log_softmax on one chunk
+    cache.reset()
+    with torch.inference_mode():
+        n = 1024
+        tg = torch.cat([ids[1:n], torch.tensor([-1])]).to(torch.int32)
+        lp, last = model.prompt_logprobs(ids[:n].cuda(), [n], cache, tg)
+        cache.reset()
+        full = torch.log_softmax(model.forward(ids[:n].cuda(), [n], cache), dim=-1)
+        want = full[torch.arange(n - 1).cuda(), ids[1:n].cuda()]
+        assert float((lp[:n - 1] - want).abs().max()) <= 2e-3
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_mixtral_8x22b_dims_3_layers_vs_oracle():
+    """BASELINE configs[4] beyond one layer: 3 layers of the Mixtral-8x22B dims (dim 6144, 48 query heads over 8 kv heads =
+    GQA ratio 6, hidden 16384, 8 experts top-2; 14.5 GB), 12-token prompt (the MFMA GEMM path, token-grouped MoE GEMM) + 3
+    teacher-forced decode steps against the bf16 oracle, layer-major (tests/moe_depth_util.py; the seed is one whose run has
+    no router near-tie, checked again here)."""
+    import moe_depth_util as mu
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    p = dict(mu.P8X22B_3L)
+    ta = TransformerArgs.from_dict(p)
+    ta.max_batch_size = 1
+    with torch.device("meta"):
+        model = Transformer(ta)
+    model = model.to(BF).to_empty(device="cuda").eval()
+    sd = dict(model.named_parameters())
+
+    def sink(w):
+        with torch.no_grad():
+            for k, t in w.items():
+                sd[k].copy_(t)
+
+    T, steps = mu.PROMPT_22B, mu.STEPS_22B
+    ids, ref, gap = mu.oracle_run(seed=mu.SEED_22B, sink=sink, p=p, prompt=T, steps=steps)
+    assert gap > 2.5, f"router near-tie in the oracle run (gap {gap:.2f} ulp): pick another seed (python tests/moe_depth_util.py 0 8x22b)"
+    model._weights_changed()
+    cache = BufferCache(p["n_layers"], 1, T + steps + 2, 8, 128, None, device="cuda", dtype=BF)
+    cache.reset()
+    with torch.inference_mode():
+        got = [model.forward(ids[:T].cuda(), [T], cache).cpu()]
+        got += [model.forward(ids[T + i:T + i + 1].cuda(), [1], cache).cpu() for i in range(steps)]
+    got = torch.cat(got)
+    d = (got - ref).abs()
+    print(f"\nMixtral-8x22B dims x 3 layers: max|HIP - oracle_bf16| {float(d.max()):.4f} (prefill rows {float(d[:T].max()):.4f}, "
+          f"decode rows {float(d[T:].max()):.4f}), mean {float(d.mean()):.5f}, |logit|max {float(ref.abs().max()):.2f}, "
+          f"min router gap {gap:.1f} ulp")
+    assert float(d.max()) <= 4e-2 and float(d.mean()) <= 3e-3
+    assert float((got.argmax(1) == ref.argmax(1)).float().mean()) >= 0.9
+    del model
+    torch.cuda.empty_cache()

@@ -83,3 +83,22 @@ def test_bench_two_ranks_prints_one_json_line():
     # north_star's multi-GPU model: a Mixtral sub-measurement over the same stages (8x7B dims for N < 8, layer-truncated here)
     mx = d["mixtral"]
     assert "Mixtral-8x7B" in mx["model"] and mx["tokens_per_s"] > 0 and 0 < mx["hbm_roofline_frac"] < 1 and mx["prefill_tokens_per_s"] > 0
+
+
+def test_plain_bench_invocation_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun environment (the shape of the driver's N = 1 command with another N) must
+    start its two ranks itself and still print exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MI_DIST_BACKEND"] = "gloo"  # two ranks on this box's one GPU (RCCL refuses that); "nccl" on a multi-GPU node
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--layers", "2",
+           "--prefill", "128", "--no-mixtral"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "pp2" in d["config"]["parallelism"]
