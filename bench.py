@@ -296,7 +296,7 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
         prefill_s = sorted(prefill_all)[1]
         # ---- decode: the generate() loop body - forward(next_token, [1], cache) under the decode hipGraph context
         # (capture happens inside the warm-up steps; W >= 2 keeps it out of the timed region)
-        if world == 1 and opt.loop == "greedy":
+        if opt.loop == "greedy":
             # generate()'s temperature-0 loop body (mistral_inference/generate.py -> Transformer.greedy_session): one
             # native call per token - argmax + log-softmax are the LM head's epilogue, the sample feeds the next step on
             # the device - replayed from a hipGraph.  Nothing of the step is skipped: logits [1, V] are written every step.
@@ -409,7 +409,9 @@ def main() -> None:
     def decode_launch_label() -> str:
         # the engine counts its own launches in the workspace: that is how we know which path was timed
         kind = "persistent decode engine (1 launch per token)" if engine["engine_launches"] > 0 else "6 launches per layer"
-        kind += ", greedy sample fused into the step" if (world == 1 and opt.loop == "greedy") else ", forward() + torch.argmax"
+        kind += ", greedy sample fused into the step" if opt.loop == "greedy" else ", forward() + torch.argmax"
+        if world > 1 and opt.loop == "greedy":
+            kind += " (one session per stage; the sample returns to stage 0 as 8 bytes per token, no logits broadcast)"
         from mistral_inference.distributed import RcclComm
         eager = opt.no_graph or (world > 1 and not isinstance(model.pp_comm, RcclComm))
         return kind + (", eager" if eager else ", hipGraph replay")
@@ -438,7 +440,7 @@ def main() -> None:
                         "tflops": round(prefill_flops(params, T0) / prefill_s / 1e12, 1), "mfma_peak_tflops": 2500.0,
                         "mfma_frac": round(prefill_flops(params, T0) / prefill_s / 2.5e15, 4)},
         }
-        if world == 1 and opt.loop == "greedy":
+        if opt.loop == "greedy":
             # not inside the K-step bracket: the once-per-chunk read-back of the samples (status copy + host sync + gather)
             out["collect_ms_per_chunk"] = round(getattr(timed_run, "collect_s", 0.0) * 1e3, 3)
         # the dominant kernel is timed on this rank's own layers (any N)

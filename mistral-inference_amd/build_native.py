@@ -24,6 +24,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 PER_FILE_FLAGS = {"decode_engine.hip": os.environ.get("MI_ENGINE_FLAGS", "-mllvm -amdgpu-sched-strategy=max-memory-clause").split()}
 
 
+# Second compile of the engine source under other entry-point names (csrc/decode_engine.hip, ENG_WIDE): the shapes the shipped
+# instantiations decline, without touching one instruction of the shipped kernels.
+VARIANT_OBJECTS = {"decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1"])}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -48,6 +53,11 @@ def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = L
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if _stale(o, [s] + HEADERS):
             jobs.append([hipcc, *FLAGS, *PER_FILE_FLAGS.get(src, []), *extra_flags, "-c", s, "-o", o])
+    for obj, (src, defs) in VARIANT_OBJECTS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(obj_dir, obj)
+        if _stale(o, [s] + HEADERS):
+            jobs.append([hipcc, *FLAGS, *PER_FILE_FLAGS.get(src, []), *extra_flags, *defs, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -60,7 +70,7 @@ def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = L
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES] + [os.path.join(obj_dir, o) for o in VARIANT_OBJECTS]
     if jobs or _stale(lib, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", lib])
     return lib

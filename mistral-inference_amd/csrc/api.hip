@@ -49,6 +49,14 @@ constexpr size_t TICKET_BYTES = 4096;  // first words: control block of the pers
 // 1 (default): batch-1 decode steps of dense models run on the persistent engine (decode_engine.hip) when the shapes
 // allow it; 0: always the launch path.  MI_DECODE_ENGINE sets the initial value, mi_set_decode_engine changes it.
 int g_engine_mode = -1;
+int g_engine_variant = -1;  // 0 (default): the shipped engine build first, the wide build for what it declines; 1: wide first
+int engine_variant() {
+  if (g_engine_variant < 0) {
+    const char* e = getenv("MI_ENGINE_VARIANT");
+    g_engine_variant = e ? atoi(e) : 0;
+  }
+  return g_engine_variant;
+}
 int engine_mode() {
   if (g_engine_mode < 0) {
     const char* e = getenv("MI_DECODE_ENGINE");
@@ -474,6 +482,7 @@ int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream) 
 }
 
 int mi_decode_engine_census(int forget) {
+  if (forget) decode_engine_forget_census_wide();
   if (forget) decode_engine_forget_census();
   return MI_OK;
 }
@@ -487,14 +496,22 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
 size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(device_cus()); }
 int mi_debug_set_engine_knobs(int thin, int depth) {
   decode_engine_set_knobs(thin, depth);
+  decode_engine_set_knobs_wide(thin, depth);
   return MI_OK;
 }
 int mi_debug_set_engine_holders(int on) {
   decode_engine_set_holders(on);
+  decode_engine_set_holders_wide(on);
   return MI_OK;
+}
+int mi_debug_set_engine_variant(int variant) {
+  const int prev = engine_variant();
+  g_engine_variant = variant != 0;
+  return prev;
 }
 int mi_debug_set_engine_trace(void* dev_buffer) {
   decode_engine_set_trace(dev_buffer);
+  decode_engine_set_trace_wide(dev_buffer);
   return MI_OK;
 }
 
@@ -570,15 +587,21 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     for (int l = 0; l < m->n_layers; ++l)
       dense_ok = dense_ok && (m->num_experts ? (m->layers[l].gate && m->layers[l].expert_w_dev)
                                              : (m->layers[l].w1 && m->layers[l].w2 && m->layers[l].w3));
-    if (dense_ok && decode_engine_applicable(pr, nullptr, 0)) {
+    // the shipped build of the engine first (the headline shapes); the "wide" build of the same source for what it declines
+    // (GQA ratio 6 + 32 KiB hid vector: Mixtral-8x22B; rows of 10 pieces: Mistral-Nemo).  g_engine_variant = 1 (tests) prefers
+    // the wide build wherever it applies, so that its code paths can be compared bit for bit at small sizes.
+    const bool wide_ok = dense_ok && decode_engine_applicable_wide(pr, nullptr, 0);
+    const bool base_ok = dense_ok && !(engine_variant() == 1 && wide_ok) && decode_engine_applicable(pr, nullptr, 0);
+    if (base_ok || wide_ok) {
       bool declined = false;
-      MI_TRY(hip_rc(launch_decode_engine(pr, s, &declined), "decode engine"));
+      MI_TRY(hip_rc(base_ok ? launch_decode_engine(pr, s, &declined) : launch_decode_engine_wide(pr, s, &declined), "decode engine"));
       if (!declined) {
         if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
         if (want_topp) MI_TRY(sample_step());
         return MI_OK;
       }
-      snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail());  // informational
+      snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s",
+               base_ok ? decode_engine_census_detail() : decode_engine_census_detail_wide());  // informational
     }
   }
 

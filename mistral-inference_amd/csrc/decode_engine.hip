@@ -35,6 +35,29 @@
 #include "attn_decode_core.cuh"
 #include "kernels.h"
 
+// ENG_WIDE = 1: this file compiled a SECOND time (build_native.py -> decode_engine_wide.o) under other entry-point names, for
+// the model shapes the shipped instantiations decline: GQA ratio 6 and a hid vector of 32 KiB (Mixtral-8x22B: dim 6144, 48 / 8
+// heads, hidden 16384 - needs a 7-fill ring), rows that are not a multiple of 4 pieces (Mistral-Nemo: dim 5120, streamed as
+// contiguous units instead of 2-piece groups).  Every difference sits behind `#if ENG_WIDE`, so the default compile of this
+// file is token for token what it was: this kernel's speed moves by several per cent with ANY change of its code (see
+// ENG_TRACE below), and the headline configuration must not pay for shapes it never runs.  scripts/engine_isa_hash.sh
+// prints a hash of the default object's ISA; it has not changed since round 3.
+#ifndef ENG_WIDE
+#define ENG_WIDE 0
+#endif
+#if ENG_WIDE
+#define launch_decode_engine launch_decode_engine_wide
+#define decode_engine_applicable decode_engine_applicable_wide
+#define decode_engine_granule_bytes decode_engine_granule_bytes_wide
+#define decode_engine_set_holders decode_engine_set_holders_wide
+#define decode_engine_set_knobs decode_engine_set_knobs_wide
+#define decode_engine_set_trace decode_engine_set_trace_wide
+#define decode_engine_trace_bytes decode_engine_trace_bytes_wide
+#define decode_engine_census_detail decode_engine_census_detail_wide
+#define decode_engine_forget_census decode_engine_forget_census_wide
+#define engine_census_kernel engine_census_kernel_wide
+#endif
+
 namespace {
 
 using namespace attn_core;
@@ -73,7 +96,13 @@ constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
 constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
 constexpr int FILL = 16;             // pieces per fill
+#if ENG_WIDE
+constexpr int RING_FILLS = 7;        // 112 KiB ring: 47 KiB left for the activation region (a 32 KiB hid vector fits)
+#define RING_IDX(sh, x) ((uint32_t)(x) % (uint32_t)(RING_FILLS * FILL))  // not a power of two: a constant modulo (scalar ALU)
+#else
 constexpr int RING_FILLS = 8;        // 128 KiB ring
+#define RING_IDX(sh, x) ((x) & (sh).ring_mask)
+#endif
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int CTL_BYTES = 256;
 constexpr int RES_BYTES = 1024;      // this CU's residual rows (bf16), <= 512 rows
@@ -305,7 +334,7 @@ struct Loader {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, OFF, 2 /* nt */);
   }
   __device__ __forceinline__ lchar* slot_of(uint32_t piece_idx) {  // wave-uniform (becomes M0)
-    return sh.ring + (uint32_t)__builtin_amdgcn_readfirstlane((int)(piece_idx & sh.ring_mask)) * PIECE;
+    return sh.ring + (uint32_t)__builtin_amdgcn_readfirstlane((int)RING_IDX(sh, piece_idx)) * PIECE;
   }
   __device__ __forceinline__ void piece(const void* src_lane) {
     if ((g & (FILL - 1)) == 0) fill_begin();
@@ -324,9 +353,40 @@ struct Loader {
   // of G pieces, row after row - rows[0][0..G), rows[1][0..G), ..., rows[0][G..2G), ... - so that the consumer can start on
   // the first group while the rest is in flight and hand ring space back group by group (a unit of W2 is 56 pieces: four
   // waves each pinning a whole unit would need 14 fills of the 8-fill ring).
+#if ENG_WIDE
+  // n pieces that are contiguous in memory (and land contiguously in the ring): four per address computation wherever the
+  // stream position allows it
+  __device__ __forceinline__ void seg(const bf16_t* base, int n) {
+    const char* src = reinterpret_cast<const char*>(base) + lane * 16;
+    int i = 0;
+    while (i < n) {
+      if ((g & 3) == 0 && n - i >= 4) {
+        piece4(src + (size_t)i * PIECE);
+        i += 4;
+      } else {
+        piece(src + (size_t)i * PIECE);
+        ++i;
+      }
+    }
+  }
+#endif
   template <int NR>
   __device__ __forceinline__ void unit(const bf16_t* const (&rp)[NR], int P) {
     const int G = unit_group(P);
+#if ENG_WIDE
+    // Rows that are not a multiple of 4 pieces (Mistral-Nemo: dim 5120 = 10 pieces).  The shipped form streams such rows in
+    // 2-piece groups, piece by piece, and the loader's cost is per GROUP (~200 cycles of address / slot / fill bookkeeping,
+    // profiles/EXPERIMENTS.md): 13.5 GB/s per CU instead of 28.  But the two rows of a pair ARE contiguous in memory
+    // (rows 2u, 2u + 1 of a row-major matrix; rows 2j, 2j + 1 of W1 and of W3 for a gate/up unit): a unit is one (or two)
+    // contiguous runs of 2P pieces, streamed four pieces per address computation like every other row, laid out in the
+    // ring linearly - row r of a pair at unit + r * P.  The consumer waits for the whole unit (20 or 40 KiB: < 1.5 us of
+    // stream, hidden behind the previous unit's reduction) instead of group by group.
+    if (G != 4) {
+      seg(rp[0], 2 * P);                      // NR == 2: rows (2u, 2u + 1); NR == 4: W1 rows (2j, 2j + 1)
+      if constexpr (NR == 4) seg(rp[1], 2 * P);  // W3 rows (2j, 2j + 1)
+      return;
+    }
+#endif
     for (int p0 = 0; p0 < P; p0 += G) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -501,6 +561,39 @@ struct Cons {
     };
     // the unit arrives in groups of G pieces per row (Loader::unit): wait for a group, reduce it, hand its ring space back
     const int G = A4 ? 4 : unit_group(P);
+#if ENG_WIDE
+    if (!A4 && G != 4) {
+      // linear unit (Loader::unit): rows of a pair are P pieces apart; a gate/up unit is [w1 2j | w1 2j+1 | w3 2j | w3 2j+1]
+      // while the accumulators are ordered (w1 2j, w3 2j, w1 2j+1, w3 2j+1)
+      need_fill(g0 + NR * P - 1);
+      int off[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) off[r] = (NR == 2 ? r : ((r & 1) * 2 + (r >> 1))) * P;
+      int p = 0;
+      for (; p + 1 < P; p += 2) {
+        u32x4 xv[2], wv[2][NR];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          xv[j] = lds16(xl + (p + j) * PIECE);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) wv[j][r] = lds16(wl + RING_IDX(sh, g0 + off[r] + p + j) * PIECE);
+        }
+        step(xv[0], wv[0]);
+        step(xv[1], wv[1]);
+      }
+      if (p < P) {
+        u32x4 wv[NR];
+        const u32x4 xv = lds16(xl + p * PIECE);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) wv[r] = lds16(wl + RING_IDX(sh, g0 + off[r] + p) * PIECE);
+        step(xv, wv);
+      }
+      set_done(g0 + NR * P);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) out[r] = wave_sum(acc[r]);
+      return;
+    }
+#endif
     constexpr int S = (NR <= 2) ? 4 : 2;  // pieces per row whose LDS reads are issued together
     uint32_t gg = g0;                     // first ring piece of the current group
     for (int p0 = 0; p0 < P; p0 += G, gg += NR * G) {
@@ -513,7 +606,7 @@ struct Cons {
           for (int j = 0; j < S; ++j) {
             xv[j] = lds16(xl + (p0 + h + j) * PIECE);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) wv[j][r] = lds16(wl + ((gg + r * 4 + h + j) & sh.ring_mask) * PIECE);
+            for (int r = 0; r < NR; ++r) wv[j][r] = lds16(wl + RING_IDX(sh, gg + r * 4 + h + j) * PIECE);
           }
 #pragma unroll
           for (int j = 0; j < S; ++j) step(xv[j], wv[j]);
@@ -523,7 +616,7 @@ struct Cons {
           u32x4 wv[NR];
           const u32x4 xv = lds16(xl + (p0 + i) * PIECE);
 #pragma unroll
-          for (int r = 0; r < NR; ++r) wv[r] = lds16(wl + ((gg + r * G + i) & sh.ring_mask) * PIECE);
+          for (int r = 0; r < NR; ++r) wv[r] = lds16(wl + RING_IDX(sh, gg + r * G + i) * PIECE);
           step(xv, wv);
         }
       }
@@ -1035,8 +1128,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           cs.set_done(gk);
           cs.need_fill(gk + 1);
         }
-        u32x4 kraw = lds16(sh.ring + (gk & sh.ring_mask) * PIECE + lane * 16);
-        u32x4 vraw = lds16(sh.ring + ((gk + 1) & sh.ring_mask) * PIECE + lane * 16);
+        u32x4 kraw = lds16(sh.ring + RING_IDX(sh, gk) * PIECE + lane * 16);
+        u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gk + 1) * PIECE + lane * 16);
         const int slot = p.s_begin + 4 * j + gl;
         if (slot == p.cur_slot) {  // this step's K/V row: taken from the granules, its ring write may still be in flight
           kraw = lds16(kn_lds + dl * 4);
@@ -1499,7 +1592,13 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   // Large dims that are not a multiple of 2048 (Mistral-Nemo: 5120 = rows of 10 pieces, streamed in 2-piece groups, no holder
   // waves): 7.6-8.0 ms per step on the engine against 5.0 ms on the launch path (profiles/EXPERIMENTS.md) - such models
   // take the launch path.  Small dims (the parity tests) stay on the engine.
+#if !ENG_WIDE
   if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
+#else
+  if ((pr.D >> 9) & 1) {  // a contiguous unit must keep the stream 4-aligned often enough to matter: even piece counts only
+    if (pr.D > 3072) return no("odd number of 512-element pieces per row at a large dim");
+  }
+#endif
   if (pr.V % 2) return no("odd vocab");
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch
@@ -1517,11 +1616,20 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   if (pr.Hkv <= 0 || pr.H % pr.Hkv) return no("heads");
   const int Rtot = pr.H / pr.Hkv;
   const int R = attn_decode_group(Rtot);
+#if ENG_WIDE
+  if (R != 4 && R != 6) return no("GQA group size (the wide build instantiates 4 and 6)");
+#else
   if (R != 1 && R != 2 && R != 4 && R != 8) return no("GQA group size");
+#endif
   const int Hs = pr.Hkv * (Rtot / R);
   const int ne_max = ((pr.H * DH / 2 + NB - 1) / NB) * 2;
   if (ne_max > 64) return no("split-merge slab");
+#if ENG_WIDE
+  // q (R*64 words) | k, v of this step (128 words) | m, l (8R floats) | acc (4 R DH floats) | merge staging (3 * 32 * ne words)
+  if ((size_t)R * 256 + 512 + (size_t)R * 32 + (size_t)4 * R * DH * 4 + (size_t)3 * 32 * ne_max * 4 > region) return no("attention scratch");
+#else
   if ((size_t)R * (256 + 2 * DH * 16 + 32) + 512 + (size_t)3 * 32 * ne_max * 4 > region) return no("attention scratch");
+#endif
   for (int l = 0; l < pr.n_layers; ++l) {
     const int ns = attn_decode_splits(pr.W[l]);
     if (ns > 32 || Hs * ns > NB) return no("more attention work items than CUs");
@@ -1675,10 +1783,15 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   (moe ? (all4 ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
        : (all4 ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
     switch (a.R) {
+#if ENG_WIDE
+      case 4: fn = ENG_PICK(4); break;
+      case 6: fn = ENG_PICK(6); break;
+#else
       case 1: fn = ENG_PICK(1); break;
       case 2: fn = ENG_PICK(2); break;
       case 4: fn = ENG_PICK(4); break;
       case 8: fn = ENG_PICK(8); break;
+#endif
       default: return hipErrorInvalidValue;
     }
 #undef ENG_PICK

@@ -274,3 +274,13 @@ void decode_engine_set_knobs(int thin, int depth);  // debug / tuning
 void decode_engine_set_holders(int on);             // debug / A/B: -1 = environment default
 
 size_t decode_engine_trace_bytes(int NB);
+// The same source compiled a second time with -DENG_WIDE=1 (decode_engine_wide.o): the shapes the shipped instantiations
+// decline - GQA ratio 6 with a 32 KiB hid vector (Mixtral-8x22B: 7-fill ring), rows of an even number of pieces that is not a
+// multiple of 4 (Mistral-Nemo: contiguous units).  Same EngProblem, same granule layout, bit-identical results.
+bool decode_engine_applicable_wide(const EngProblem& pr, char* why, size_t why_len);
+hipError_t launch_decode_engine_wide(const EngProblem& pr, hipStream_t s, bool* declined);
+const char* decode_engine_census_detail_wide();
+void decode_engine_forget_census_wide();
+void decode_engine_set_trace_wide(void* dev_buffer);
+void decode_engine_set_knobs_wide(int thin, int depth);
+void decode_engine_set_holders_wide(int on);

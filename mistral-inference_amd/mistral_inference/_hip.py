@@ -105,6 +105,7 @@ _SIGS = {
     "mi_debug_set_engine_knobs": (C.c_int, [C.c_int, C.c_int]),
     "mi_debug_engine_sabotage": (C.c_int, [_vp, C.c_int, _vp]),
     "mi_debug_set_engine_holders": (C.c_int, [C.c_int]),
+    "mi_debug_set_engine_variant": (C.c_int, [C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

@@ -116,10 +116,13 @@ def generate(
     assert last_token_prelogits is not None
     fused_greedy = (max_tokens > 0 and hasattr(model, "greedy_session")
                     and (dev.type == "cuda" or (temperature == 0 and getattr(model, "greedy_session_any_device", False)))  # (CPU stand-ins: tests)
-                    and getattr(model, "num_pipeline_ranks", 1) == 1 and getattr(model, "softmax_fp32", True)
+                    and (getattr(model, "num_pipeline_ranks", 1) == 1 or getattr(model, "greedy_session_pp", False))
+                    and getattr(model, "softmax_fp32", True)
                     and getattr(model, "fused_greedy", True))  # (model.fused_greedy = False: the loop below, for A/B)
     if fused_greedy:
-        # One HIP stage: the sample rides on the LM head inside the step (GreedySession) - argmax + log-softmax at temperature
+        # One HIP stage - or pipeline stages, each with its own session; the sample then crosses from the last stage to the
+        # first as 8 bytes per sequence instead of the reference's [B, vocab] logits broadcast (GreedySession) -: the sample
+        # rides on the LM head inside the step (GreedySession) - argmax + log-softmax at temperature
         # 0, the native nucleus draw (csrc/sampling.hip, generate.py:151-170 in one kernel) otherwise - it feeds the next step
         # on the device, and the tokens come back in one copy per CHUNK steps.  Temperature 0: same values as the loop below
         # (token i+1 = first argmax of the logits after token i; its logprob = log_softmax at it).  Temperature > 0: the same
@@ -128,7 +131,13 @@ def generate(
         seed = 0
         if temperature > 0:
             from . import _hip
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            seed_t = torch.randint(0, 2 ** 62, (1,))
+            if getattr(model, "num_pipeline_ranks", 1) > 1:
+                # the reference's ranks stay in step only because they share torch's default seed (generate.py:126 on every
+                # rank); here only the last stage draws, and rank 0's seed is the generation's seed on every stage
+                seed_t = seed_t.to(dev)
+                model.pp_comm.broadcast(seed_t, src=0)
+            seed = int(seed_t.item())
             next_token, first_lp = _hip.sample_top_p(last_token_prelogits.contiguous(), temperature, 0.8, seed=seed, offset=1 << 63)
         else:
             next_token = sample(last_token_prelogits, temperature=0.0, top_p=0.8)

@@ -146,6 +146,19 @@ class HipStackBackend:
             raise RuntimeError(f"persistent decode engine: status 0x{st['status']:x} - {what}.  "
                                "MI_DECODE_ENGINE=0 selects the launch path.")
 
+    # -- hooks of GreedySession (a test backend provides the same three) ------------------------------
+    def session_status(self) -> dict:
+        """Control words of the workspace (synchronises): steps run, sticky engine status, ..."""
+        return _hip.decode_engine_status(self._workspace)
+
+    def prepare_session(self, model: "Transformer", B: int, cache: BufferCache) -> None:
+        self._get_workspace(model, self.plan(model), 1, B, max(cache.cache_sizes))
+
+    def session_disable_engine(self) -> None:
+        """After a raised engine status: clear the word (it poisons the workspace) and take the launch path from now on."""
+        _hip.decode_engine_reset(self._workspace)
+        _hip.set_decode_engine(False)
+
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
         need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
         ws = self._workspace
@@ -190,6 +203,7 @@ class HipStackBackend:
 
 class Transformer(ModelBase):
     supports_prompt_logprobs = True
+    greedy_session_pp = True  # generate(): the fused sampling session also runs across pipeline stages (GreedySession)
 
     def __init__(self, args: TransformerArgs, pipeline_rank: int = 0, num_pipeline_ranks: int = 1,
                  softmax_fp32: bool = True, backend: Optional[Any] = None):
@@ -616,7 +630,15 @@ class GreedySession:
 
     temperature > 0 (`mistral-chat`'s default, reference main.py:105 + generate.py:126,151-170): the same session with the
     argmax replaced by the native nucleus draw (csrc/sampling.hip: one more small kernel behind the LM head inside the same
-    captured step, Philox variate keyed by the seed and the workspace's step counter) - still one native call per token."""
+    captured step, Philox variate keyed by the seed and the workspace's step counter) - still one native call per token.
+
+    PIPELINE STAGES (num_pipeline_ranks > 1; reference transformer.py:195-196,213-214,236-237 per token): every stage runs
+    this session on its own layer range.  Per token: stage r receives the [B, dim] activations of stage r - 1, runs ONE
+    native call, sends them on; the LAST stage's call ends in the sample, and that sample - 8 bytes per sequence - goes
+    back to stage 0 as the next step's input id.  The reference broadcasts the [B, vocab] logits to every rank per token
+    (64 KiB at vocab 32768) and lets every rank sample; here nothing of vocab size crosses a link at decode, and the other
+    ranks learn the tokens (generate() returns them on every rank) from ONE broadcast of the history per collect().
+    With the C-ABI RCCL transport (MI_PP_TRANSPORT=rccl) the hops are stream-ordered and part of the captured step."""
 
     HIST = 1024
     # decode steps per hipGraph launch.  Measured (profiles/EXPERIMENTS.md): 8 steps per graph close the ~9 us gap between two
@@ -625,10 +647,12 @@ class GreedySession:
 
     def __init__(self, model: "Transformer", cache: BufferCache, first_tokens: torch.Tensor, graph: bool = True,
                  temperature: float = 0.0, top_p: float = 0.8, seed: int = 0):
-        assert model.num_pipeline_ranks == 1, "GreedySession runs on a single pipeline stage"
-        assert isinstance(model._backend, HipStackBackend), "the fused greedy step needs the HIP backend"
+        be = model._backend
+        assert hasattr(be, "session_status"), "the fused sampling step needs a backend with a step counter (HipStackBackend)"
         dev = model.device
         self.model, self.cache = model, cache
+        self.rank, self.world = model.pipeline_rank, model.num_pipeline_ranks
+        self.is_last = self.rank == self.world - 1
         B = int(first_tokens.numel())
         self.B = B
         assert cache._seen is not None and len(cache._seen) == B and cache._seen[0] > 0, "prefill the cache first"
@@ -637,9 +661,12 @@ class GreedySession:
                                  hist_tok=torch.zeros((self.HIST, B), dtype=torch.long, device=dev),
                                  hist_lp=torch.zeros((self.HIST, B), dtype=torch.float32, device=dev),
                                  temperature=float(temperature), top_p=float(top_p), seed=int(seed))
-        self.logits = torch.empty((B, model.vocab_size), dtype=torch.float32, device=dev)
+        self.logits = torch.empty((B, model.vocab_size), dtype=torch.float32, device=dev) if self.is_last else None
         self.h = torch.empty((B, model.args.dim), dtype=model.dtype, device=dev)
-        self._use_graph = graph and dev.type == "cuda"
+        from .distributed import RcclComm
+        # hops through torch.distributed are not capturable: such stages step launch by launch (ONE launch on the engine)
+        self._use_graph = (graph and dev.type == "cuda" and isinstance(be, HipStackBackend)
+                           and (self.world == 1 or isinstance(model.pp_comm, RcclComm)))
         self._graphs: dict = {}            # steps per graph -> captured hipGraph
         self._warm = False
         self._base: Optional[int] = None   # value of the workspace's step counter when this session began
@@ -651,17 +678,29 @@ class GreedySession:
         m, cache = self.model, self.cache
         meta = cache.batch_metadata([1] * self.B)
         assert meta.branch == _hip.BRANCH_DECODE
-        m._backend.run_stack(m, self.h, self.buf.tok, meta, cache, self.logits, greedy=self.buf)
+        if self.rank > 0:
+            m.pp_comm.recv(self.h, src=self.rank - 1)
+        ids = self.buf.tok if self.rank == 0 else None
+        m._backend.run_stack(m, self.h, ids, meta, cache, self.logits, greedy=self.buf if self.is_last else None)
+        if not self.is_last:
+            m.pp_comm.send(self.h, dst=self.rank + 1)
+        if self.world > 1:
+            # the sample travels from the last stage to the first: 8 bytes per sequence (the reference: [B, vocab] logits to
+            # every rank, transformer.py:236-237).  Stage 0 receives it into the id buffer its NEXT step reads.
+            if self.is_last:
+                m.pp_comm.send(self.buf.tok, dst=0)
+            elif self.rank == 0:
+                m.pp_comm.recv(self.buf.tok, src=self.world - 1)
 
     def _steps_now(self) -> int:
-        return _hip.decode_engine_status(self.model._backend._workspace)["steps"]
+        return self.model._backend.session_status()["steps"]
 
     def _one_step(self) -> None:
         m, cache = self.model, self.cache
         if not self._warm:  # first step eagerly: sizes the workspace, runs the engine's one-time residency census
             # size the workspace exactly as run_stack will BEFORE reading its step counter: a re-allocation inside the first
             # step would restart the counter at zero and collect() would index the wrong history rows
-            m._backend._get_workspace(m, m._backend.plan(m), 1, self.B, max(cache.cache_sizes))
+            m._backend.prepare_session(m, self.B, cache)
             self._base = self._steps_now()
             self.buf.offset = -self._base  # (mod 2^64) a generation's variates do not depend on what ran on the workspace before
             self._step_eager()
@@ -682,12 +721,21 @@ class GreedySession:
         if g is None:
             torch.cuda.synchronize(self.model.device)
             g = torch.cuda.CUDAGraph()
+            ok, why = True, None
             try:
                 with torch.cuda.graph(g):  # (capture enqueues nothing: the steps themselves are the replays)
                     for _ in range(steps):
                         self._step_eager()
             except RuntimeError as e:  # a runtime that refuses to capture: launch by launch from here on
-                logging.warning("greedy decode step not graph-capturable (%s): continuing eagerly", e)
+                ok, why = False, e
+            if self.world > 1 and torch.distributed.is_initialized():
+                # every stage replays or every stage steps eagerly (a stage that could not capture while its neighbours
+                # replay would post its hops in a different order): agreed over the bootstrap process group
+                flag = torch.tensor([1 if ok else 0], device=self.model.device, dtype=torch.int32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = bool(int(flag.item()))
+            if not ok:
+                logging.warning("decode step not graph-capturable on every stage (%s): continuing eagerly", why)
                 self._use_graph = False
                 return None
             self._graphs[steps] = g
@@ -715,26 +763,37 @@ class GreedySession:
 
     def collect(self, n: Optional[int] = None):
         """(tokens int64 [n, B], logprobs fp32 [n, B]) of the n oldest uncollected steps, on the host side of one
-        synchronisation; verifies that the device really ran them (and re-runs what an engine failure skipped)."""
+        synchronisation; verifies that the device really ran them (and re-runs what an engine failure skipped).  Under
+        pipeline parallelism the last stage's history is broadcast to every stage here (once per collect, not per token)."""
         n = self._pending if n is None else n
         assert 0 < n <= self._pending
         m = self.model
-        ws = m._backend._workspace
-        st = _hip.decode_engine_status(ws)  # synchronises
+        be = m._backend
+        st = be.session_status()  # synchronises
         assert self._base is not None
         done_total = st["steps"] - self._base      # steps the device completed since the session began
         issued_total = self._issued()
-        if st["status"] != 0:
+        status = st["status"]
+        if self.world > 1 and torch.distributed.is_initialized():
+            # a stage that stops while its neighbours wait in a hop would hang the job: everybody learns the worst status
+            flag = torch.tensor([status], device=m.device, dtype=torch.int64)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            worst = int(flag.item())
+            if worst != 0:
+                be.session_disable_engine()
+                self._graphs, self._use_graph = {}, False
+                raise RuntimeError(f"persistent decode engine: status 0x{worst:x} on a pipeline stage; this generation is lost, "
+                                   "the engine is now off for this process and later calls take the launch path")
+        if status != 0:
             missing = issued_total - done_total
-            if st["status"] != 0x700:
+            if status != 0x700:
                 # a bounded wait timed out mid-step: the step's outputs are undefined and a raised status word makes every
                 # later engine launch on this workspace leave at once.  Leave the process usable: clear the word, switch to
                 # the launch path, drop the graphs that hold engine launches - the NEXT generate() runs launch by launch.
-                _hip.decode_engine_reset(ws)
-                _hip.set_decode_engine(False)
+                be.session_disable_engine()
                 self._graphs = {}
                 self._use_graph = False
-                raise RuntimeError(f"persistent decode engine: bounded wait 0x{st['status']:x} timed out; this generation is "
+                raise RuntimeError(f"persistent decode engine: bounded wait 0x{status:x} timed out; this generation is "
                                    "lost (its cache is undefined), the engine is now off for this process and later calls "
                                    "take the launch path")
             logging.warning("persistent decode engine: %d of the GPU's workgroups were not resident together; %d step(s) "
@@ -746,6 +805,10 @@ class GreedySession:
         idx = torch.arange(first, first + n, device=m.device) + self._base
         idx = idx % self.HIST
         toks, lps = self.buf.hist_tok[idx], self.buf.hist_lp[idx]
+        if self.world > 1:  # (the step counters of the stages run in lockstep, but only the last stage's rings hold samples)
+            toks, lps = toks.contiguous(), lps.contiguous()
+            m.pp_comm.broadcast(toks, src=self.world - 1)
+            m.pp_comm.broadcast(lps, src=self.world - 1)
         if bool((toks == 0x7FFFFFFF).any()):
             # the argmax reductions start from "no index yet" and a row of NaN logits never replaces it (torch.argmax would
             # return the NaN's position): report what happened instead of the IndexError the next step's embedding raises
@@ -764,8 +827,7 @@ class GreedySession:
         """The device state is that of the first failed step (nothing was written since): clear the status, switch
         this process to the launch path and run the `missing` steps again."""
         m, cache = self.model, self.cache
-        _hip.decode_engine_reset(m._backend._workspace)
-        _hip.set_decode_engine(False)
+        m._backend.session_disable_engine()
         self._graphs = {}  # they hold engine launches
         cache._seen = [p - missing for p in cache._seen]
         for _ in range(missing):

@@ -61,6 +61,9 @@ FILE_VARIANTS = {
     "e_noslp": ("decode_engine.hip", ("-fno-slp-vectorize",)),
     "e_nounroll": ("decode_engine.hip", ("-fno-unroll-loops",)),
     "e_relaxed_occ": ("decode_engine.hip", ("-mllvm", "-amdgpu-schedule-relaxed-occupancy=1")),
+    # the stamp sites again, as a one-object variant (round 4: PMC counters of both builds, scripts/engine_pmc.sh)
+    "e_trace0": ("decode_engine.hip", ("-DENG_TRACE=0",)),
+    "e_trace2": ("decode_engine.hip", ("-DENG_TRACE=2",)),
     # launch path (Nemo dims, batch > 1): the same strategy for the GEMV / decode-attention sources
     "l_gemv_mmc": ("gemv.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
     "l_attn_mmc": ("attn_decode.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
@@ -94,6 +97,7 @@ def build_file_variant(name, src, flags):
     hipcc = b._hipcc()
     subprocess.run([hipcc, *b.FLAGS, *b.PER_FILE_FLAGS.get(src, []), *flags, "-c", os.path.join(b.CSRC, src), "-o", o], check=True)
     objs = [o if s == src else os.path.join(b.OBJ, s.replace(".hip", ".o")) for s in b.SOURCES]
+    objs += [os.path.join(b.OBJ, v) for v in b.VARIANT_OBJECTS]  # (the wide engine object: always the main build's)
     lib = os.path.join(ROOT, "lib", "variants", f"libmistral_hip_{name}.so")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", lib], check=True)
     return lib

@@ -20,7 +20,8 @@ SEED = 17  # chosen with `python tests/moe_depth_util.py`: the closest router ca
 P8X22B_3L = dict(dim=6144, n_layers=3, head_dim=128, hidden_dim=16384, n_heads=48, n_kv_heads=8, norm_eps=1e-5,
                  vocab_size=2048, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2))
 PROMPT_22B, STEPS_22B = 12, 3
-SEED_22B = 9  # first seed of the search without a router near-tie: closest call 3.66 bf16 ulp
+SEED_22B = 9  # no router near-tie on the build container (closest call 3.66 bf16 ulp); the GPU box's host arithmetic differs
+# in the last bit (1.84 ulp there): the test compares the rows in front of the first near-tie of ITS oracle run
 
 
 def _lin(o, i, g):
@@ -58,6 +59,7 @@ def oracle_run(seed=SEED, sink=None, p=P8X7B_4L, prompt=PROMPT, steps=STEPS):
     ids = torch.randint(0, V, (prompt + steps,), generator=torch.Generator().manual_seed(seed + 100))
     h_pre, h_dec = None, [None] * steps
     min_gap = float("inf")
+    tok_gap = torch.full((prompt + steps,), float("inf"))  # per token (prompt rows, then decode rows): min over the layers
     for l in range(L):
         w = layer_weights(l, p, g)
         if sink:
@@ -73,12 +75,17 @@ def oracle_run(seed=SEED, sink=None, p=P8X7B_4L, prompt=PROMPT, steps=STEPS):
         h_pre = om.forward_partial(ids[:prompt], [prompt], oc, h_in=h_pre)
         h_dec = [om.forward_partial(ids[prompt + s:prompt + s + 1], [1], oc, h_in=h_dec[s]) for s in range(steps)]
         trace, mo.ROUTER_TRACE = mo.ROUTER_TRACE, None
-        for lg in trace:
+        row = 0
+        for lg in trace:  # one entry per forward call of this layer: the prompt, then each decode step
             srt = torch.sort(lg, dim=1, descending=True).values
             ulp = srt[:, 1].abs().clamp(min=1e-3) * 2.0 ** -7
-            min_gap = min(min_gap, float(((srt[:, 1] - srt[:, 2]) / ulp).min()))
+            gaps = (srt[:, 1] - srt[:, 2]) / ulp
+            min_gap = min(min_gap, float(gaps.min()))
+            tok_gap[row:row + gaps.numel()] = torch.minimum(tok_gap[row:row + gaps.numel()], gaps)
+            row += gaps.numel()
         del w, om
     logits = F.linear(torch.cat([h_pre] + h_dec), out_w).float()
+    oracle_run.token_gaps = tok_gap
     return ids, logits, min_gap
 
 

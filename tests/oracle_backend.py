@@ -9,10 +9,25 @@ import mistral_oracle as mo
 
 
 class OracleStackBackend:
+    HIST_BRANCH_DECODE = 2  # mi_branch MI_BRANCH_DECODE
+
+    def __init__(self):
+        self.steps = 0  # decode-branch calls so far: the workspace's step counter of the HIP backend (status word 5)
+
     def invalidate(self):
         pass
 
-    def run_stack(self, model, h, input_ids, meta, cache, logits):
+    # -- the three hooks GreedySession needs from a backend (HipStackBackend: the workspace's control words)
+    def session_status(self):
+        return {"steps": self.steps, "status": 0, "arrivals": 0, "engine_launches": 0}
+
+    def prepare_session(self, model, B, cache):
+        pass
+
+    def session_disable_engine(self):
+        pass
+
+    def run_stack(self, model, h, input_ids, meta, cache, logits, greedy=None):
         a = model.args
         oargs = mo.OracleArgs(dim=a.dim, n_layers=a.n_layers, head_dim=a.head_dim, hidden_dim=a.hidden_dim,
                               n_heads=a.n_heads, n_kv_heads=a.n_kv_heads, norm_eps=a.norm_eps, vocab_size=a.vocab_size,
@@ -45,3 +60,14 @@ class OracleStackBackend:
         if logits is not None:
             logits.copy_(F.linear(out, om.w["output.weight"]).float())
         h.copy_(out)
+        if meta.branch == self.HIST_BRANCH_DECODE:
+            self.steps += 1
+        if greedy is not None:  # mi_batch_t.greedy_token & co. (ABI v4): argmax + log-softmax behind the LM head, history ring
+            assert logits is not None and greedy.temperature == 0
+            tok = torch.argmax(logits, dim=-1)
+            lp = torch.log_softmax(logits, dim=-1).gather(1, tok[:, None])[:, 0]
+            greedy.tok.copy_(tok)
+            greedy.lp.copy_(lp)
+            row = (self.steps - 1) % greedy.hist_tok.shape[0]
+            greedy.hist_tok[row].copy_(tok)
+            greedy.hist_lp[row].copy_(lp)

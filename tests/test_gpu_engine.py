@@ -215,6 +215,59 @@ def test_engine_bit_equal_launch_path(name):
         assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
 
 
+# The WIDE build of the engine (csrc/decode_engine.hip compiled with -DENG_WIDE=1: GQA ratio 4 and 6, a 7-fill ring, rows that
+# are not a multiple of 4 pieces streamed as contiguous units).  mi_debug_set_engine_variant(1) makes it the first choice, so
+# its code paths run at sizes the suite can afford; the first three shapes are declined by the shipped build anyway.
+WIDE_SHAPES = {
+    # Mixtral-8x22B in small: GQA ratio 6 (48 / 8 heads), every row a multiple of 4 pieces, top-2 MoE
+    "gqa6_moe_rows_of_4": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=48, n_kv_heads=8, norm_eps=1e-5,
+                               vocab_size=1000, sliding_window=48, num_experts=4, num_experts_per_tok=2),
+    # Mistral-Nemo's rows: dim 5120 = 10 pieces (contiguous units of 20 and 40 pieces), n_heads * 128 != dim
+    "rows_of_10_pieces": dict(dim=5120, n_layers=2, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
+                              vocab_size=1002, sliding_window=48),
+    # GQA ratio 6 dense, odd piece counts everywhere (dim 2560 = 5, Wo rows 1536 = 3, hidden 1536 = 3): the unaligned tails of
+    # a contiguous unit go piece by piece
+    "gqa6_rows_of_5_and_3": dict(dim=2560, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=12, n_kv_heads=2, norm_eps=1e-5,
+                                 vocab_size=770, sliding_window=None),
+    # shapes the shipped build takes as well, forced through the wide one: the 7-fill ring under the shipped row layout,
+    # a ring longer than the LDS ring (K/V pieces streamed with per-piece bookkeeping), MoE at GQA ratio 4
+    "gqa4_window_wraps": SHAPES["gqa4_window_wraps"],
+    "ring_longer_than_lds": SHAPES["ring_longer_than_lds"],
+    "moe_8_experts_top2": SHAPES["moe_8_experts_top2"],
+    "rows_of_6_and_3_pieces": dict(SHAPES["rows_of_6_and_3_pieces"], n_heads=24, n_kv_heads=6),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE_SHAPES))
+def test_wide_engine_build_bit_equal_launch_path(name):
+    from mistral_inference import _hip
+    p = WIDE_SHAPES[name]
+    args = mo.OracleArgs(**p)
+    m, _ = _model(args, seed=17)
+    W = p["sliding_window"] if isinstance(p["sliding_window"], int) else 10 ** 9
+    prompt_len, steps = (40, 12) if W < 100 else (300, 8)
+    if name == "ring_longer_than_lds":
+        prompt_len, steps = 8290, 6
+    if name == "rows_of_6_and_3_pieces":
+        prompt_len = 57
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(3)).cuda()
+    prev = _hip.lib().mi_debug_set_engine_variant(1)
+    try:
+        ref, ref_rings, st0 = _run(m, ids, prompt_len, steps, engine=False)
+        got, got_rings, st1 = _run(m, ids, prompt_len, steps, engine=True)
+        graph, _, st2 = _run(m, ids, prompt_len, steps, engine=True, graph=True)
+    finally:
+        _hip.lib().mi_debug_set_engine_variant(prev)
+    assert st1["status"] == 0 and st1["abort"] == 0 and st2["status"] == 0, (st1, st2)
+    assert st1["engine_launches"] - st0["engine_launches"] >= steps   # an engine build really ran (for the first three: the wide one)
+    for i, (a, b, c) in enumerate(zip(ref, got, graph)):
+        assert torch.isfinite(b).all(), i
+        assert torch.equal(a, b), (name, i, float((a - b).abs().max()))
+        assert torch.equal(a, c), (name, "graph", i)
+    for l, ((k0, v0), (k1, v1)) in enumerate(zip(ref_rings, got_rings)):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
+
+
 def test_engine_right_after_a_one_token_prompt():
     """kv_len = 2, 3, ...: every split but the first is empty, the current slot is the only other key."""
     p = SHAPES["gqa4_window_wraps"]

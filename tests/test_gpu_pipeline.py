@@ -1,6 +1,7 @@
-"""The HIP pipeline path with 2 ranks: real kernels, per-rank layer ranges, device-tensor send/recv and the logits
-broadcast.  Both ranks share the one GPU of the test box, so the transport is gloo (RCCL refuses two ranks on one
-device); on a multi-GPU node the same code runs over "nccl" = RCCL (bench.py --gpus N)."""
+"""The HIP pipeline path with 2 ranks: real kernels, per-rank layer ranges, device-tensor send/recv, the prompt's
+log-probability broadcast and the decode loop's GreedySession per stage (activations forward, the sample back to stage 0 as 8
+bytes).  On a 1-GPU box both ranks share the GPU and the transport is gloo (RCCL refuses two ranks on one device); the same
+cases are COLLECTED for "nccl" = RCCL with both transports and run wherever two GPUs are visible (bench.py --gpus N)."""
 import os
 import sys
 
@@ -13,11 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, tmp, q):
+def _worker(rank, world, port, name, tmp, q, backend="gloo", transport="torch"):
     for p in (os.path.join(ROOT, "mistral-inference_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MI_PP_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = "cuda:0" if backend == "gloo" else f"cuda:{rank}"   # gloo: both ranks share the box's one GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from golden_util import Case
         from hip_util import write_checkpoint
@@ -28,23 +32,49 @@ def _worker(rank, world, port, name, tmp, q):
         if rank == 0:
             write_checkpoint(folder, case.args, case.weights())
         dist.barrier()
-        m = Transformer.from_folder(folder, max_batch_size=case.max_batch_size, num_pipeline_ranks=world, device="cuda:0",
+        m = Transformer.from_folder(folder, max_batch_size=case.max_batch_size, num_pipeline_ranks=world, device=dev,
                                     dtype=torch.bfloat16)
+        comm, big = m.pp_comm, []
+        B, V = len(case.prompts), case.args.vocab_size
+
+        class Recorder:  # what crosses between the stages at decode
+            def send(self, t, dst):
+                comm.send(t, dst)
+
+            def recv(self, t, src):
+                comm.recv(t, src)
+
+            def broadcast(self, t, src):
+                if tuple(t.shape) == (B, V):
+                    big.append(tuple(t.shape))
+                comm.broadcast(t, src)
+        m._pp_comm = Recorder()
         prompts = case.prompts if rank == 0 else [[0] * len(p) for p in case.prompts]
         toks, lps = generate(prompts, m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size)
-        q.put((rank, toks, lps, m.n_local_layers, sorted(m.layers.keys())))
+        q.put((rank, toks, lps, m.n_local_layers, sorted(m.layers.keys()), len(big), type(comm).__name__))
     finally:
         dist.destroy_process_group()
 
 
+def _two_gpus():
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.parametrize("backend,transport", [
+    ("gloo", "torch"),
+    # collected everywhere, run where two GPUs exist (the driver's 8-GPU node): the reference's own transport over RCCL ...
+    pytest.param("nccl", "torch", marks=pytest.mark.skipif(not _two_gpus(), reason="needs 2 GPUs (RCCL refuses two ranks on one device)")),
+    # ... and the stream-ordered C-ABI communicator (mi_rccl_send / recv / bcast), hops captured in the decode hipGraph
+    pytest.param("nccl", "rccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs 2 GPUs (RCCL refuses two ranks on one device)")),
+])
 @pytest.mark.parametrize("name", ["dense_bf16", "swa_chunk_bf16", "moe_bf16"])
-def test_two_stage_pipeline_on_hip(name, tmp_path):
+def test_two_stage_pipeline_on_hip(name, backend, transport, tmp_path):
     from golden_util import Case
     case = Case(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 500) + sum(map(ord, name)) % 97  # a fresh port per case (no TIME_WAIT reuse)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, str(tmp_path), q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 500) + (sum(map(ord, name + backend + transport)) % 97)  # a fresh port per case (no TIME_WAIT reuse)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, str(tmp_path), q, backend, transport)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in procs)
@@ -52,9 +82,11 @@ def test_two_stage_pipeline_on_hip(name, tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     ref_toks, ref_lps = case.tokens(), case.logprobs()
-    (_, t0, lp0, n0, k0), (_, t1, lp1, n1, k1) = res
+    (_, t0, lp0, n0, k0, big0, comm0), (_, t1, lp1, n1, k1, big1, comm1) = res
     assert (n0, n1) == (1, 1) and k0 == ["0"] and k1 == ["1"]
-    assert t0 == t1  # every rank samples from the same broadcast logits
+    assert t0 == t1  # the last stage's samples, broadcast once per collect()
+    assert big0 == 0 and big1 == 0   # no [B, vocab] logits broadcast at decode: the sample crosses as 8 bytes per sequence
+    assert comm0 == comm1 == ("RcclComm" if transport == "rccl" else "TorchDistComm")
     for b, (mine, ref) in enumerate(zip(t0, ref_toks)):
         n = next((i for i, (x, y) in enumerate(zip(mine, ref)) if x != y), len(ref))
         assert n >= 1, (name, b, mine, ref)
