@@ -160,7 +160,13 @@ struct Shared {
   gu64* trace;         // optional timeline buffer
 };
 
+// ENG_TRACE_MASK (variant builds only, scripts/build_variants.py e_mask_*): bit ev = 0 compiles stamp site `ev` out - the
+// bisect of WHICH sites the kernel's speed depends on (profiles/EXPERIMENTS.md round 4).  `ev` is a constant at every call.
+#ifndef ENG_TRACE_MASK
+#define ENG_TRACE_MASK 0xffffffffu
+#endif
 __device__ __forceinline__ void trace_ev(const Shared& sh, int c, int layer, int ev, bool who) {
+  if (!((ENG_TRACE_MASK >> ev) & 1u)) return;
 #if ENG_TRACE == 1
   if (sh.trace && who) sh.trace[((size_t)c * ENG_MAXL + layer) * TR_EVENTS + ev] = __builtin_amdgcn_s_memrealtime();
 #elif ENG_TRACE == 2

@@ -64,6 +64,13 @@ FILE_VARIANTS = {
     # the stamp sites again, as a one-object variant (round 4: PMC counters of both builds, scripts/engine_pmc.sh)
     "e_trace0": ("decode_engine.hip", ("-DENG_TRACE=0",)),
     "e_trace2": ("decode_engine.hip", ("-DENG_TRACE=2",)),
+    # which stamp sites matter (consumer events 0-17, loader events 18-25; bit set = site compiled in)
+    "e_mask_loader": ("decode_engine.hip", ("-DENG_TRACE_MASK=0x03fc0000u",)),
+    "e_mask_cons": ("decode_engine.hip", ("-DENG_TRACE_MASK=0x0003ffffu",)),
+    "e_mask_cons_lo": ("decode_engine.hip", ("-DENG_TRACE_MASK=0x000001ffu",)),
+    "e_mask_cons_hi": ("decode_engine.hip", ("-DENG_TRACE_MASK=0x0003fe00u",)),
+    "e_mask_even": ("decode_engine.hip", ("-DENG_TRACE_MASK=0x01555555u",)),
+    "e_mask_odd": ("decode_engine.hip", ("-DENG_TRACE_MASK=0x02aaaaaau",)),
     # launch path (Nemo dims, batch > 1): the same strategy for the GEMV / decode-attention sources
     "l_gemv_mmc": ("gemv.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
     "l_attn_mmc": ("attn_decode.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
@@ -107,7 +114,7 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "lib", "variants"), exist_ok=True)
     b.build(verbose=False)
     for name, (src, flags) in FILE_VARIANTS.items():
-        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_") or "engine_flags" in sys.argv[1:] and name.startswith("e_") or "launch_flags" in sys.argv[1:] and name.startswith("l_"):
+        if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_") or "engine_flags" in sys.argv[1:] and name.startswith("e_") and not name.startswith("e_mask") or "engine_masks" in sys.argv[1:] and name.startswith("e_mask") or "launch_flags" in sys.argv[1:] and name.startswith("l_"):
             print(name, build_file_variant(name, src, flags), flush=True)
     for name, flags in VARIANTS.items():
         if name not in sys.argv[1:] and "engine" not in sys.argv[1:]:

@@ -438,21 +438,21 @@ def test_mixtral_8x22b_dims_3_layers_vs_oracle():
     # torch.topk's order on a near-tie is unspecified, and this host's bf16 matmul may round the router logits differently
     # from the build container's: rows from the first near-tie on (a picked-expert swap reaches every later token through
     # the K/V of the next layer) are not compared.  On the build container no row of this seed is near a tie.
-    near = (mu.oracle_run.token_gaps <= 2.5).nonzero()
-    n_ok = int(near[0]) if near.numel() else T + steps
-    assert n_ok >= 6, f"router near-tie at token {n_ok} of the oracle run (gap {gap:.2f} ulp): pick another seed (python tests/moe_depth_util.py 0 8x22b)"
+    keep = mu.clean_rows(mu.oracle_run.token_gaps)
+    assert int(keep.sum()) >= 5, (f"only {int(keep.sum())} rows of this host's oracle run are free of a router near-tie (closest call "
+                                  f"{gap:.2f} ulp): pick another seed (python tests/moe_depth_util.py 0 8x22b all)")
     model._weights_changed()
     cache = BufferCache(p["n_layers"], 1, T + steps + 2, 8, 128, None, device="cuda", dtype=BF)
     cache.reset()
     with torch.inference_mode():
         got = [model.forward(ids[:T].cuda(), [T], cache).cpu()]
         got += [model.forward(ids[T + i:T + i + 1].cuda(), [1], cache).cpu() for i in range(steps)]
-    got = torch.cat(got)[:n_ok]
-    ref = ref[:n_ok]
+    got_all, ref_all = torch.cat(got), ref
+    got, ref = got_all[keep], ref_all[keep]
     d = (got - ref).abs()
-    print(f"\nMixtral-8x22B dims x 3 layers: max|HIP - oracle_bf16| {float(d.max()):.4f} over the first {n_ok} of {T + steps} rows "
-          f"(prefill rows {float(d[:T].max()):.4f}" + (f", decode rows {float(d[T:].max()):.4f}" if n_ok > T else "") +
-          f"), mean {float(d.mean()):.5f}, |logit|max {float(ref.abs().max()):.2f}, min router gap {gap:.1f} ulp")
+    print(f"\nMixtral-8x22B dims x 3 layers: max|HIP - oracle_bf16| {float(d.max()):.4f} over the {int(keep.sum())} of {T + steps} rows "
+          f"free of a router near-tie ({int(keep[T:].sum())} of them decode rows), mean {float(d.mean()):.5f}; all rows: max "
+          f"{float((got_all - ref_all).abs().max()):.4f}; |logit|max {float(ref_all.abs().max()):.2f}, closest router call {gap:.1f} ulp")
     assert float(d.max()) <= 4e-2 and float(d.mean()) <= 3e-3
     assert float((got.argmax(1) == ref.argmax(1)).float().mean()) >= 0.9
     del model

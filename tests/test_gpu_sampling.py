@@ -70,7 +70,7 @@ def test_fixed_uniforms_match_the_inverse_cdf_of_the_reference_distribution(name
     want = order[pos]
     clear = ~near
     # (a nucleus of thousands of tokens has thousands of CDF steps: more variates fall within 1e-5 of one)
-    assert int(clear.sum()) >= (0.97 if n_kept < 2000 else 0.85) * n_u, (name, int(clear.sum()), n_kept)
+    assert int(clear.sum()) >= 0.9 * n_u, (name, int(clear.sum()), n_kept)
     if not slack:
         # exact ties in probability: the kernel orders ties by ascending token id (the oracle's stable sort does too)
         assert torch.equal(tok[clear], want[clear]), (name, int((tok[clear] != want[clear]).sum()))
