@@ -28,9 +28,11 @@ int mi_debug_set_engine_knobs(int thin, int depth);
 /* holder waves on (1) / off (0) / environment default (-1); results never depend on it (bit-identical either way) */
 int mi_debug_set_engine_holders(int on);
 /* The engine source is compiled twice: the shipped build (the headline shapes) and a "wide" build for the shapes that one
- * declines (GQA ratio 6 with a 32 KiB hid vector; rows of an even number of pieces that is not a multiple of 4).  0 (default;
- * environment MI_ENGINE_VARIANT): shipped build first, wide build as the fallback; 1: the wide build wherever it applies, so
- * that tests can compare its code paths with the launch path at small sizes.  Returns the previous setting. */
+ * declines (GQA ratio 6 with a 32 KiB hid vector; rows of an even number of pieces that is not a multiple of 4) and for MoE
+ * models (the batched router).  0 (default; environment MI_ENGINE_VARIANT): dense models the shipped build first, MoE models
+ * the wide build first; 1: the wide build wherever it applies (tests compare its code paths with the launch path at small
+ * sizes; also admits shapes that measured slower than the launch path); 2: the shipped build first for every model.
+ * Returns the previous setting. */
 int mi_debug_set_engine_variant(int variant);
 /* Test hook: the next `launches` engine launches on this workspace (hipGraph replays included: the count lives in the
  * workspace) wait for one workgroup more than exist, i.e. fail their residency gate after its ~50 ms bound exactly as a

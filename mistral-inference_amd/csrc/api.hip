@@ -49,7 +49,7 @@ constexpr size_t TICKET_BYTES = 4096;  // first words: control block of the pers
 // 1 (default): batch-1 decode steps of dense models run on the persistent engine (decode_engine.hip) when the shapes
 // allow it; 0: always the launch path.  MI_DECODE_ENGINE sets the initial value, mi_set_decode_engine changes it.
 int g_engine_mode = -1;
-int g_engine_variant = -1;  // 0 (default): the shipped engine build first, the wide build for what it declines; 1: wide first
+int g_engine_variant = -1;  // 0 (default): the shipped engine build first (MoE: the wide build first); 1: wide first; 2: shipped first
 int engine_variant() {
   if (g_engine_variant < 0) {
     const char* e = getenv("MI_ENGINE_VARIANT");
@@ -506,7 +506,7 @@ int mi_debug_set_engine_holders(int on) {
 }
 int mi_debug_set_engine_variant(int variant) {
   const int prev = engine_variant();
-  g_engine_variant = variant != 0;
+  g_engine_variant = variant < 0 || variant > 2 ? 0 : variant;
   return prev;
 }
 int mi_debug_set_engine_trace(void* dev_buffer) {
@@ -583,6 +583,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     }
     pr.granules = ws.gran; pr.granule_bytes = ws.gran_bytes; pr.ctrl = engine_ctrl;
     pr.E = m->num_experts; pr.top_k = m->top_k;
+    pr.forced = engine_variant() == 1;
     bool dense_ok = true;
     for (int l = 0; l < m->n_layers; ++l)
       dense_ok = dense_ok && (m->num_experts ? (m->layers[l].gate && m->layers[l].expert_w_dev)
@@ -590,8 +591,12 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     // the shipped build of the engine first (the headline shapes); the "wide" build of the same source for what it declines
     // (GQA ratio 6 + 32 KiB hid vector: Mixtral-8x22B; rows of 10 pieces: Mistral-Nemo).  g_engine_variant = 1 (tests) prefers
     // the wide build wherever it applies, so that its code paths can be compared bit for bit at small sizes.
+    // MoE models take the wide build wherever it applies: it carries the round-4 router (two experts per wave, batched loads:
+    // -8..-11 us per layer), which the shipped object - frozen, see decode_engine.hip - does not.  Variant 2 = shipped build
+    // first for every model (the A/B of that choice).
     const bool wide_ok = dense_ok && decode_engine_applicable_wide(pr, nullptr, 0);
-    const bool base_ok = dense_ok && !(engine_variant() == 1 && wide_ok) && decode_engine_applicable(pr, nullptr, 0);
+    const bool wide_first = engine_variant() == 1 || (engine_variant() == 0 && m->num_experts > 0);
+    const bool base_ok = dense_ok && !(wide_first && wide_ok) && decode_engine_applicable(pr, nullptr, 0);
     if (base_ok || wide_ok) {
       bool declined = false;
       MI_TRY(hip_rc(base_ok ? launch_decode_engine(pr, s, &declined) : launch_decode_engine_wide(pr, s, &declined), "decode engine"));

@@ -849,6 +849,68 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
   }
   cs.cbar();
   // ---- router (moe_router_kernel: one wave per expert there, experts w, w + 4, ... per wave here)
+#if ENG_WIDE
+  // Round 4 (timeline of an 8x7B / 8x22B stage, profiles/r04_engine_trace_*): the form below - gate row and norm weights
+  // fetched INSIDE the per-piece loop, one expert after the other - took 11-15 us per layer, a chain of 16-24 dependent L2
+  // round trips during which the loader has nothing to stream (it waits for this decision).  Here a wave handles its two
+  // experts together, four pieces per batch: gate rows of both experts and the norm weights of a batch are in flight at once
+  // (2-3 round trips in all), the normalised activations are computed once for both experts.  Per expert the fmaf chain runs
+  // over the same elements in the same order - bit-identical.
+  {
+    const bf16_t* gate = L.w1;
+    float ss = 0.f;
+    for (int pp = lane; pp < np; pp += 64) {
+      const u32x4 v = lds16(raw + pp * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = bf_lo(v[i]), x1 = bf_hi(v[i]);
+        ss = fmaf(x0, x0, ss);
+        ss = fmaf(x1, x1, ss);
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+    constexpr int CH = 4;
+    for (int ea = w; ea < a.E; ea += 2 * NCONS) {
+      const int eb = ea + NCONS;
+      const bool two = eb < a.E;
+      const bf16_t* ga = gate + (size_t)ea * a.D;
+      const bf16_t* gb = gate + (size_t)(two ? eb : ea) * a.D;
+      float acc_a = 0.f, acc_b = 0.f;
+      for (int p0 = lane; p0 < np; p0 += 64 * CH) {
+        u32x4 va[CH], vb[CH], wn[CH], xv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int pp = min(p0 + 64 * i, np - 1);  // (np is a multiple of 64: a batch is inside the vector or outside it for the whole wave)
+          va[i] = ld16(ga + pp * 8);
+          vb[i] = ld16(gb + pp * 8);
+          wn[i] = ld16(L.fn + pp * 8);
+          xv[i] = lds16(raw + pp * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          if (p0 + 64 * i < np) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float x0 = bf_round(bf_round(bf_lo(xv[i][cc]) * inv) * bf_lo(wn[i][cc]));
+              const float x1 = bf_round(bf_round(bf_hi(xv[i][cc]) * inv) * bf_hi(wn[i][cc]));
+              acc_a = fmaf(bf_lo(va[i][cc]), x0, acc_a);
+              acc_a = fmaf(bf_hi(va[i][cc]), x1, acc_a);
+              acc_b = fmaf(bf_lo(vb[i][cc]), x0, acc_b);
+              acc_b = fmaf(bf_hi(vb[i][cc]), x1, acc_b);
+            }
+          }
+        }
+      }
+      acc_a = wave_sum(acc_a);
+      acc_b = wave_sum(acc_b);
+      if (lane == 0) {
+        reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[ea] = bf_round(acc_a);
+        if (two) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[eb] = bf_round(acc_b);
+      }
+    }
+  }
+#else
   {
     const bf16_t* gate = L.w1;  // (MoE layers carry the gate in the w1 slot and the expert table in the w2 slot)
     float ss = 0.f;
@@ -882,6 +944,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
       if (lane == 0) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[e] = bf_round(acc);
     }
   }
+#endif
   cs.cbar();
   int eA, eB;
   float wA, wB;
@@ -1114,6 +1177,52 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       sh.ctl[C_GATHERING] = 0;
       trace_ev(sh, c, l, 5, trc);
       const int gl = lane >> 4, dl = lane & 15;
+#if ENG_WIDE
+      // GQA ratio 6 (Mixtral-8x22B): six heads' q rows and running sums in one pass need ~140 live registers on top of the
+      // kernel's standing state and the instantiation spills 45 of them - the attention pieces of a layer took 9.1 us
+      // against 3.7 us at ratio 4 (profiles/r04_engine_trace_8x22b_stage7_wide.txt).  While the pieces all sit in the ring
+      // (not `streamed`) the heads are served in two passes of three over the same ring slots: heads do not interact in
+      // reduce_slot, so the partials are the same bits.
+      if constexpr (R == 6) {
+        {  // (never `streamed`: decode_engine_applicable declines rings whose split does not fit the LDS ring at this ratio)
+          if (p.n_att) cs.need_fill(g + 2 * p.n_att - 1);
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            constexpr int RP = 3;
+            const int r_off = pass * RP;
+            float qh[RP][8];
+            {
+              u32x4 qraw[RP];
+#pragma unroll
+              for (int r = 0; r < RP; ++r) qraw[r] = lds16(q_lds + (r_off + r) * 64 + dl * 4);
+              load_q<RP>(qh, qraw);
+            }
+            State<RP> sp;
+            init_state<RP>(sp);
+            for (int j = w; j < p.n_att; j += NCONS) {
+              const uint32_t gk = g + 2 * j;
+              u32x4 kraw = lds16(sh.ring + RING_IDX(sh, gk) * PIECE + lane * 16);
+              u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gk + 1) * PIECE + lane * 16);
+              const int slot = p.s_begin + 4 * j + gl;
+              if (slot == p.cur_slot) {
+                kraw = lds16(kn_lds + dl * 4);
+                vraw = lds16(vn_lds + dl * 4);
+              }
+              const bool valid = slot < p.s_end;
+              if (!valid) {
+                kraw = u32x4{0u, 0u, 0u, 0u};
+                vraw = u32x4{0u, 0u, 0u, 0u};
+              }
+              reduce_slot<RP>(sp, qh, kraw, vraw, valid);
+            }
+            wave_state_to_lds_heads<RP, R>(sp, w, lane, r_off, sm_m, sm_l, sm_acc);
+          }
+          g += 2 * p.n_att;
+          cs.set_done(g);
+          trace_ev(sh, c, l, 6, trc);
+        }
+      } else {
+#endif
       float qf[R][8];
       {
         u32x4 qraw[R];
@@ -1152,6 +1261,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       cs.set_done(g);
       trace_ev(sh, c, l, 6, trc);
       wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
+#if ENG_WIDE
+      }
+#endif
       cs.cbar();
       const uint32_t tp = tag_of(l, 2);
       const size_t bh = p.kvh;  // batch 1
@@ -1601,9 +1713,11 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
 #if !ENG_WIDE
   if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
 #else
-  if ((pr.D >> 9) & 1) {  // a contiguous unit must keep the stream 4-aligned often enough to matter: even piece counts only
-    if (pr.D > 3072) return no("odd number of 512-element pieces per row at a large dim");
-  }
+  // The wide build streams such rows as contiguous units (Loader::unit) - the third form tried for the Nemo dims, and still
+  // slower than the launch path there: 5.47 vs 4.94 ms per step at an 8192-token context (profiles/EXPERIMENTS.md round 4;
+  // 2-piece groups: 7.6-8.0 ms, 4 + 4 + 2 groups: 5.62 ms).  Declined unless the caller forces the wide build (traces, tests).
+  if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0 && !pr.forced) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
+  if (((pr.D >> 9) & 1) && pr.D > 3072) return no("odd number of 512-element pieces per row at a large dim");
 #endif
   if (pr.V % 2) return no("odd vocab");
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
@@ -1639,6 +1753,10 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   for (int l = 0; l < pr.n_layers; ++l) {
     const int ns = attn_decode_splits(pr.W[l]);
     if (ns > 32 || Hs * ns > NB) return no("more attention work items than CUs");
+#if ENG_WIDE
+    // ratio 6 serves its heads in two passes over K/V pieces that must all sit in the LDS ring (run_consumer)
+    if (R == 6 && 2 * ((attn_core::split_chunk(pr.W[l], ns) + 3) >> 2) > (RING_FILLS - 2) * FILL) return no("GQA ratio 6: ring longer than 5120 slots");
+#endif
   }
   return true;
 }

@@ -261,6 +261,7 @@ struct EngProblem {
   void* granules;
   size_t granule_bytes;
   uint32_t* ctrl;
+  int forced;                // mi_debug_set_engine_variant(1): take shapes that measured slower than the launch path too (traces, tests)
 };
 static_assert(sizeof(EngArgs) <= 4096, "EngArgs must fit the kernel-argument segment");
 size_t decode_engine_granule_bytes(int D, int H, int Hkv, int F, int maxW);

@@ -151,13 +151,25 @@ class HipStackBackend:
         """Control words of the workspace (synchronises): steps run, sticky engine status, ..."""
         return _hip.decode_engine_status(self._workspace)
 
+    _engine_suspended = False  # process-wide: a residency failure switched the engine off until the next session probes again
+
     def prepare_session(self, model: "Transformer", B: int, cache: BufferCache) -> None:
+        if HipStackBackend._engine_suspended:
+            # A co-tenant or a CU mask made an earlier step's residency gate fail and the rest of THAT generation ran on the
+            # launch path.  Conditions change: a new session forgets the verdict, switches the engine back on and lets the
+            # library's census (one probe launch at first use, include/mistral_hip.h) decide again - if it fails, mi_forward
+            # takes the launch path on its own; if the gate of a step fails again, collect() suspends the engine again.
+            HipStackBackend._engine_suspended = False
+            _hip.check(_hip.lib().mi_decode_engine_census(1), "mi_decode_engine_census")
+            _hip.set_decode_engine(True)
         self._get_workspace(model, self.plan(model), 1, B, max(cache.cache_sizes))
 
     def session_disable_engine(self) -> None:
-        """After a raised engine status: clear the word (it poisons the workspace) and take the launch path from now on."""
+        """After a raised engine status: clear the word (it poisons the workspace) and take the launch path for the rest of this
+        generation; the next session probes the device again (prepare_session)."""
         _hip.decode_engine_reset(self._workspace)
         _hip.set_decode_engine(False)
+        HipStackBackend._engine_suspended = True
 
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
         need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
@@ -797,7 +809,8 @@ class GreedySession:
                                    "lost (its cache is undefined), the engine is now off for this process and later calls "
                                    "take the launch path")
             logging.warning("persistent decode engine: %d of the GPU's workgroups were not resident together; %d step(s) "
-                            "re-run on the launch path (engine off for this process)", st["arrivals"], missing)
+                            "re-run on the launch path (engine off until the next generation probes the device again)",
+                            st["arrivals"], missing)
             self._recover(missing)
         elif done_total != issued_total:
             raise RuntimeError(f"decode steps issued {issued_total} != completed {done_total}")

@@ -20,8 +20,9 @@ SEED = 17  # chosen with `python tests/moe_depth_util.py`: the closest router ca
 P8X22B_3L = dict(dim=6144, n_layers=3, head_dim=128, hidden_dim=16384, n_heads=48, n_kv_heads=8, norm_eps=1e-5,
                  vocab_size=2048, rope_theta=1e6, moe=dict(num_experts=8, num_experts_per_tok=2))
 PROMPT_22B, STEPS_22B = 12, 3
-SEED_22B = 9  # no router near-tie on the build container (closest call 3.66 bf16 ulp); the GPU box's host arithmetic differs
-# in the last bit (1.84 ulp there): the test compares the rows in front of the first near-tie of ITS oracle run
+SEED_22B = 12  # of seeds 0-21 the one with the widest margin on a GPU box's host (closest router call 7.3 bf16 ulp there; host
+# arithmetic differs in the last bit between machines - seed 9: 3.66 ulp on the build container, 1.84 on the box): the test
+# additionally drops the rows behind any near-tie of ITS oracle run (clean_rows)
 
 
 def _lin(o, i, g):

@@ -205,7 +205,16 @@ def test_residency_gate_failure_writes_nothing_and_steps_are_rerun():
         assert st["status"] == 0 and int(c.kv_seqlens[0]) == kv_before + 7
         got = torch.cat([first[None], a_t, b_t])
         assert torch.equal(got, ref_t), (got[:, 0].tolist(), ref_t[:, 0].tolist())
-        assert _hip.set_decode_engine(True) is False      # the session switched the process to the launch path
+        assert _hip.set_decode_engine(False) is False     # the session switched the process to the launch path ...
+        # ... for the rest of THAT generation: the next session forgets the verdict and probes the device again
+        launches = _hip.decode_engine_status(m._backend._workspace)["engine_launches"]
+        c2, last2 = _prefill(m, prompts, 60)
+        sess2 = m.greedy_session(c2, torch.argmax(last2, dim=-1), graph=True)
+        sess2.run(5)
+        t2, _ = sess2.collect()
+        st = _hip.decode_engine_status(m._backend._workspace)
+        assert st["status"] == 0 and st["engine_launches"] >= launches + 5   # back on the persistent engine
+        assert torch.equal(t2[:, 0], ref_t[1:6, 0])
         # forward() callers: the flag is raised (and cleared) by raise_if_flagged
         _hip.debug_engine_sabotage(m._backend._workspace, 1)
         m.forward(first, [1], c)

@@ -39,6 +39,17 @@ def _big_cases():
 ALL = {**sampling_cases(), **_big_cases()}
 
 
+def _exact_distribution(row, t, p):
+    """top_p_distribution in float64 throughout: the cut where the EXACT mass-before exceeds p.  The reference's fp32 cumsum
+    (which the oracle follows) places the cut up to a few 1e-6 of mass away from it - one token more or less when thousands of
+    tokens share the nucleus; the kernel's 40-bit fixed-point masses sit on the exact side."""
+    probs = torch.softmax(row.double() / t, dim=-1)
+    ps, order = torch.sort(probs, descending=True, stable=True)
+    before = torch.cumsum(ps, 0) - ps
+    kept = ps.masked_fill(before > p, 0.0)
+    return order, kept / kept.sum()
+
+
 @pytest.mark.parametrize("name", sorted(ALL))
 def test_fixed_uniforms_match_the_inverse_cdf_of_the_reference_distribution(name):
     from mistral_inference import _hip
@@ -47,37 +58,38 @@ def test_fixed_uniforms_match_the_inverse_cdf_of_the_reference_distribution(name
     n_u = 768
     g = torch.Generator().manual_seed(7)
     u = torch.cat([torch.tensor([0.0, 1e-7, 0.5, 0.999999]), torch.rand(n_u - 4, generator=g)]).float()
-    order, kept = mo.top_p_distribution(row, t, p)
-    cdf = torch.cumsum(kept, 0)
-    n_kept = int((kept > 0).sum())
     logits = row[None, :].expand(n_u, V).contiguous().cuda()
     tok, lp = _hip.sample_top_p(logits, t, p, uniforms=u)
     tok, lp = tok.cpu(), lp.cpu()
-    # (a) always inside the kept set - except the first token BEHIND the cut when the cut's mass-before sits within
-    # rounding of p (the reference's fp32 cumsum vs the kernel's fixed point)
-    kept_ids = set(order[:n_kept].tolist())
-    probs = torch.softmax(row.double() / t, -1)
-    slack = set()
-    if n_kept < V:
-        before = float(probs[order[:n_kept]].sum())
-        if abs(before - p) < 1e-5:
-            slack.add(int(order[n_kept]))
-    assert all(int(x) in kept_ids or int(x) in slack for x in tok), name
-    # (b) the inverse-CDF token for every variate that is not within 1e-5 of a CDF step
-    pos = torch.searchsorted(cdf, u.double(), right=True).clamp(max=n_kept - 1)
-    near = (cdf[pos] - u.double()).abs() < 1e-5
-    near |= (pos > 0) & ((u.double() - cdf[(pos - 1).clamp(min=0)]).abs() < 1e-5)
-    want = order[pos]
-    clear = ~near
-    # (a nucleus of thousands of tokens has thousands of CDF steps: more variates fall within 1e-5 of one)
-    assert int(clear.sum()) >= 0.9 * n_u, (name, int(clear.sum()), n_kept)
-    if not slack:
-        # exact ties in probability: the kernel orders ties by ascending token id (the oracle's stable sort does too)
-        assert torch.equal(tok[clear], want[clear]), (name, int((tok[clear] != want[clear]).sum()))
+    # candidates for "the reference's distribution": the oracle's (fp32 softmax + fp32 cumsum, as the reference computes the
+    # cut) and the same in exact arithmetic; they differ by at most a token or two at the cut of a wide nucleus
+    cands = [mo.top_p_distribution(row, t, p), _exact_distribution(row, t, p)]
+    n_kept = [int((k > 0).sum()) for _, k in cands]
+    assert abs(n_kept[0] - n_kept[1]) <= max(2, n_kept[0] // 2000), (name, n_kept)
+    # (a) never outside the (larger of the) kept sets
+    order, kept = cands[0]
+    allowed = set(order[:max(n_kept) + 1].tolist())
+    assert all(int(x) in allowed for x in tok), name
+    # (b) the inverse-CDF token for every variate that is not within TOL of a CDF step, under one of the two cuts
+    best = None
+    for order, kept in cands:
+        nk = int((kept > 0).sum())
+        cdf = torch.cumsum(kept, 0)
+        pos = torch.searchsorted(cdf, u.double(), right=True).clamp(max=nk - 1)
+        step = kept[pos]
+        tol = torch.minimum(torch.full_like(step, 2e-6), 0.25 * step)
+        near = (cdf[pos] - u.double()).abs() < tol
+        near |= (pos > 0) & ((u.double() - cdf[(pos - 1).clamp(min=0)]).abs() < tol)
+        clear = ~near
+        miss = int((tok[clear] != order[pos][clear]).sum())
+        if best is None or miss < best[0]:
+            best = (miss, int(clear.sum()))
+    assert best[1] >= 0.9 * n_u, (name, best)
+    # exact ties in probability: the kernel orders ties by ascending token id (the oracle's stable sort does too)
+    assert best[0] == 0, (name, best, n_kept)
     # (c) logprob = log_softmax of the UNSCALED logits at the token (generate.py:134-136)
     ref_lp = torch.log_softmax(row.double(), -1)[tok]
-    fin = torch.isfinite(ref_lp)
-    assert fin.all() and float((lp.double() - ref_lp).abs().max()) < 2e-5, name
+    assert torch.isfinite(ref_lp).all() and float((lp.double() - ref_lp).abs().max()) < 2e-5, name
 
 
 def test_philox_stream_reproduces_the_distribution_and_is_deterministic():
