@@ -483,6 +483,7 @@ int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream) 
 
 int mi_decode_engine_census(int forget) {
   if (forget) decode_engine_forget_census_wide();
+  if (forget) decode_engine_forget_census_moe();
   if (forget) decode_engine_forget_census();
   return MI_OK;
 }
@@ -497,11 +498,13 @@ size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(devi
 int mi_debug_set_engine_knobs(int thin, int depth) {
   decode_engine_set_knobs(thin, depth);
   decode_engine_set_knobs_wide(thin, depth);
+  decode_engine_set_knobs_moe(thin, depth);
   return MI_OK;
 }
 int mi_debug_set_engine_holders(int on) {
   decode_engine_set_holders(on);
   decode_engine_set_holders_wide(on);
+  decode_engine_set_holders_moe(on);
   return MI_OK;
 }
 int mi_debug_set_engine_variant(int variant) {
@@ -512,6 +515,7 @@ int mi_debug_set_engine_variant(int variant) {
 int mi_debug_set_engine_trace(void* dev_buffer) {
   decode_engine_set_trace(dev_buffer);
   decode_engine_set_trace_wide(dev_buffer);
+  decode_engine_set_trace_moe(dev_buffer);
   return MI_OK;
 }
 
@@ -594,19 +598,22 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     // MoE models take the wide build wherever it applies: it carries the round-4 router (two experts per wave, batched loads:
     // -8..-11 us per layer), which the shipped object - frozen, see decode_engine.hip - does not.  Variant 2 = shipped build
     // first for every model (the A/B of that choice).
-    const bool wide_ok = dense_ok && decode_engine_applicable_wide(pr, nullptr, 0);
+    // (MoE: the 8-fill MoE build where the model fits it - Mixtral-8x7B -, else the 7-fill wide build - Mixtral-8x22B.)
+    const bool moe_ok = dense_ok && m->num_experts > 0 && engine_variant() == 0 && decode_engine_applicable_moe(pr, nullptr, 0);
+    const bool wide_ok = !moe_ok && dense_ok && decode_engine_applicable_wide(pr, nullptr, 0);
     const bool wide_first = engine_variant() == 1 || (engine_variant() == 0 && m->num_experts > 0);
-    const bool base_ok = dense_ok && !(wide_first && wide_ok) && decode_engine_applicable(pr, nullptr, 0);
-    if (base_ok || wide_ok) {
+    const bool base_ok = !moe_ok && dense_ok && !(wide_first && wide_ok) && decode_engine_applicable(pr, nullptr, 0);
+    if (moe_ok || base_ok || wide_ok) {
       bool declined = false;
-      MI_TRY(hip_rc(base_ok ? launch_decode_engine(pr, s, &declined) : launch_decode_engine_wide(pr, s, &declined), "decode engine"));
+      MI_TRY(hip_rc(moe_ok ? launch_decode_engine_moe(pr, s, &declined)
+                           : (base_ok ? launch_decode_engine(pr, s, &declined) : launch_decode_engine_wide(pr, s, &declined)), "decode engine"));
       if (!declined) {
         if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
         if (want_topp) MI_TRY(sample_step());
         return MI_OK;
       }
       snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s",
-               base_ok ? decode_engine_census_detail() : decode_engine_census_detail_wide());  // informational
+               moe_ok ? decode_engine_census_detail_moe() : (base_ok ? decode_engine_census_detail() : decode_engine_census_detail_wide()));  // informational
     }
   }
 

@@ -45,17 +45,25 @@
 #ifndef ENG_WIDE
 #define ENG_WIDE 0
 #endif
+// ENG_WIDE = 2: the same additions with the shipped 8-fill ring, MoE models only (decode_engine_moe.o): at dim 4096 the four
+// consumer waves' W1|W3 units span exactly 8 fills, and the 7-fill ring of ENG_WIDE = 1 costs Mixtral-8x7B 6 % of its W1|W3
+// streaming rate (25.6 vs 27.2 GB/s per CU, profiles/r04_engine_trace_8x7b_*) - as much as the batched router saves.
+#if ENG_WIDE == 1
+#define ENG_NAME(x) x##_wide
+#elif ENG_WIDE == 2
+#define ENG_NAME(x) x##_moe
+#endif
 #if ENG_WIDE
-#define launch_decode_engine launch_decode_engine_wide
-#define decode_engine_applicable decode_engine_applicable_wide
-#define decode_engine_granule_bytes decode_engine_granule_bytes_wide
-#define decode_engine_set_holders decode_engine_set_holders_wide
-#define decode_engine_set_knobs decode_engine_set_knobs_wide
-#define decode_engine_set_trace decode_engine_set_trace_wide
-#define decode_engine_trace_bytes decode_engine_trace_bytes_wide
-#define decode_engine_census_detail decode_engine_census_detail_wide
-#define decode_engine_forget_census decode_engine_forget_census_wide
-#define engine_census_kernel engine_census_kernel_wide
+#define launch_decode_engine ENG_NAME(launch_decode_engine)
+#define decode_engine_applicable ENG_NAME(decode_engine_applicable)
+#define decode_engine_granule_bytes ENG_NAME(decode_engine_granule_bytes)
+#define decode_engine_set_holders ENG_NAME(decode_engine_set_holders)
+#define decode_engine_set_knobs ENG_NAME(decode_engine_set_knobs)
+#define decode_engine_set_trace ENG_NAME(decode_engine_set_trace)
+#define decode_engine_trace_bytes ENG_NAME(decode_engine_trace_bytes)
+#define decode_engine_census_detail ENG_NAME(decode_engine_census_detail)
+#define decode_engine_forget_census ENG_NAME(decode_engine_forget_census)
+#define engine_census_kernel ENG_NAME(engine_census_kernel)
 #endif
 
 namespace {
@@ -96,7 +104,7 @@ constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
 constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
 constexpr int FILL = 16;             // pieces per fill
-#if ENG_WIDE
+#if ENG_WIDE == 1
 constexpr int RING_FILLS = 7;        // 112 KiB ring: 47 KiB left for the activation region (a 32 KiB hid vector fits)
 #define RING_IDX(sh, x) ((uint32_t)(x) % (uint32_t)(RING_FILLS * FILL))  // not a power of two: a constant modulo (scalar ALU)
 #else
@@ -1177,52 +1185,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       sh.ctl[C_GATHERING] = 0;
       trace_ev(sh, c, l, 5, trc);
       const int gl = lane >> 4, dl = lane & 15;
-#if ENG_WIDE
-      // GQA ratio 6 (Mixtral-8x22B): six heads' q rows and running sums in one pass need ~140 live registers on top of the
-      // kernel's standing state and the instantiation spills 45 of them - the attention pieces of a layer took 9.1 us
-      // against 3.7 us at ratio 4 (profiles/r04_engine_trace_8x22b_stage7_wide.txt).  While the pieces all sit in the ring
-      // (not `streamed`) the heads are served in two passes of three over the same ring slots: heads do not interact in
-      // reduce_slot, so the partials are the same bits.
-      if constexpr (R == 6) {
-        {  // (never `streamed`: decode_engine_applicable declines rings whose split does not fit the LDS ring at this ratio)
-          if (p.n_att) cs.need_fill(g + 2 * p.n_att - 1);
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            constexpr int RP = 3;
-            const int r_off = pass * RP;
-            float qh[RP][8];
-            {
-              u32x4 qraw[RP];
-#pragma unroll
-              for (int r = 0; r < RP; ++r) qraw[r] = lds16(q_lds + (r_off + r) * 64 + dl * 4);
-              load_q<RP>(qh, qraw);
-            }
-            State<RP> sp;
-            init_state<RP>(sp);
-            for (int j = w; j < p.n_att; j += NCONS) {
-              const uint32_t gk = g + 2 * j;
-              u32x4 kraw = lds16(sh.ring + RING_IDX(sh, gk) * PIECE + lane * 16);
-              u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gk + 1) * PIECE + lane * 16);
-              const int slot = p.s_begin + 4 * j + gl;
-              if (slot == p.cur_slot) {
-                kraw = lds16(kn_lds + dl * 4);
-                vraw = lds16(vn_lds + dl * 4);
-              }
-              const bool valid = slot < p.s_end;
-              if (!valid) {
-                kraw = u32x4{0u, 0u, 0u, 0u};
-                vraw = u32x4{0u, 0u, 0u, 0u};
-              }
-              reduce_slot<RP>(sp, qh, kraw, vraw, valid);
-            }
-            wave_state_to_lds_heads<RP, R>(sp, w, lane, r_off, sm_m, sm_l, sm_acc);
-          }
-          g += 2 * p.n_att;
-          cs.set_done(g);
-          trace_ev(sh, c, l, 6, trc);
-        }
-      } else {
-#endif
       float qf[R][8];
       {
         u32x4 qraw[R];
@@ -1261,9 +1223,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       cs.set_done(g);
       trace_ev(sh, c, l, 6, trc);
       wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
-#if ENG_WIDE
-      }
-#endif
       cs.cbar();
       const uint32_t tp = tag_of(l, 2);
       const size_t bh = p.kvh;  // batch 1
@@ -1720,6 +1679,9 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   if (((pr.D >> 9) & 1) && pr.D > 3072) return no("odd number of 512-element pieces per row at a large dim");
 #endif
   if (pr.V % 2) return no("odd vocab");
+#if ENG_WIDE == 2
+  if (!pr.E) return no("the 8-fill MoE build takes MoE models only");
+#endif
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
   const size_t region = (size_t)LDS_TOTAL - RING_FILLS * FILL * PIECE - XS_OFF;  // activation vector / attention scratch
   if ((size_t)kmax * 2 > region) return no("activation vector does not fit beside the 8-fill ring");
@@ -1736,7 +1698,9 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   if (pr.Hkv <= 0 || pr.H % pr.Hkv) return no("heads");
   const int Rtot = pr.H / pr.Hkv;
   const int R = attn_decode_group(Rtot);
-#if ENG_WIDE
+#if ENG_WIDE == 2
+  if (R != 4) return no("GQA group size (the 8-fill MoE build instantiates 4)");
+#elif ENG_WIDE
   if (R != 4 && R != 6) return no("GQA group size (the wide build instantiates 4 and 6)");
 #else
   if (R != 1 && R != 2 && R != 4 && R != 8) return no("GQA group size");
@@ -1753,10 +1717,6 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   for (int l = 0; l < pr.n_layers; ++l) {
     const int ns = attn_decode_splits(pr.W[l]);
     if (ns > 32 || Hs * ns > NB) return no("more attention work items than CUs");
-#if ENG_WIDE
-    // ratio 6 serves its heads in two passes over K/V pieces that must all sit in the LDS ring (run_consumer)
-    if (R == 6 && 2 * ((attn_core::split_chunk(pr.W[l], ns) + 3) >> 2) > (RING_FILLS - 2) * FILL) return no("GQA ratio 6: ring longer than 5120 slots");
-#endif
   }
   return true;
 }
@@ -1907,7 +1867,9 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   (moe ? (all4 ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
        : (all4 ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
     switch (a.R) {
-#if ENG_WIDE
+#if ENG_WIDE == 2
+      case 4: fn = !moe ? nullptr : (all4 ? (const void*)decode_engine_kernel<4, true, true> : (const void*)decode_engine_kernel<4, true, false>); break;
+#elif ENG_WIDE
       case 4: fn = ENG_PICK(4); break;
       case 6: fn = ENG_PICK(6); break;
 #else
@@ -1919,6 +1881,7 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
       default: return hipErrorInvalidValue;
     }
 #undef ENG_PICK
+    if (!fn) return hipErrorInvalidValue;
     // 160 KiB of dynamic LDS is an opt-in per function AND per device
     static bool attr_set[64][36] = {};
     const int slot = a.R + (moe ? 9 : 0) + (all4 ? 18 : 0);

@@ -285,3 +285,12 @@ void decode_engine_forget_census_wide();
 void decode_engine_set_trace_wide(void* dev_buffer);
 void decode_engine_set_knobs_wide(int thin, int depth);
 void decode_engine_set_holders_wide(int on);
+// ... and a third time with -DENG_WIDE=2 (decode_engine_moe.o): the wide build's additions on the shipped 8-fill ring, for MoE
+// models whose hid vector fits beside it (Mixtral-8x7B: the four consumers' W1|W3 units span exactly 8 fills at dim 4096).
+bool decode_engine_applicable_moe(const EngProblem& pr, char* why, size_t why_len);
+hipError_t launch_decode_engine_moe(const EngProblem& pr, hipStream_t s, bool* declined);
+const char* decode_engine_census_detail_moe();
+void decode_engine_forget_census_moe();
+void decode_engine_set_trace_moe(void* dev_buffer);
+void decode_engine_set_knobs_moe(int thin, int depth);
+void decode_engine_set_holders_moe(int on);
