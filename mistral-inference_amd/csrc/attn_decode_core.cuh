@@ -150,6 +150,27 @@ __device__ __forceinline__ void wave_state_to_lds(State<R>& st, int vw, int lane
   }
 }
 
+// The same for RP of the RT query heads of a kv head (heads r_off .. r_off + RP): a block that serves its heads in several
+// passes over the same K/V slots (fewer live registers per pass) leaves the LDS image of the one-pass form.  Heads do not
+// interact in reduce_slot (a head that keeps its reference maximum is multiplied by exactly 1), so the results are the same bits.
+template <int RP, int RT, class FP>
+__device__ __forceinline__ void wave_state_to_lds_heads(State<RP>& st, int vw, int lane, int r_off, FP sm_m, FP sm_l, FP sm_acc) {
+  merge_from<RP, 16>(st, lane);
+  merge_from<RP, 32>(st, lane);
+  const int g = lane >> 4, dl = lane & 15;
+  if (g == 0) {
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+      if (dl == 0) {
+        sm_m[vw * RT + r_off + r] = st.m[r];
+        sm_l[vw * RT + r_off + r] = st.l[r];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sm_acc[(vw * RT + r_off + r) * DH + dl * 8 + i] = st.acc[r][i];
+    }
+  }
+}
+
 // 4 virtual waves -> the split's partial for flat index idx = r * DH + d.
 template <int R, class FP>
 __device__ __forceinline__ void split_partial(int idx, FP sm_m, FP sm_l, FP sm_acc, float& A, float& M, float& L) {

@@ -837,9 +837,84 @@ struct Cons {
 //   W2       expert A rows with hid A (gathered long after its last producer finished: the sweep is one pass), then
 //            expert B rows with hid B; r = bf16(bf16(0 + bf16(wA yA)) + bf16(wB yB)); h = bf16(h1 + r)  (moe.py:28-32 +
 //            transformer_layers.py:168, the order of the launch path's moe_w2_kernel)
+#if ENG_WIDE
+// MoE router on the HOLDER waves.  In a MoE layer the three holder waves have nothing to hold (their W1|W3 units would depend on
+// the router), and the router's inputs apart from h1 - the gate rows, the ffn norm weights - are static: holder hi keeps the gate
+// rows of experts hi, hi + 3, hi + 6 and the norm weights in its registers, fetched a whole layer ahead, and turns the raw h1
+// vector into their logits the moment the consumers have put it into LDS.  The consumers (whose registers have no room for a
+// prefetch - it spills) wait for three counter ticks instead of running 2-3 L2 round trips in front of the expert decision the
+// loader is waiting for.  Same arithmetic per expert as the consumer form below (sum of squares and the fmaf chain over the
+// lane's pieces in ascending order, wave sum, bf16 rounding): bit-identical.
+constexpr int RH_E = 3, RH_P = 12;  // experts per holder, 512-element pieces per lane (dim <= 6144)
+__device__ __forceinline__ bool router_on_holders(const EngArgs& a) {
+  return NHOLD == 3 && a.holders && a.E > 0 && a.E <= NHOLD * RH_E && (a.D >> 9) <= RH_P;
+}
+template <bool DUMMY = true>
+__device__ __forceinline__ void run_router_holder(const EngArgs& a, const Shared& sh, int hi, int lane) {
+  if (!router_on_holders(a)) return;
+  const int npl = a.D >> 9;  // pieces per lane
+  const lbf16* raw = reinterpret_cast<const lbf16*>(sh.xs) + a.D;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const EngLayer& L = a.L[l];
+    u32x4 gw[RH_E][RH_P], nv[RH_P];
+#pragma unroll
+    for (int k = 0; k < RH_P; ++k) {
+      const int pp = lane + 64 * min(k, npl - 1);
+      nv[k] = ld16(L.fn + pp * 8);
+#pragma unroll
+      for (int j = 0; j < RH_E; ++j) gw[j][k] = ld16(L.w1 + (size_t)min(hi + NHOLD * j, a.E - 1) * a.D + pp * 8);
+    }
+    uint32_t spins = 0;
+    while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
+      if (!spin_ok(sh, spins, 0x600)) return;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < RH_P; ++k)
+      if (k < npl) {
+        const u32x4 v = lds16(raw + (lane + 64 * k) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = bf_lo(v[i]), x1 = bf_hi(v[i]);
+          ss = fmaf(x0, x0, ss);
+          ss = fmaf(x1, x1, ss);
+        }
+      }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
+    float acc[RH_E] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < RH_P; ++k)
+      if (k < npl) {
+        const u32x4 v = lds16(raw + (lane + 64 * k) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = bf_round(bf_round(bf_lo(v[i]) * inv) * bf_lo(nv[k][i]));
+          const float x1 = bf_round(bf_round(bf_hi(v[i]) * inv) * bf_hi(nv[k][i]));
+#pragma unroll
+          for (int j = 0; j < RH_E; ++j) {
+            acc[j] = fmaf(bf_lo(gw[j][k][i]), x0, acc[j]);
+            acc[j] = fmaf(bf_hi(gw[j][k][i]), x1, acc[j]);
+          }
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < RH_E; ++j) {
+      const float t = wave_sum(acc[j]);
+      const int e = hi + NHOLD * j;
+      if (lane == 0 && e < a.E) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[e] = bf_round(t);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+#endif
+
 template <bool ALL4>
 __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons& cs, const EngLayer& L, const LayerPlan& p, int l,
                                         int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
+#if ENG_WIDE
+                                        uint32_t& hold_target,
+#endif
                                         const u32x4 (&xr)[4], bool trc) {
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -858,13 +933,20 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
   cs.cbar();
   // ---- router (moe_router_kernel: one wave per expert there, experts w, w + 4, ... per wave here)
 #if ENG_WIDE
-  // Round 4 (timeline of an 8x7B / 8x22B stage, profiles/r04_engine_trace_*): the form below - gate row and norm weights
+  // Round 4 (timeline of an 8x7B / 8x22B stage, profiles/r04_engine_trace_*): the shipped form - gate row and norm weights
   // fetched INSIDE the per-piece loop, one expert after the other - took 11-15 us per layer, a chain of 16-24 dependent L2
   // round trips during which the loader has nothing to stream (it waits for this decision).  Here a wave handles its two
   // experts together, four pieces per batch: gate rows of both experts and the norm weights of a batch are in flight at once
   // (2-3 round trips in all), the normalised activations are computed once for both experts.  Per expert the fmaf chain runs
   // over the same elements in the same order - bit-identical.
-  {
+  if (router_on_holders(a)) {
+    // the holder waves compute the logits (run_router_holder): tell them that raw h1 stands in LDS, wait for their three ticks
+    if (w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (behind the barrier above: every wave's part of raw is written)
+    hold_target += (uint32_t)NHOLD;
+    uint32_t spins = 0;
+    while (sh.ctl[C_HDONE] < hold_target)
+      if (!spin_ok(sh, spins, 0x500)) break;
+  } else {
     const bf16_t* gate = L.w1;
     float ss = 0.f;
     for (int pp = lane; pp < np; pp += 64) {
@@ -879,6 +961,23 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
     ss = wave_sum(ss);
     const float inv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
     constexpr int CH = 4;
+    auto fold = [&](int p0, const u32x4 (&va)[CH], const u32x4 (&vb)[CH], const u32x4 (&wn)[CH], const u32x4 (&xv)[CH], float& acc_a,
+                    float& acc_b) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if (p0 + 64 * i < np) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float x0 = bf_round(bf_round(bf_lo(xv[i][cc]) * inv) * bf_lo(wn[i][cc]));
+            const float x1 = bf_round(bf_round(bf_hi(xv[i][cc]) * inv) * bf_hi(wn[i][cc]));
+            acc_a = fmaf(bf_lo(va[i][cc]), x0, acc_a);
+            acc_a = fmaf(bf_hi(va[i][cc]), x1, acc_a);
+            acc_b = fmaf(bf_lo(vb[i][cc]), x0, acc_b);
+            acc_b = fmaf(bf_hi(vb[i][cc]), x1, acc_b);
+          }
+        }
+      }
+    };
     for (int ea = w; ea < a.E; ea += 2 * NCONS) {
       const int eb = ea + NCONS;
       const bool two = eb < a.E;
@@ -895,20 +994,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
           wn[i] = ld16(L.fn + pp * 8);
           xv[i] = lds16(raw + pp * 8);
         }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          if (p0 + 64 * i < np) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-              const float x0 = bf_round(bf_round(bf_lo(xv[i][cc]) * inv) * bf_lo(wn[i][cc]));
-              const float x1 = bf_round(bf_round(bf_hi(xv[i][cc]) * inv) * bf_hi(wn[i][cc]));
-              acc_a = fmaf(bf_lo(va[i][cc]), x0, acc_a);
-              acc_a = fmaf(bf_hi(va[i][cc]), x1, acc_a);
-              acc_b = fmaf(bf_lo(vb[i][cc]), x0, acc_b);
-              acc_b = fmaf(bf_hi(vb[i][cc]), x1, acc_b);
-            }
-          }
-        }
+        fold(p0, va, vb, wn, xv, acc_a, acc_b);
       }
       acc_a = wave_sum(acc_a);
       acc_b = wave_sum(acc_b);
@@ -917,6 +1003,7 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
         if (two) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[eb] = bf_round(acc_b);
       }
     }
+    cs.cbar();
   }
 #else
   {
@@ -952,19 +1039,36 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
       if (lane == 0) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[e] = bf_round(acc);
     }
   }
-#endif
   cs.cbar();
+#endif
   int eA, eB;
   float wA, wB;
   {
+#if ENG_WIDE
+    // (the 16 logits in four 16-byte LDS reads instead of 2 x E dependent volatile reads)
+    float lg[16];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const u32x4 t = *reinterpret_cast<const LDS_AS volatile u32x4*>(sh.ctl + C_RLOGIT + 4 * q4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lg[4 * q4 + i] = __uint_as_float(t[i]);
+    }
+#else
     const lvf32* lg = reinterpret_cast<const lvf32*>(sh.ctl + C_RLOGIT);
+#endif
     int ti[2];
     float tw[2];
     unsigned taken = 0;
     for (int k = 0; k < 2; ++k) {
       int best = -1;
       float bv = -INFINITY;
+#if ENG_WIDE
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j >= a.E) break;
+#else
       for (int j = 0; j < a.E; ++j) {
+#endif
         const float v = lg[j];
         if (!((taken >> j) & 1u) && (best < 0 || v > bv)) {  // ties: lowest expert id
           best = j;
@@ -1185,6 +1289,53 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       sh.ctl[C_GATHERING] = 0;
       trace_ev(sh, c, l, 5, trc);
       const int gl = lane >> 4, dl = lane & 15;
+#if ENG_WIDE
+      // GQA ratio 6 (Mixtral-8x22B): six heads' q rows and running sums in one pass need ~140 live registers on top of the
+      // kernel's standing state and the instantiation spills 45 of them - not only here: a 7-layer 8x22B stage ran 2.00 ms
+      // per step with the spilling one-pass form against 1.88 ms with this one (and 1.94-1.97 ms on the launch path; same
+      // boxes, profiles/EXPERIMENTS.md round 4), although the attention pieces themselves take the same ~10 us either way.
+      // The heads are served in two passes of three over the same ring slots: heads do not interact in reduce_slot, so the
+      // partials are the same bits.
+      if constexpr (R == 6) {
+        {  // (never `streamed`: decode_engine_applicable declines rings whose split does not fit the LDS ring at this ratio)
+          if (p.n_att) cs.need_fill(g + 2 * p.n_att - 1);
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            constexpr int RP = 3;
+            const int r_off = pass * RP;
+            float qh[RP][8];
+            {
+              u32x4 qraw[RP];
+#pragma unroll
+              for (int r = 0; r < RP; ++r) qraw[r] = lds16(q_lds + (r_off + r) * 64 + dl * 4);
+              load_q<RP>(qh, qraw);
+            }
+            State<RP> sp;
+            init_state<RP>(sp);
+            for (int j = w; j < p.n_att; j += NCONS) {
+              const uint32_t gk = g + 2 * j;
+              u32x4 kraw = lds16(sh.ring + RING_IDX(sh, gk) * PIECE + lane * 16);
+              u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gk + 1) * PIECE + lane * 16);
+              const int slot = p.s_begin + 4 * j + gl;
+              if (slot == p.cur_slot) {
+                kraw = lds16(kn_lds + dl * 4);
+                vraw = lds16(vn_lds + dl * 4);
+              }
+              const bool valid = slot < p.s_end;
+              if (!valid) {
+                kraw = u32x4{0u, 0u, 0u, 0u};
+                vraw = u32x4{0u, 0u, 0u, 0u};
+              }
+              reduce_slot<RP>(sp, qh, kraw, vraw, valid);
+            }
+            wave_state_to_lds_heads<RP, R>(sp, w, lane, r_off, sm_m, sm_l, sm_acc);
+          }
+          g += 2 * p.n_att;
+          cs.set_done(g);
+          trace_ev(sh, c, l, 6, trc);
+        }
+      } else {
+#endif
       float qf[R][8];
       {
         u32x4 qraw[R];
@@ -1223,6 +1374,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       cs.set_done(g);
       trace_ev(sh, c, l, 6, trc);
       wave_state_to_lds<R>(st, w, lane, sm_m, sm_l, sm_acc);
+#if ENG_WIDE
+      }
+#endif
       cs.cbar();
       const uint32_t tp = tag_of(l, 2);
       const size_t bh = p.kvh;  // batch 1
@@ -1372,7 +1526,11 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         cs.set_done(g);
       }
     } else {
+#if ENG_WIDE
+      moe_ffn<ALL4>(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), hold_target, xr, trc);
+#else
       moe_ffn<ALL4>(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
+#endif
     }
     trace_ev(sh, c, l, 16, trc);
     cs.cbar();
@@ -1607,7 +1765,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int seq = 0;
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
   if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
+#if ENG_WIDE
+  else if (w > NCONS) {
+    if constexpr (MOE) run_router_holder(a, sh, w - NCONS - 1, lane);
+    else run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
+  }
+#else
   else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
+#endif
   else {
     // residency census: every workgroup counts itself in; consumers check the total before their first side effect
     uint32_t arrive_target = 0;
@@ -1717,6 +1882,10 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   for (int l = 0; l < pr.n_layers; ++l) {
     const int ns = attn_decode_splits(pr.W[l]);
     if (ns > 32 || Hs * ns > NB) return no("more attention work items than CUs");
+#if ENG_WIDE
+    // ratio 6 serves its heads in two passes over K/V pieces that must all sit in the LDS ring (run_consumer)
+    if (R == 6 && 2 * ((attn_core::split_chunk(pr.W[l], ns) + 3) >> 2) > (RING_FILLS - 2) * FILL) return no("GQA ratio 6: ring longer than 5120 slots");
+#endif
   }
   return true;
 }
