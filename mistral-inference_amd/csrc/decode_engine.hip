@@ -837,84 +837,9 @@ struct Cons {
 //   W2       expert A rows with hid A (gathered long after its last producer finished: the sweep is one pass), then
 //            expert B rows with hid B; r = bf16(bf16(0 + bf16(wA yA)) + bf16(wB yB)); h = bf16(h1 + r)  (moe.py:28-32 +
 //            transformer_layers.py:168, the order of the launch path's moe_w2_kernel)
-#if ENG_WIDE
-// MoE router on the HOLDER waves.  In a MoE layer the three holder waves have nothing to hold (their W1|W3 units would depend on
-// the router), and the router's inputs apart from h1 - the gate rows, the ffn norm weights - are static: holder hi keeps the gate
-// rows of experts hi, hi + 3, hi + 6 and the norm weights in its registers, fetched a whole layer ahead, and turns the raw h1
-// vector into their logits the moment the consumers have put it into LDS.  The consumers (whose registers have no room for a
-// prefetch - it spills) wait for three counter ticks instead of running 2-3 L2 round trips in front of the expert decision the
-// loader is waiting for.  Same arithmetic per expert as the consumer form below (sum of squares and the fmaf chain over the
-// lane's pieces in ascending order, wave sum, bf16 rounding): bit-identical.
-constexpr int RH_E = 3, RH_P = 12;  // experts per holder, 512-element pieces per lane (dim <= 6144)
-__device__ __forceinline__ bool router_on_holders(const EngArgs& a) {
-  return NHOLD == 3 && a.holders && a.E > 0 && a.E <= NHOLD * RH_E && (a.D >> 9) <= RH_P;
-}
-template <bool DUMMY = true>
-__device__ __forceinline__ void run_router_holder(const EngArgs& a, const Shared& sh, int hi, int lane) {
-  if (!router_on_holders(a)) return;
-  const int npl = a.D >> 9;  // pieces per lane
-  const lbf16* raw = reinterpret_cast<const lbf16*>(sh.xs) + a.D;
-  for (int l = 0; l < a.n_layers; ++l) {
-    const EngLayer& L = a.L[l];
-    u32x4 gw[RH_E][RH_P], nv[RH_P];
-#pragma unroll
-    for (int k = 0; k < RH_P; ++k) {
-      const int pp = lane + 64 * min(k, npl - 1);
-      nv[k] = ld16(L.fn + pp * 8);
-#pragma unroll
-      for (int j = 0; j < RH_E; ++j) gw[j][k] = ld16(L.w1 + (size_t)min(hi + NHOLD * j, a.E - 1) * a.D + pp * 8);
-    }
-    uint32_t spins = 0;
-    while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
-      if (!spin_ok(sh, spins, 0x600)) return;
-    float ss = 0.f;
-#pragma unroll
-    for (int k = 0; k < RH_P; ++k)
-      if (k < npl) {
-        const u32x4 v = lds16(raw + (lane + 64 * k) * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float x0 = bf_lo(v[i]), x1 = bf_hi(v[i]);
-          ss = fmaf(x0, x0, ss);
-          ss = fmaf(x1, x1, ss);
-        }
-      }
-    ss = wave_sum(ss);
-    const float inv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
-    float acc[RH_E] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < RH_P; ++k)
-      if (k < npl) {
-        const u32x4 v = lds16(raw + (lane + 64 * k) * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float x0 = bf_round(bf_round(bf_lo(v[i]) * inv) * bf_lo(nv[k][i]));
-          const float x1 = bf_round(bf_round(bf_hi(v[i]) * inv) * bf_hi(nv[k][i]));
-#pragma unroll
-          for (int j = 0; j < RH_E; ++j) {
-            acc[j] = fmaf(bf_lo(gw[j][k][i]), x0, acc[j]);
-            acc[j] = fmaf(bf_hi(gw[j][k][i]), x1, acc[j]);
-          }
-        }
-      }
-#pragma unroll
-    for (int j = 0; j < RH_E; ++j) {
-      const float t = wave_sum(acc[j]);
-      const int e = hi + NHOLD * j;
-      if (lane == 0 && e < a.E) reinterpret_cast<lvf32*>(sh.ctl + C_RLOGIT)[e] = bf_round(t);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-#endif
-
 template <bool ALL4>
 __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons& cs, const EngLayer& L, const LayerPlan& p, int l,
                                         int c, int w, int lane, uint32_t& g, uint32_t tag_hid, uint32_t tag_h,
-#if ENG_WIDE
-                                        uint32_t& hold_target,
-#endif
                                         const u32x4 (&xr)[4], bool trc) {
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
@@ -933,21 +858,24 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
   cs.cbar();
   // ---- router (moe_router_kernel: one wave per expert there, experts w, w + 4, ... per wave here)
 #if ENG_WIDE
-  // Round 4 (timeline of an 8x7B / 8x22B stage, profiles/r04_engine_trace_*): the shipped form - gate row and norm weights
-  // fetched INSIDE the per-piece loop, one expert after the other - took 11-15 us per layer, a chain of 16-24 dependent L2
-  // round trips during which the loader has nothing to stream (it waits for this decision).  Here a wave handles its two
-  // experts together, four pieces per batch: gate rows of both experts and the norm weights of a batch are in flight at once
-  // (2-3 round trips in all), the normalised activations are computed once for both experts.  Per expert the fmaf chain runs
-  // over the same elements in the same order - bit-identical.
-  if (router_on_holders(a)) {
-    // the holder waves compute the logits (run_router_holder): tell them that raw h1 stands in LDS, wait for their three ticks
-    if (w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (behind the barrier above: every wave's part of raw is written)
-    hold_target += (uint32_t)NHOLD;
-    uint32_t spins = 0;
-    while (sh.ctl[C_HDONE] < hold_target)
-      if (!spin_ok(sh, spins, 0x500)) break;
-  } else {
+  // Round 4 (timelines of an 8x7B / 8x22B stage, profiles/r04_engine_trace_*).  The shipped form below took 11-15 us per layer
+  // - time in which the loader has nothing to stream (it waits for this decision): (1) the gate row and the norm weights
+  // were fetched INSIDE the per-piece loop, one expert after the other: 16-24 dependent L2 round trips; (2) every wave
+  // normalised the WHOLE vector again for every one of its experts (two bf16 roundings per element, ~3 us of VALU).
+  // Here: every wave computes the sum of squares (the launch path's per-wave order), normalises ITS QUARTER of the vector
+  // once into LDS - the same numbers the shipped form recomputes - and after one barrier runs its two experts' dot
+  // products together over four pieces per batch, the first batch of gate rows requested before that barrier.  Per
+  // expert the fmaf chain runs over the same values in the same order: bit-identical.  (Two more forms were measured and
+  // dropped: prefetching the gate rows before the h1 sweep spills the consumers' registers; the whole router on the idle
+  // holder waves is compute-bound there - three experts per wave - and came out slower: profiles/EXPERIMENTS.md.)
+  {
     const bf16_t* gate = L.w1;
+    lbf16* xn = raw + a.D;  // router-normalised activations (bf16), behind the raw copy
+    constexpr int CH = 4;
+    const int ea0 = w, eb0 = (w + NCONS < a.E) ? w + NCONS : w;
+    u32x4 wnq[4];  // norm weights of this wave's quarter of the pieces (dim <= 8192: at most 4 per lane)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wnq[i] = ld16(L.fn + (size_t)min(w * 64 + lane + NCONS * 64 * i, np - 1) * 8);
     float ss = 0.f;
     for (int pp = lane; pp < np; pp += 64) {
       const u32x4 v = lds16(raw + pp * 8);
@@ -960,41 +888,62 @@ __device__ __forceinline__ void moe_ffn(const EngArgs& a, const Shared& sh, Cons
     }
     ss = wave_sum(ss);
     const float inv = 1.0f / sqrtf(ss / (float)a.D + a.eps);
-    constexpr int CH = 4;
-    auto fold = [&](int p0, const u32x4 (&va)[CH], const u32x4 (&vb)[CH], const u32x4 (&wn)[CH], const u32x4 (&xv)[CH], float& acc_a,
-                    float& acc_b) {
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        if (p0 + 64 * i < np) {
+    for (int i = 0; i < 4; ++i) {  // this wave's quarter of the pieces
+      const int pp = w * 64 + lane + NCONS * 64 * i;
+      if (pp < np) {
+        const u32x4 v = lds16(raw + pp * 8);
+        u32x4 o;
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const float x0 = bf_round(bf_round(bf_lo(xv[i][cc]) * inv) * bf_lo(wn[i][cc]));
-            const float x1 = bf_round(bf_round(bf_hi(xv[i][cc]) * inv) * bf_hi(wn[i][cc]));
-            acc_a = fmaf(bf_lo(va[i][cc]), x0, acc_a);
-            acc_a = fmaf(bf_hi(va[i][cc]), x1, acc_a);
-            acc_b = fmaf(bf_lo(vb[i][cc]), x0, acc_b);
-            acc_b = fmaf(bf_hi(vb[i][cc]), x1, acc_b);
-          }
-        }
+        for (int cc = 0; cc < 4; ++cc)
+          o[cc] = pack_bf2(bf_round(bf_lo(v[cc]) * inv) * bf_lo(wnq[i][cc]), bf_round(bf_hi(v[cc]) * inv) * bf_hi(wnq[i][cc]));
+        lds_st16(xn + pp * 8, o);
       }
-    };
+    }
+    u32x4 va0[CH], vb0[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {  // first batch of this wave's first two experts: in flight across the barrier
+      const int pp = min(lane + 64 * i, np - 1);
+      va0[i] = ld16(gate + (size_t)ea0 * a.D + pp * 8);
+      vb0[i] = ld16(gate + (size_t)eb0 * a.D + pp * 8);
+    }
+    cs.cbar();
     for (int ea = w; ea < a.E; ea += 2 * NCONS) {
       const int eb = ea + NCONS;
       const bool two = eb < a.E;
       const bf16_t* ga = gate + (size_t)ea * a.D;
       const bf16_t* gb = gate + (size_t)(two ? eb : ea) * a.D;
       float acc_a = 0.f, acc_b = 0.f;
-      for (int p0 = lane; p0 < np; p0 += 64 * CH) {
-        u32x4 va[CH], vb[CH], wn[CH], xv[CH];
+      auto fold = [&](int p0, const u32x4 (&va)[CH], const u32x4 (&vb)[CH]) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-          const int pp = min(p0 + 64 * i, np - 1);  // (np is a multiple of 64: a batch is inside the vector or outside it for the whole wave)
+          if (p0 + 64 * i < np) {  // (np is a multiple of 64: a batch is inside the vector or outside it for the whole wave)
+            const u32x4 xv = lds16(xn + (p0 + 64 * i) * 8);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float x0 = bf_lo(xv[cc]), x1 = bf_hi(xv[cc]);
+              acc_a = fmaf(bf_lo(va[i][cc]), x0, acc_a);
+              acc_a = fmaf(bf_hi(va[i][cc]), x1, acc_a);
+              acc_b = fmaf(bf_lo(vb[i][cc]), x0, acc_b);
+              acc_b = fmaf(bf_hi(vb[i][cc]), x1, acc_b);
+            }
+          }
+        }
+      };
+      int p0 = lane;
+      if (ea == w) {  // the batch that has been in flight since before the barrier
+        fold(p0, va0, vb0);
+        p0 += 64 * CH;
+      }
+      for (; p0 < np; p0 += 64 * CH) {
+        u32x4 va[CH], vb[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int pp = min(p0 + 64 * i, np - 1);
           va[i] = ld16(ga + pp * 8);
           vb[i] = ld16(gb + pp * 8);
-          wn[i] = ld16(L.fn + pp * 8);
-          xv[i] = lds16(raw + pp * 8);
         }
-        fold(p0, va, vb, wn, xv, acc_a, acc_b);
+        fold(p0, va, vb);
       }
       acc_a = wave_sum(acc_a);
       acc_b = wave_sum(acc_b);
@@ -1526,11 +1475,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         cs.set_done(g);
       }
     } else {
-#if ENG_WIDE
-      moe_ffn<ALL4>(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), hold_target, xr, trc);
-#else
       moe_ffn<ALL4>(a, sh, cs, L, p, l, c, w, lane, g, tag_of(l, 5), tag_of(l, 0), xr, trc);
-#endif
     }
     trace_ev(sh, c, l, 16, trc);
     cs.cbar();
@@ -1765,14 +1710,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int seq = 0;
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
   if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
-#if ENG_WIDE
-  else if (w > NCONS) {
-    if constexpr (MOE) run_router_holder(a, sh, w - NCONS - 1, lane);
-    else run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
-  }
-#else
   else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
-#endif
   else {
     // residency census: every workgroup counts itself in; consumers check the total before their first side effect
     uint32_t arrive_target = 0;
@@ -1852,7 +1790,11 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   if ((size_t)kmax * 2 > region) return no("activation vector does not fit beside the 8-fill ring");
   if (pr.E) {
     if (pr.E > 16 || pr.top_k != 2) return no("MoE: at most 16 experts, top-2 routing");
+#if ENG_WIDE
+    if ((size_t)pr.D * 6 > region) return no("MoE: normalised + raw + router-normalised activation vector");
+#else
     if ((size_t)pr.D * 4 > region) return no("MoE: normalised + raw activation vector");
+#endif
     if ((size_t)pr.F * 2 + (size_t)((pr.D / 2 + pr.NB - 1) / pr.NB) * 8 > region) return no("MoE: hid vector + per-unit partial sums");
   }
   if ((size_t)pr.D * 2 + (size_t)((pr.V / 2 + pr.NB - 1) / pr.NB) * 8 + 16 + (size_t)pr.NB * 16 > region)
