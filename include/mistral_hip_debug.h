@@ -38,6 +38,11 @@ int mi_debug_set_engine_variant(int variant);
  * workspace) wait for one workgroup more than exist, i.e. fail their residency gate after its ~50 ms bound exactly as a
  * launch with a missing workgroup would (status 0x700, nothing written).  Synchronises the stream. */
 int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream);
+/* Same-process A/B of the prefill kernels' alternative forms (negative = keep the current setting): attn_waves 0 =
+ * automatic, 4 | 8 = pin the attention block shape (MI_ATTN_PREFILL_WAVES); gemm_tail 0 = no tail split, 1 = the last
+ * partly filled round of a 256x256-tile GEMM on the 128x128 kernel, 2 = as 128x256 tiles of the 256 kernel (default,
+ * bit-identical to 0; MI_GEMM_TAIL). */
+int mi_debug_set_prefill_kernels(int attn_waves, int gemm_tail);
 
 #ifdef __cplusplus
 }

@@ -512,6 +512,11 @@ int mi_debug_set_engine_variant(int variant) {
   g_engine_variant = variant < 0 || variant > 2 ? 0 : variant;
   return prev;
 }
+int mi_debug_set_prefill_kernels(int attn_waves, int gemm_tail) {
+  attn_prefill_set_mode(attn_waves);
+  if (gemm_tail >= 0) gemm_set_tail_mode(gemm_tail);
+  return MI_OK;
+}
 int mi_debug_set_engine_trace(void* dev_buffer) {
   decode_engine_set_trace(dev_buffer);
   decode_engine_set_trace_wide(dev_buffer);

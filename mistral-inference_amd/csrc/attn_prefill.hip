@@ -339,9 +339,14 @@ static hipError_t launch_nw(const AttnPrefillArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+static int g_force_waves = -1;
+void attn_prefill_set_mode(int waves) {
+  if (waves >= 0) g_force_waves = waves;
+}
+
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
   if (a.Dh != DH || a.H % a.Hkv != 0) return hipErrorInvalidValue;
-  static int force = -1;  // MI_ATTN_PREFILL_WAVES=4|8 pins the block shape (A/B testing)
+  int& force = g_force_waves;  // MI_ATTN_PREFILL_WAVES=4|8 / mi_debug_set_prefill_kernels pin the block shape (A/B testing)
   if (force < 0) {
     const char* e = getenv("MI_ATTN_PREFILL_WAVES");
     force = e ? atoi(e) : 0;

@@ -305,6 +305,9 @@ GemmArgs column_slice(const GemmArgs& g, int c0, int c1) {
 
 }  // namespace
 
+static int split_tail = -1;  // MI_GEMM_TAIL / mi_debug_set_prefill_kernels: 0 no split, 1 tail on the 128 kernel, 2 half-height tiles
+void gemm_set_tail_mode(int mode) { split_tail = mode; }
+
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.K % 8 != 0 || g.M <= 0 || g.N <= 0) return hipErrorInvalidValue;
   static int use_256 = -1;  // MI_GEMM_256=0 keeps every shape on the 128x128 kernel (A/B testing)
@@ -318,11 +321,13 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   // One 256x256 block per CU: a tile count that is not a multiple of the CU count (256) leaves the last round partly empty
   // (q|k|v of Mistral-7B: 384 tiles = 1.5 rounds cost 2).  When the last round would be under 3/4 full, the columns
   // are split: full rounds on the 256 kernel, the remaining columns on the 128 kernel (two blocks per CU, four times
-  // the tiles) - MI_GEMM_TAIL=0 disables the split.
-  static int split_tail = -1;
+  // the tiles) - MI_GEMM_TAIL=0 disables the split.  Round 4: when the remaining columns are at most HALF a round of
+  // 256 x 256 tiles they run as 128 x 256 tiles of the 256 kernel instead (launch_gemm256_half: twice the blocks, so the
+  // half round becomes a full one; q|k|v of Mistral-7B: 256 + 128 tiles -> 256 + 256 blocks) - MI_GEMM_TAIL=1 keeps the
+  // 128 x 128 kernel for the tail, 2 (default) prefers the half-height tiles.
   if (split_tail < 0) {
     const char* e = getenv("MI_GEMM_TAIL");
-    split_tail = e ? atoi(e) : 1;
+    split_tail = e ? atoi(e) : 2;
   }
   const int nout = (g.epi == GEMM_SWIGLU) ? 128 : 256;
   const int m_tiles = (g.M + 255) / 256, n_tiles = (g.N + nout - 1) / nout;
@@ -338,7 +343,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       const int c0 = n_first * nout;
       hipError_t e = launch_gemm256(column_slice(g, 0, c0), s);
       if (e != hipSuccess) return e;
-      return launch_gemm128(column_slice(g, c0, g.N), s);
+      const GemmArgs tail = column_slice(g, c0, g.N);
+      if (split_tail >= 2 && rem * 2 <= cus && gemm256_half_applicable(tail)) return launch_gemm256_half(tail, s);
+      return launch_gemm128(tail, s);
     }
   }
   return launch_gemm256(g, s);

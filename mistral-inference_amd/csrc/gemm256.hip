@@ -64,6 +64,13 @@ constexpr int BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB: 128 rows x 128 B
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // A0 A1 B0 B1
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 KiB
+// Half-height form (MH = 1, round 4): a 128 x 256 output tile = ONE A half against both B halves, two phases per K tile,
+// three stages of {A0, B0, B1} (144 KiB).  It exists for the LAST, partly filled round of a launch: 384 tiles of
+// 256 x 256 (q|k|v of Mistral-7B at 4096 tokens) are 1.5 rounds of 256 CUs; the columns of the half round used to go
+// to the 128 x 128 kernel (twice the LDS bytes per flop: 0.72 PF); as 128 x 256 tiles they are exactly one full round
+// at 1.5x the LDS bytes per flop of the square tile.  Same MFMA shape, same k order: bit-identical outputs.
+constexpr int STAGE_BYTES_H = 3 * HALF_BYTES;
+constexpr int LDS_BYTES_H = 3 * STAGE_BYTES_H;  // 144 KiB
 
 __device__ __forceinline__ const bf16_t* seg_row256(const GemmArgs& g, int r) {
   if (r < g.n0) return g.w0 + (size_t)r * g.K;
@@ -91,10 +98,13 @@ __device__ __forceinline__ void lds_reads_done_then_barrier() {
   raw_barrier();
 }
 
-template <int EPI, bool STAGGER>
+template <int EPI, bool STAGGER, int MH = 2>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NOUT = (EPI == GEMM_SWIGLU) ? 128 : 256;  // output columns per block
+  constexpr int MROWS = MH * 128;                         // output rows per block
+  constexpr int STG = (MH + 2) * HALF_BYTES;              // bytes per stage: the A halves, B0, B1
+  static_assert(MH == 2 || (EPI == GEMM_STORE || EPI == GEMM_RESIDUAL), "half-height tiles: store / residual epilogues");
   // bf16 outputs: MFMAs issued as W-fragment x A-fragment (transposed 16x16 result tiles, see the epilogue); fp32
   // logits: A x W, whose 4-byte stores already cover 64-byte row segments and measured faster than 16-byte ones.
   constexpr bool kSwap = EPI != GEMM_LOGITS && EPI != GEMM_LOGPROB;
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   // ---- block -> tile.  Block b runs on XCD b % 8; a 4 (m) x 8 (n) supertile = the 32 blocks one XCD runs at a time
   // stays on one XCD so that its blocks share 4 A panels and 8 W panels in that XCD's L2 (guide T1; speed only).
   const bool grouped = g.tile_tab != nullptr;  // token-grouped MoE form: m-tiles come from the device tile table
-  const int m_tiles = grouped ? g.max_m_tiles : (g.M + 255) >> 8, n_tiles = (g.N + NOUT - 1) / NOUT;
+  const int m_tiles = grouped ? g.max_m_tiles : (g.M + MROWS - 1) / MROWS, n_tiles = (g.N + NOUT - 1) / NOUT;
   const int MS = (m_tiles + 3) >> 2, NS = (n_tiles + 7) >> 3;
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
   const int st = (q >> 5) * 8 + xcd, wi = q & 31;
@@ -126,34 +136,36 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
     w0 = reinterpret_cast<const bf16_t*>(g.expert_tab[e * 3 + g.w_sel0]);
     if (g.w_sel1 >= 0) w1 = reinterpret_cast<const bf16_t*>(g.expert_tab[e * 3 + g.w_sel1]);
   } else {
-    row0 = m_tile * 256;
-    rows_valid = min(256, g.M - row0);
+    row0 = m_tile * MROWS;
+    rows_valid = min(MROWS, g.M - row0);
   }
 
   // ---- DMA sources.  One instruction fills 8 consecutive 128-B rows of a half tile; wave w, piece j covers rows
   // (2w + j) * 8 .. + 8; lane l lands at (row + (l >> 3), slot l & 7) and fetches global slot (l & 7) ^ (row & 7).
   const int sslot = (lane & 7) ^ ((lane >> 3) & 7);
-  const bf16_t* src[4][2];
+  const bf16_t* src[MH + 2][2];  // halves of a stage: A0 (A1) B0 B1
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = (wid * 2 + j) * 8 + (lane >> 3);
-      int m = row0 + min(h * 128 + r, rows_valid - 1);
-      if (g.a_gather) m = g.a_gather[m];
-      src[h][j] = g.a + (size_t)m * g.lda + sslot * 8;
+      if (h < MH) {
+        int m = row0 + min(h * 128 + r, rows_valid - 1);
+        if (g.a_gather) m = g.a_gather[m];
+        src[h][j] = g.a + (size_t)m * g.lda + sslot * 8;
+      }
       if (EPI == GEMM_SWIGLU) {
         const int n = min(n_tile * 128 + r, g.N - 1);
-        src[2 + h][j] = (h == 0 ? w0 : w1) + (size_t)n * g.K + sslot * 8;
+        src[MH + h][j] = (h == 0 ? w0 : w1) + (size_t)n * g.K + sslot * 8;
       } else {
         const int n = min(n_tile * 256 + h * 128 + r, g.N - 1);
-        src[2 + h][j] = (grouped ? w0 + (size_t)n * g.K : seg_row256(g, n)) + sslot * 8;
+        src[MH + h][j] = (grouped ? w0 + (size_t)n * g.K : seg_row256(g, n)) + sslot * 8;
       }
     }
   char* const my_piece = smem + wid * 2048;  // this wave's two 1-KiB pieces inside any half tile
 #define STAGE_HALF(HALF, KT, STAGE)                                                              \
   do {                                                                                           \
-    char* dst_ = my_piece + (STAGE) * STAGE_BYTES + (HALF) * HALF_BYTES;                         \
+    char* dst_ = my_piece + (STAGE) * STG + (HALF) * HALF_BYTES;                                 \
     dma16(src[HALF][0] + (size_t)(KT) * BK, dst_);                                               \
     dma16(src[HALF][1] + (size_t)(KT) * BK, dst_ + 1024);                                        \
   } while (0)
@@ -162,11 +174,11 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   const int fq = lane >> 4;
   const int sw0 = ((fq) ^ (lane & 7)) << 4, sw1 = ((4 + fq) ^ (lane & 7)) << 4;
   const int a_off = (wr * 64 + (lane & 15)) * 128;
-  const int b_off = 2 * HALF_BYTES + (wc * 32 + (lane & 15)) * 128;
+  const int b_off = MH * HALF_BYTES + (wc * 32 + (lane & 15)) * 128;
 
-  f32x4 acc[2][2][4][2];
+  f32x4 acc[MH][2][4][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MH; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -210,6 +222,52 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[HA][HB][i][j], 0, 0, 0);
 
   const int nk = g.K / BK;
+  if constexpr (MH == 1) {
+    // ---- half-height tile: stage = {A0, B0, B1} (half indices 0, 1, 2), three stages, tile t in stage t % 3.  Tile
+    // t + 2 is staged during tile t into the stage tile t - 1 was read from (its last reads - by the group that runs one
+    // barrier behind - ended with the barrier before this tile's first read segment), and is waited for one tile later
+    // (vmcnt(6): everything but the six pieces issued since), two barriers before its first read.
+    STAGE_HALF(0, 0, 0);
+    STAGE_HALF(1, 0, 0);
+    STAGE_HALF(2, 0, 0);
+    if (nk > 1) {
+      STAGE_HALF(0, 1, 1);
+      STAGE_HALF(1, 1, 1);
+      STAGE_HALF(2, 1, 1);
+      wait_vm<6>();
+    } else {
+      wait_vm<0>();
+    }
+    raw_barrier();
+    if (STAGGER && wr == 1) raw_barrier();
+    int s = 0, s2 = 2;  // stage of tile t, of tile t + 2
+    for (int t = 0; t < nk; ++t) {
+      const char* sb = smem + s * STG;
+      const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+      // phase 1: quadrant (0, 0)
+      READ_B(b0x, 0, sb)
+      READ_A(0, sb)
+      if (more2) STAGE_HALF(0, t + 2, s2);
+      SEGMENT_END();
+      MFMA_QUAD(0, 0, b0x)
+      MFMA_END();
+      // phase 2: quadrant (0, 1); retire tile t + 1
+      READ_B(b1, 1, sb)
+      if (more2) {
+        STAGE_HALF(1, t + 2, s2);
+        STAGE_HALF(2, t + 2, s2);
+        wait_vm<6>();
+      } else if (more1) {
+        wait_vm<0>();
+      }
+      SEGMENT_END();
+      MFMA_QUAD(0, 1, b1)
+      MFMA_END();
+      s = (s == 2) ? 0 : s + 1;
+      s2 = (s2 == 2) ? 0 : s2 + 1;
+    }
+    if (STAGGER && wr == 0) raw_barrier();
+  } else {
   // ---- prologue: all of tile 0, then A0 B0 B1 of tile 1 (its A1 is staged by phase 1 of tile 0)
   STAGE_HALF(0, 0, 0);
   STAGE_HALF(2, 0, 0);
@@ -268,6 +326,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
     MFMA_END();
   }
   if (STAGGER && wr == 0) raw_barrier();
+  }  // MH == 2
 #undef STAGE_HALF
 #undef READ_A
 #undef READ_B
@@ -291,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
     __syncthreads();
     float2* part = reinterpret_cast<float2*>(smem);  // [256 rows][4 waves]
 #pragma unroll
-    for (int ha = 0; ha < 2; ++ha)
+    for (int ha = 0; ha < MH; ++ha)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -332,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   if constexpr (!kSwap) {
     // acc[ha][hb][i][j][r]: tile row ha*128 + wr*64 + i*16 + (lane>>4)*4 + r, tile column hb*128 + wc*32 + j*16 + (lane & 15)
 #pragma unroll
-    for (int ha = 0; ha < 2; ++ha)
+    for (int ha = 0; ha < MH; ++ha)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -360,7 +419,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   const bool wide_ok = (g.ldo & 3) == 0 && (reinterpret_cast<size_t>(g.out) & 15) == 0 &&
                        (EPI != GEMM_RESIDUAL || (reinterpret_cast<size_t>(g.residual) & 7) == 0);
 #pragma unroll
-  for (int ha = 0; ha < 2; ++ha)
+  for (int ha = 0; ha < MH; ++ha)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rl = ha * 128 + wr * 64 + i * 16 + (lane & 15);
@@ -434,26 +493,27 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
     }
 }
 
-template <int EPI, bool STAGGER>
+template <int EPI, bool STAGGER, int MH = 2>
 hipError_t launch_var(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  constexpr int lds = MH == 2 ? LDS_BYTES : LDS_BYTES_H;
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, STAGGER>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, STAGGER, MH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<EPI, STAGGER>), grid, dim3(512), LDS_BYTES, s, g);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, STAGGER, MH>), grid, dim3(512), lds, s, g);
   return hipGetLastError();
 }
-template <int EPI>
+template <int EPI, int MH = 2>
 hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
   static int stagger = -1;  // MI_GEMM_STAGGER=0: both wave groups in lockstep (A/B testing)
   if (stagger < 0) {
     const char* e = getenv("MI_GEMM_STAGGER");
     stagger = e ? atoi(e) : 1;
   }
-  return stagger ? launch_var<EPI, true>(g, grid, s) : launch_var<EPI, false>(g, grid, s);
+  return stagger ? launch_var<EPI, true, MH>(g, grid, s) : launch_var<EPI, false, MH>(g, grid, s);
 }
 
 }  // namespace
@@ -462,6 +522,23 @@ bool gemm256_applicable(const GemmArgs& g) {
   if (g.K % BK != 0 || g.K < 2 * BK) return false;
   if (g.tile_tab != nullptr) return g.tile_rows == 256;  // token-grouped form: the tile table decides
   return g.a_gather == nullptr && g.M >= 256;
+}
+
+// 128 x 256 tiles (MH = 1) for the columns of a launch's partly filled last round: plain (not token-grouped) store /
+// residual problems only.
+bool gemm256_half_applicable(const GemmArgs& g) {
+  return gemm256_applicable(g) && g.tile_tab == nullptr && (g.epi == GEMM_STORE || g.epi == GEMM_RESIDUAL);
+}
+
+hipError_t launch_gemm256_half(const GemmArgs& g, hipStream_t s) {
+  const int m_tiles = (g.M + 127) >> 7, n_tiles = (g.N + 255) >> 8;
+  const int supertiles = ((m_tiles + 3) >> 2) * ((n_tiles + 7) >> 3);
+  const dim3 grid((unsigned)(((supertiles + 7) / 8) * 8 * 32));
+  switch (g.epi) {
+    case GEMM_STORE: return launch_one<GEMM_STORE, 1>(g, grid, s);
+    case GEMM_RESIDUAL: return launch_one<GEMM_RESIDUAL, 1>(g, grid, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s) {

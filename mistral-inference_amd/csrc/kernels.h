@@ -97,6 +97,9 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 bool gemm256_applicable(const GemmArgs& g);  // gemm256.hip: 256x256 tile for the large prefill shapes
 hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s);
+bool gemm256_half_applicable(const GemmArgs& g);  // 128x256 tiles of the same kernel: the columns of a half-filled last round
+hipError_t launch_gemm256_half(const GemmArgs& g, hipStream_t s);
+void gemm_set_tail_mode(int mode);  // mi_debug_set_prefill_kernels
 
 // ---------------------------------------------------------------------------------------------- attention
 struct AttnDecodeArgs {
@@ -130,6 +133,7 @@ struct AttnPrefillArgs {
   float scale;  // softmax scale (already validated: > 0)
 };
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s);
+void attn_prefill_set_mode(int waves);  // mi_debug_set_prefill_kernels (negative: keep)
 
 // Compute units of the current device (256 on a full MI355X; fewer in partitioned modes).  Grid-shaping heuristics
 // (rounds of blocks, tail splitting) use it; results never depend on it.

@@ -106,6 +106,7 @@ _SIGS = {
     "mi_debug_engine_sabotage": (C.c_int, [_vp, C.c_int, _vp]),
     "mi_debug_set_engine_holders": (C.c_int, [C.c_int]),
     "mi_debug_set_engine_variant": (C.c_int, [C.c_int]),
+    "mi_debug_set_prefill_kernels": (C.c_int, [C.c_int, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -379,6 +380,11 @@ def decode_engine_status(workspace: torch.Tensor) -> dict:
 def debug_engine_sabotage(workspace: torch.Tensor, launches: int) -> None:
     """Test hook: the next `launches` engine launches on this workspace fail their residency gate."""
     check(lib().mi_debug_engine_sabotage(workspace.data_ptr(), launches, stream_ptr(workspace.device)), "mi_debug_engine_sabotage")
+
+
+def debug_set_prefill_kernels(attn_waves: int = -1, gemm_tail: int = -1) -> None:
+    """Same-process A/B of the prefill kernels' alternative forms (include/mistral_hip_debug.h; negative = keep)."""
+    check(lib().mi_debug_set_prefill_kernels(attn_waves, gemm_tail), "mi_debug_set_prefill_kernels")
 
 
 def decode_engine_reset(workspace: torch.Tensor) -> None:

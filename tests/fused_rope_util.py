@@ -2,8 +2,9 @@
 tests/test_gpu_ops.py::test_fused_rope_epilogue_bit_equal_to_separate_pass runs this file twice and compares the dumps.
 
   small: 3 layers of toy dims, ragged 3-sequence batch of 200 tokens  -> every GEMM on the 128-tile kernel (M < 256)
-  wide : 2 layers of the Mistral-7B dims, one 1000-token prompt then a 300-token chunk -> q on the 256-tile kernel, k | v on
-         the 128-tile kernel (the tail-round split), ragged last m-tile (1000 = 3 x 256 + 232)"""
+  wide : 2 layers of the Mistral-7B dims, one 1000-token prompt then a 300-token chunk -> the 256-tile kernel with a ragged last
+         m-tile (1000 = 3 x 256 + 232)
+  tail : 1 layer of the same dims, 4096 tokens -> 1.5 rounds of square tiles: the k | v columns run as half-height tiles"""
 import os
 import sys
 
@@ -21,6 +22,9 @@ CASES = {
                    rope_theta=1e4), [[120, 47, 33]]),
     "wide": (dict(dim=4096, n_layers=2, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5, vocab_size=4096,
                   rope_theta=1e6), [[1000], [300]]),
+    # 4096 tokens: q|k|v is 16 x 24 = 384 square tiles -> 256 of them + the k | v columns as 128 x 256 tiles (gemm256.hip, MH = 1)
+    "tail": (dict(dim=4096, n_layers=1, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5, vocab_size=1024,
+                  rope_theta=1e6), [[4096]]),
 }
 
 

@@ -180,6 +180,45 @@ def test_linear_tail_round_split():
     assert bool((e3 <= 4 * r3.abs() * 2.0 ** -7 + 8e-3).all()), float(e3.max())
 
 
+@pytest.mark.parametrize("M", [4096, 4000])
+@pytest.mark.parametrize("K", [128, 192, 448, 4096])
+def test_linear_half_height_tail_tiles(M, K):
+    """The partly filled last round of a 256-tile launch runs as 128 x 256 tiles of the same kernel (three-stage ring, two
+    phases per K tile: launch_gemm256_half).  16 x 24 = 384 tiles -> columns 4096.. are the tail.  Same MFMA shape and k
+    order as the square tile, so the tail columns must equal, bit for bit, (a) the same columns computed as a problem of
+    their own (128 square tiles: no split) and (c) the unsplit launch, and agree with (b) the tail on the 128-tile kernel; K from
+    two K tiles (prologue only) over odd counts (ring wrap at every phase) to the real 64; ragged last m-tile (M = 4000);
+    store and residual epilogues; repeated launches (DMAs stay in flight across barriers)."""
+    h = _hip()
+    N = 6144
+    x = rnd(M, K, seed=50)
+    ws = [rnd(4096, K, seed=51, scale=1 / math.sqrt(K)), rnd(1024, K, seed=52, scale=1 / math.sqrt(K)),
+          rnd(1024, K, seed=53, scale=1 / math.sqrt(K))]
+    res = rnd(M, N, seed=54)
+    xc, wc, rc = x.cuda(), tuple(w.cuda() for w in ws), res.cuda()
+    try:
+        h.debug_set_prefill_kernels(gemm_tail=2)
+        got = h.linear(xc, wc, h.EPI_STORE)
+        for _ in range(5):
+            assert torch.equal(h.linear(xc, wc, h.EPI_STORE), got)
+        got_r = h.linear(xc, wc, h.EPI_RESIDUAL, residual=rc)
+        alone = h.linear(xc, wc[1:], h.EPI_STORE)                      # (a) 16 x 8 tiles: one launch of the square kernel
+        assert torch.equal(got[:, 4096:], alone)
+        alone_r = h.linear(xc, wc[1:], h.EPI_RESIDUAL, residual=rc[:, 4096:].contiguous())
+        assert torch.equal(got_r[:, 4096:], alone_r)
+        h.debug_set_prefill_kernels(gemm_tail=0)                       # (c) unsplit: 1.5 rounds of the square kernel
+        assert torch.equal(h.linear(xc, wc, h.EPI_STORE), got)
+        assert torch.equal(h.linear(xc, wc, h.EPI_RESIDUAL, residual=rc), got_r)
+        h.debug_set_prefill_kernels(gemm_tail=1)                       # (b) tail on the 128-tile kernel (A x W operand order)
+        ok, err = bf16_ulp_close(h.linear(xc, wc, h.EPI_STORE).cpu(), got.cpu(), ulps=1.0)
+        assert ok, err
+    finally:
+        h.debug_set_prefill_kernels(gemm_tail=2)
+    if K <= 448:  # (the CPU matmul of the full K is minutes)
+        ok, err = bf16_ulp_close(got.cpu(), _lin_ref(x, ws).to(BF), ulps=1.0)
+        assert ok, err
+
+
 @pytest.mark.parametrize("M", [3, 40, 300, 1030])
 @pytest.mark.parametrize("K,V", [(256, 1000), (512, 4096), (200, 1000)])  # K = 200: never the fused route (K % 64)
 def test_lm_head_logprobs(M, K, V):
@@ -498,7 +537,8 @@ def test_moe_layer_general_route_any_expert_count_and_topk(E, k, T):
 def test_fused_rope_epilogue_bit_equal_to_separate_pass(tmp_path):
     """RoPE as the q|k|v GEMM's epilogue (csrc/gemm256.hip, csrc/gemm.hip; transformer_layers.py:66-70) == RoPE as the separate
     pass it replaced (MI_FUSE_ROPE=0), bit for bit: prefill logits of every chunk and the K/V rings, on the 128-tile kernel
-    alone (ragged 3-sequence batch) and on the 256-tile kernel + tail-round split (Mistral-7B dims, 1000 + 300 tokens)."""
+    alone (ragged 3-sequence batch), on the 256-tile kernel (Mistral-7B dims, 1000 + 300 tokens) and on its half-height tail
+    tiles (4096 tokens: the k | v columns)."""
     import os
     import subprocess
     import sys
