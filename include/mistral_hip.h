@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
@@ -269,6 +269,16 @@ size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_s
 /* The workspace must be ZERO-FILLED once after allocation (the first 4 KiB hold the control words of the persistent
  * decode engine - step epoch, status - and the engine's hand-off granules carry tags that must never match garbage). */
 int mi_forward(const mi_model_t* model, const mi_batch_t* batch, mi_stream_t stream);
+
+/* ABI v6 - storage dtypes other than bf16 (reference transformer.py:303,338: `from_folder(dtype=...)` keeps the dtype the
+ * caller asks for; the reference's own tests build fp32 models, tests/test_generate.py:51,100) and bf16 models of a shape
+ * mi_forward declines with MI_ERR_SHAPE (head_dim != 128, more than 16 experts, top_k = 3).  Same structs, same metadata
+ * protocol, same sample epilogue; every weight / activation / cache pointer is to `dtype` elements, `logits` stays fp32.
+ * Rounding points are the reference's in that dtype (csrc/generic.hip); with MI_DTYPE_FP32 nothing is rounded.  Launch by
+ * launch (capturable in a hipGraph by the caller), not tuned to the roofline: BASELINE's configurations are bf16. */
+enum mi_dtype { MI_DTYPE_BF16 = 0, MI_DTYPE_FP16 = 1, MI_DTYPE_FP32 = 2 };
+size_t mi_workspace_bytes_generic(const mi_model_t* model, int T, int dtype);
+int mi_forward_generic(const mi_model_t* model, const mi_batch_t* batch, int dtype, mi_stream_t stream);
 
 /* Persistent decode engine (csrc/decode_engine.hip).  A DECODE-branch mi_forward with T == B == 1 on a dense model runs
  * all local layers - TransformerBlock.forward (transformer_layers.py:158-169) x n_layers, the ring write (cache.py:83-92)

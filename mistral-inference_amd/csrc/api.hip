@@ -802,3 +802,182 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- generic storage dtype
+// mi_forward for fp32 / fp16 storage (and for bf16 models of a shape check_model declines): launch by launch over the
+// kernels of generic.hip.  Same mi_model_t / mi_batch_t contract (pointers are to `dtype` elements), same metadata
+// protocol (DECODE: positions from kv_seqlens on the device), same sample epilogue behind the LM head.
+namespace {
+
+struct GWorkspace {
+  uint32_t* ctrl;
+  char *xn, *qkv, *attn, *a, *b, *y, *res, *glog;
+  int32_t *sel_idx, *active;
+  float *sel_w, *wt;
+  size_t total;
+};
+
+GWorkspace carve_generic(const mi_model_t* m, int T, size_t es, char* base) {
+  GWorkspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  };
+  const size_t qkv_cols = (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
+  const bool moe = m->num_experts > 0;
+  w.ctrl = (uint32_t*)take(TICKET_BYTES);  // same control words as mi_forward (step counter, bad-id flag)
+  w.xn = take((size_t)T * m->dim * es);
+  w.qkv = take((size_t)T * qkv_cols * es);
+  w.attn = take((size_t)T * m->n_heads * m->head_dim * es);
+  w.a = take((size_t)T * m->hidden_dim * es);
+  w.b = take((size_t)T * m->hidden_dim * es);
+  w.y = take(moe ? (size_t)T * m->dim * es : 0);
+  w.res = take(moe ? (size_t)T * m->dim * es : 0);
+  w.glog = take(moe ? (size_t)T * m->num_experts * es : 0);
+  w.sel_idx = (int32_t*)take(moe ? (size_t)T * m->top_k * 4 : 0);
+  w.sel_w = (float*)take(moe ? (size_t)T * m->top_k * 4 : 0);
+  w.active = (int32_t*)take(moe ? (size_t)T * 4 : 0);
+  w.wt = (float*)take(moe ? (size_t)T * 4 : 0);
+  w.total = off;
+  return w;
+}
+
+int check_model_generic(const mi_model_t* m, int dtype) {
+  if (!m || !m->layers) return fail(MI_ERR_ARG, "null model");
+  if (dtype != G_DT_BF16 && dtype != G_DT_FP16 && dtype != G_DT_FP32) return fail(MI_ERR_ARG, "storage dtype %d", dtype);
+  if (m->head_dim <= 0 || m->head_dim > 256 || m->head_dim % 8) return fail(MI_ERR_SHAPE, "head_dim %d: multiple of 8, <= 256", m->head_dim);
+  if (m->n_kv_heads <= 0 || m->n_heads % m->n_kv_heads) return fail(MI_ERR_SHAPE, "n_heads %% n_kv_heads != 0");
+  if (m->dim % 8 || m->hidden_dim % 8) return fail(MI_ERR_SHAPE, "dim/hidden_dim must be multiples of 8");
+  if (m->num_experts > 0 && (m->top_k <= 0 || m->top_k > m->num_experts)) return fail(MI_ERR_SHAPE, "MoE: 0 < top_k <= num_experts");
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_workspace_bytes_generic(const mi_model_t* model, int T, int dtype) {
+  if (!model || T <= 0) return 0;
+  return carve_generic(model, T, g_elem_bytes(dtype), nullptr).total;
+}
+
+int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_stream_t stream) {
+  MI_TRY(check_model_generic(m, dtype));
+  if (!bt || bt->T <= 0 || bt->B <= 0 || !bt->h || !bt->workspace) return fail(MI_ERR_ARG, "mi_forward_generic: batch");
+  if (!bt->q_start || !bt->kv_before || !bt->tok_seq || !bt->tok_pos) return fail(MI_ERR_ARG, "mi_forward_generic: metadata");
+  const int T = bt->T, B = bt->B, branch = bt->branch;
+  const bool has_cache = branch != MI_BRANCH_NOCACHE;
+  if (has_cache && (!bt->cache_k || !bt->cache_v || !bt->cache_sizes)) return fail(MI_ERR_ARG, "mi_forward_generic: cache");
+  if (branch == MI_BRANCH_DECODE && (T != B || !bt->kv_seqlens)) return fail(MI_ERR_ARG, "mi_forward_generic: decode needs T == B");
+  if (bt->logits && (!m->final_norm || !m->output)) return fail(MI_ERR_ARG, "mi_forward_generic: logits on a rank without LM head");
+  hipStream_t s = (hipStream_t)stream;
+  const int dt = dtype;
+  const size_t es = g_elem_bytes(dt);
+  GWorkspace ws = carve_generic(m, T, es, (char*)bt->workspace);
+  if (ws.total > bt->workspace_bytes)
+    return fail(MI_ERR_WORKSPACE, "workspace %zu < required %zu", bt->workspace_bytes, ws.total);
+
+  const int D = m->dim, H = m->n_heads, Hkv = m->n_kv_heads, Dh = m->head_dim, F = m->hidden_dim;
+  const int nq = H * Dh, nkv = Hkv * Dh, qkv_cols = nq + 2 * nkv;
+  char* h = (char*)bt->h;
+  const bool want_sample = branch == MI_BRANCH_DECODE && bt->logits && bt->greedy_token && bt->greedy_logprob;
+  if (bt->greedy_token && !want_sample)
+    return fail(MI_ERR_ARG, "mi_forward_generic: greedy_token needs the DECODE branch, logits and greedy_logprob");
+  if (want_sample && bt->hist_len > 0 && (!bt->hist_token || !bt->hist_logprob))
+    return fail(MI_ERR_ARG, "mi_forward_generic: hist_len > 0 without history buffers");
+  const bool want_topp = want_sample && bt->sample_temperature > 0.f;
+  if (bt->sample_temperature < 0.f || (want_topp && !(bt->sample_top_p >= 0.f && bt->sample_top_p <= 1.f)))
+    return fail(MI_ERR_ARG, "mi_forward_generic: sample_temperature / sample_top_p");
+
+  auto linear = [&](const void* x, int ldx, const void* w, void* out, int ldo, int N, int K, int epi, const void* residual,
+                    const int32_t* active, const char* what) -> int {
+    GLinearArgs g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.ldx = ldx; g.w = w; g.out = out; g.ldo = ldo; g.residual = residual; g.ldr = ldo;
+    g.M = T; g.N = N; g.K = K; g.epi = epi; g.active = active;
+    return hip_rc(launch_g_linear(dt, g, s), what);
+  };
+
+  if (branch == MI_BRANCH_DECODE)
+    MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, ws.ctrl, s), "decode_prep"));
+  if (m->tok_embeddings && bt->input_ids)
+    MI_TRY(hip_rc(launch_g_embedding(dt, h, m->tok_embeddings, bt->input_ids, T, D, m->vocab_size, ws.ctrl + 3, s), "embedding"));
+
+  for (int l = 0; l < m->n_layers; ++l) {
+    const mi_layer_t& L = m->layers[l];
+    const int W = has_cache ? bt->cache_sizes[l] : T;
+    void* ck = has_cache ? bt->cache_k[l] : nullptr;
+    void* cv = has_cache ? bt->cache_v[l] : nullptr;
+    // ---- attention_norm, q | k | v, RoPE (transformer_layers.py:66-70)
+    MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.attention_norm, T, D, m->norm_eps, s), "attention_norm"));
+    MI_TRY(linear(ws.xn, D, L.wq, ws.qkv, qkv_cols, nq, D, G_EPI_STORE, nullptr, nullptr, "wq"));
+    MI_TRY(linear(ws.xn, D, L.wk, ws.qkv + (size_t)nq * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wk"));
+    MI_TRY(linear(ws.xn, D, L.wv, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wv"));
+    MI_TRY(hip_rc(launch_g_rope(dt, ws.qkv, qkv_cols, T, nq + nkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
+    // ---- attention over [surviving ring entries ++ this forward's keys], then the ring write (cache.py:83-117)
+    GAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.out = ws.attn; a.ldo = nq; a.qkv = ws.qkv; a.ld = qkv_cols; a.cache_k = ck; a.cache_v = cv;
+    a.W = W; a.T = T; a.H = H; a.Hkv = Hkv; a.Dh = Dh;
+    a.q_start = bt->q_start; a.kv_before = bt->kv_before; a.tok_seq = bt->tok_seq; a.tok_pos = bt->tok_pos;
+    a.causal = has_cache ? 1 : 0;
+    a.scale = 1.0f / sqrtf((float)Dh);
+    MI_TRY(hip_rc(launch_g_attention(dt, a, s), "attention"));
+    if (has_cache)
+      MI_TRY(hip_rc(launch_g_kv_write(dt, ck, cv, W, ws.qkv + (size_t)nq * es, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, T, nkv,
+                                      bt->tok_seq, bt->tok_pos, bt->q_start, s), "kv_write"));
+    // ---- h = h + wo(attn)
+    MI_TRY(linear(ws.attn, nq, L.wo, h, D, D, nq, G_EPI_RESIDUAL, h, nullptr, "wo"));
+    // ---- h = h + FFN(ffn_norm(h))
+    MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
+    if (m->num_experts == 0) {
+      if (!L.w1 || !L.w2 || !L.w3) return fail(MI_ERR_ARG, "mi_forward_generic: dense layer without w1/w2/w3");
+      MI_TRY(linear(ws.xn, D, L.w1, ws.a, F, F, D, G_EPI_STORE, nullptr, nullptr, "w1"));
+      MI_TRY(linear(ws.xn, D, L.w3, ws.b, F, F, D, G_EPI_STORE, nullptr, nullptr, "w3"));
+      MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, nullptr, s), "swiglu"));
+      MI_TRY(linear(ws.a, F, L.w2, h, D, D, F, G_EPI_RESIDUAL, h, nullptr, "w2"));
+    } else {
+      // moe.py:24-32: experts in ascending id, each adding round(weight * expert(x)) for the rows that picked it
+      const int E = m->num_experts, k = m->top_k;
+      if (!L.gate || !L.expert_w_host) return fail(MI_ERR_ARG, "mi_forward_generic: MoE layer tables");
+      MI_TRY(linear(ws.xn, D, L.gate, ws.glog, E, E, D, G_EPI_STORE, nullptr, nullptr, "gate"));
+      MI_TRY(hip_rc(launch_g_moe_topk(dt, ws.glog, T, E, k, ws.sel_idx, ws.sel_w, s), "moe top-k"));
+      MI_TRY(hip_rc(launch_g_zero(dt, ws.res, (size_t)T * D, s), "moe zero"));
+      for (int e = 0; e < E; ++e) {
+        const void* w1 = L.expert_w_host[e * 3 + 0];
+        const void* w2 = L.expert_w_host[e * 3 + 1];
+        const void* w3 = L.expert_w_host[e * 3 + 2];
+        MI_TRY(hip_rc(launch_g_moe_mask(ws.sel_idx, ws.sel_w, T, k, e, ws.active, ws.wt, s), "moe mask"));
+        MI_TRY(linear(ws.xn, D, w1, ws.a, F, F, D, G_EPI_STORE, nullptr, ws.active, "expert w1"));
+        MI_TRY(linear(ws.xn, D, w3, ws.b, F, F, D, G_EPI_STORE, nullptr, ws.active, "expert w3"));
+        MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, ws.active, s), "expert swiglu"));
+        MI_TRY(linear(ws.a, F, w2, ws.y, D, D, F, G_EPI_STORE, nullptr, ws.active, "expert w2"));
+        MI_TRY(hip_rc(launch_g_moe_accum(dt, ws.res, ws.y, ws.active, ws.wt, T, D, s), "moe accumulate"));
+      }
+      MI_TRY(hip_rc(launch_g_add(dt, h, h, ws.res, (size_t)T * D, s), "moe residual"));
+    }
+  }
+
+  if (m->final_norm) {
+    if (bt->logits) {
+      MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+      MI_TRY(linear(ws.xn, D, m->output, bt->logits, m->vocab_size, m->vocab_size, D, G_EPI_LOGITS, nullptr, nullptr, "lm head"));
+      if (want_sample) {
+        if (want_topp)
+          MI_TRY(hip_rc(launch_sample_top_p(bt->logits, m->vocab_size, B, m->vocab_size, bt->sample_temperature, bt->sample_top_p,
+                                            bt->sample_seed, bt->sample_offset, nullptr, bt->greedy_token, bt->greedy_logprob,
+                                            bt->hist_token, bt->hist_logprob, bt->hist_len, ws.ctrl, s), "top-p sample"));
+        else
+          MI_TRY(hip_rc(launch_greedy_rows(bt->logits, m->vocab_size, B, m->vocab_size, bt->greedy_token, bt->greedy_logprob,
+                                           bt->hist_token, bt->hist_logprob, bt->hist_len, ws.ctrl, s), "greedy sample"));
+      }
+    } else {
+      MI_TRY(hip_rc(launch_g_rmsnorm(dt, h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+    }
+  }
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,549 @@
+// Generic-storage layer kernels: the same operator sequence as the bf16 hot path for models whose storage dtype is fp32 or
+// fp16 (reference transformer.py:303,338: `from_folder(dtype=...)` keeps whatever dtype the caller asks for, and the
+// reference's own tests build fp32 models, tests/test_generate.py:51,100), and for bf16 models of a shape the tuned gfx950
+// kernels decline (head_dim != 128, more than 16 experts, top_k = 3: csrc/api.hip check_model).
+//
+// Numerics contract = the reference's execution in the storage dtype T (the test oracle
+// restates it): every nn.Linear accumulates in fp32 and rounds its output to T; RMSNorm normalises in fp32, rounds to T,
+// multiplies by the weight and rounds again (transformer_layers.py:115-120); RoPE is an fp32 complex multiply rounded to T
+// (rope.py:13-23); attention is fp32 softmax(q k^T / sqrt(Dh) + mask) v rounded to T; SiLU, the gate product, both
+// residual adds and the MoE accumulation (moe.py:24-32) each round to T.  With T = fp32 nothing is rounded and the logits
+// agree with the reference's stored fp32 outputs to ~1e-5 (tests/test_gpu_generic.py).
+//
+// These kernels are written for correctness and reasonable streaming behaviour, not for the roofline: BASELINE.json's
+// configurations are all bf16 and run on the tuned kernels (gemv_core.cuh, gemm256.hip, decode_engine.hip, ...).
+//   * linear, more than 8 rows: 64 x 64 output tile, K in slabs of 16 staged through LDS as fp32, 4 x 4 outputs per thread,
+//     one fp32 FMA chain per output in ascending k;
+//   * linear, up to 8 rows (decode): one wave per output column, 16-byte weight loads, lanes stride K, wave reduction;
+//   * attention: one block per (query token, head); a thread scores one key per 128-key sweep, online softmax across
+//     sweeps, a thread owns one (two) output dimension(s).  Keys older than this forward come from the ring at slot
+//     position % W, newer ones from the post-RoPE activation rows (same visibility rule as attn_prefill.hip), so the one
+//     kernel serves first prefills, later chunks, decode steps and the cache=None call.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace {
+
+struct sbf16 {
+  uint16_t v;
+};
+
+template <typename T>
+struct St;
+template <>
+struct St<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+  static __device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[i] = a[i];
+      o[4 + i] = b[i];
+    }
+  }
+};
+template <>
+struct St<_Float16> {
+  static __device__ __forceinline__ float ld(const _Float16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+  static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+  static __device__ __forceinline__ void ld8(const _Float16* p, float (&o)[8]) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 a = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+  }
+};
+template <>
+struct St<sbf16> {
+  static __device__ __forceinline__ float ld(const sbf16* p) { return bf_to_f(p->v); }
+  static __device__ __forceinline__ void st(sbf16* p, float v) { p->v = f_to_bf(v); }
+  static __device__ __forceinline__ float rnd(float v) { return bf_round(v); }
+  static __device__ __forceinline__ void ld8(const sbf16* p, float (&o)[8]) {
+    const u32x4 a = ld16(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = bf_lo(a[i]);
+      o[2 * i + 1] = bf_hi(a[i]);
+    }
+  }
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+// transformer.py:193.  Out-of-range ids: flagged in *bad_id (1 + token index) and clamped, as embedding_kernel does.
+template <typename T>
+__global__ __launch_bounds__(256) void g_embedding_kernel(T* out, const T* table, const int64_t* ids, int D, int vocab,
+                                                          uint32_t* bad_id) {
+  const int t = blockIdx.x;
+  long id = ids[t];
+  if (id < 0 || id >= vocab) {
+    if (bad_id && threadIdx.x == 0) atomicMax(bad_id, (uint32_t)t + 1u);
+    id = id < 0 ? 0 : vocab - 1;
+  }
+  const T* src = table + (size_t)id * D;
+  T* dst = out + (size_t)t * D;
+  for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ RMSNorm
+// transformer_layers.py:115-120: one block per row.
+template <typename T>
+__global__ __launch_bounds__(256) void g_rmsnorm_kernel(T* out, const T* x, const T* w, int D, float eps) {
+  __shared__ float part[4];
+  const int t = blockIdx.x;
+  const T* xr = x + (size_t)t * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float a = St<T>::ld(xr + i);
+    ss = fmaf(a, a, ss);
+  }
+  ss = wave_sum_f(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+  const float inv = 1.0f / sqrtf(tot / (float)D + eps);
+  T* o = out + (size_t)t * D;
+  for (int i = threadIdx.x; i < D; i += 256)
+    St<T>::st(o + i, St<T>::rnd(St<T>::ld(xr + i) * inv) * St<T>::ld(w + i));
+}
+
+// ------------------------------------------------------------------------------------------------ linear
+// out[m, n] = epilogue(sum_k x[m, k] * w[n, k]): STORE rounds to T, RESIDUAL adds the (T) residual to the rounded product
+// and rounds again (`h + wo(...)`), LOGITS writes fp32 of the T-rounded value (`output(...).float()`, transformer.py:235-242).
+// `active` (MoE): tiles / launches none of whose rows is active do nothing; rows of a computed tile are all written.
+template <typename T, int EPI>
+__device__ __forceinline__ void g_store(const GLinearArgs& g, int m, int n, float acc) {
+  const float v = St<T>::rnd(acc);
+  if (EPI == G_EPI_LOGITS) {
+    reinterpret_cast<float*>(g.out)[(size_t)m * g.ldo + n] = v;
+  } else if (EPI == G_EPI_RESIDUAL) {
+    const float r = St<T>::ld(reinterpret_cast<const T*>(g.residual) + (size_t)m * g.ldr + n);
+    St<T>::st(reinterpret_cast<T*>(g.out) + (size_t)m * g.ldo + n, r + v);
+  } else {
+    St<T>::st(reinterpret_cast<T*>(g.out) + (size_t)m * g.ldo + n, v);
+  }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void g_gemm_kernel(GLinearArgs g) {
+  constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
+  __shared__ float As[BK][BM + PAD];
+  __shared__ float Ws[BK][BN + PAD];
+  __shared__ int any_active;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (g.active) {
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M && g.active[m0 + tid]) any_active = 1;
+    __syncthreads();
+    if (!any_active) return;
+  }
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* w = reinterpret_cast<const T*>(g.w);
+  // staging: thread -> (row tid >> 2, k offset (tid & 3) * 4) of both tiles
+  const int sr = tid >> 2, sk = (tid & 3) * 4;
+  const int am = min(m0 + sr, g.M - 1), wn = min(n0 + sr, g.N - 1);
+  const T* ap = x + (size_t)am * g.ldx + sk;
+  const T* wp = w + (size_t)wn * g.K + sk;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool in = k0 + sk + i < g.K;
+      As[sk + i][sr] = in ? St<T>::ld(ap + k0 + i) : 0.f;
+      Ws[sk + i][sr] = in ? St<T>::ld(wp + k0 + i) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[kk][ty * 4]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[kk][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n < g.N) g_store<T, EPI>(g, m, n, acc[i][j]);
+    }
+  }
+}
+
+// M <= 8 rows, K a multiple of 8: one wave per output column.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= g.N) return;
+  if (g.active) {
+    bool any = false;
+    for (int m = 0; m < g.M; ++m) any = any || g.active[m] != 0;
+    if (!any) return;
+  }
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* wr = reinterpret_cast<const T*>(g.w) + (size_t)n * g.K;
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+  for (int k = lane * 8; k < g.K; k += 64 * 8) {
+    float wv[8];
+    St<T>::ld8(wr + k, wv);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < g.M) {
+        float xv[8];
+        St<T>::ld8(x + (size_t)m * g.ldx + k, xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[m] = fmaf(xv[i], wv[i], acc[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    if (m < g.M) {
+      const float v = wave_sum_f(acc[m]);
+      if (lane == 0) g_store<T, EPI>(g, m, n, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE
+// rope.py:13-23, in place on the first n_rot_cols columns (q | k) of the fused buffer; one thread per pair.
+template <typename T>
+__global__ __launch_bounds__(256) void g_rope_kernel(T* qkv, int ld, int T_rows, int n_rot_cols, int Dh, const float* rope_cs,
+                                                     const int32_t* tok_pos) {
+  const int pairs = n_rot_cols >> 1;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)T_rows * pairs) return;
+  const int t = (int)(gid / pairs), p = (int)(gid % pairs);
+  const int i = p % (Dh >> 1);
+  T* ptr = qkv + (size_t)t * ld + 2 * p;
+  const float* cs = rope_cs + ((size_t)tok_pos[t] * (Dh >> 1) + i) * 2;
+  float re, im;
+  rope_pair(St<T>::ld(ptr), St<T>::ld(ptr + 1), cs[0], cs[1], re, im);
+  St<T>::st(ptr, re);
+  St<T>::st(ptr + 1, im);
+}
+
+// ------------------------------------------------------------------------------------------------ ring write
+// cache.py:83-92 + 226-235 (kv_write_kernel for any element type): only the last W tokens of a chunk are stored.
+template <typename T>
+__global__ __launch_bounds__(256) void g_kv_write_kernel(T* ck, T* cv, int W, const T* k, const T* v, int ld, int T_rows, int kv_dim,
+                                                         const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)T_rows * kv_dim) return;
+  const int t = (int)(gid / kv_dim), c = (int)(gid % kv_dim);
+  const int b = tok_seq[t];
+  const int i = t - q_start[b];
+  const int s = q_start[b + 1] - q_start[b];
+  if (i < s - W) return;
+  const size_t slot = (size_t)b * W + (tok_pos[t] % W);
+  ck[slot * kv_dim + c] = k[(size_t)t * ld + c];
+  cv[slot * kv_dim + c] = v[(size_t)t * ld + c];
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// transformer_layers.py:74-89 for every branch.  Block = (query token, q head), 128 threads.
+template <typename T>
+__global__ __launch_bounds__(128) void g_attention_kernel(GAttnArgs a) {
+  __shared__ float qs[256];
+  __shared__ float ps[128];
+  __shared__ const T* kptr[128];
+  __shared__ const T* vptr[128];
+  __shared__ float red[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = blockIdx.x, h = blockIdx.y;
+  const int Dh = a.Dh, kvh = h / (a.H / a.Hkv);
+  const int nq = a.H * Dh, kv_dim = a.Hkv * Dh;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  int row0, p_b, qp, b, W;
+  if (a.causal) {
+    b = a.tok_seq[t];
+    row0 = a.q_start[b];
+    p_b = a.kv_before[b];
+    qp = a.tok_pos[t];
+    W = a.W;
+  } else {
+    b = 0;
+    row0 = 0;
+    p_b = 0;
+    qp = a.T - 1;
+    W = a.T;
+  }
+  const int n_old = min(p_b, W);
+  const int kp_lo = a.causal ? max(p_b - n_old, qp - W + 1) : 0;
+  const int kp_hi = qp;
+  for (int d = tid; d < Dh; d += 128) qs[d] = St<T>::ld(qkv + (size_t)t * a.ld + (size_t)h * Dh + d);
+  const T* ring_k = a.cache_k ? reinterpret_cast<const T*>(a.cache_k) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : nullptr;
+  const T* ring_v = a.cache_v ? reinterpret_cast<const T*>(a.cache_v) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : nullptr;
+  const T* act_k = qkv + nq + (size_t)kvh * Dh;
+  const T* act_v = act_k + kv_dim;
+  float m_run = -INFINITY, l_run = 0.f, acc0 = 0.f, acc1 = 0.f;
+  __syncthreads();
+  for (int base = kp_lo; base <= kp_hi; base += 128) {
+    const int kp = base + tid;
+    const bool valid = kp <= kp_hi;
+    float s = -INFINITY;
+    if (valid) {
+      const T *kr, *vr;
+      if (kp < p_b) {
+        const size_t off = (size_t)(kp % W) * kv_dim;
+        kr = ring_k + off;
+        vr = ring_v + off;
+      } else {
+        const size_t off = (size_t)(row0 + kp - p_b) * a.ld;
+        kr = act_k + off;
+        vr = act_v + off;
+      }
+      kptr[tid] = kr;
+      vptr[tid] = vr;
+      float dot = 0.f;
+      for (int d = 0; d < Dh; d += 8) {
+        float kv8[8];
+        St<T>::ld8(kr + d, kv8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dot = fmaf(qs[d + i], kv8[i], dot);
+      }
+      s = dot * a.scale;
+    }
+    float mx = wave_max_f(s);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    const float m_new = fmaxf(m_run, fmaxf(red[0], red[1]));
+    const float p = valid ? expf(s - m_new) : 0.f;
+    ps[tid] = p;
+    float sum = wave_sum_f(p);
+    __syncthreads();  // red[] read by everybody, ps / vptr written
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float alpha = expf(m_run - m_new);  // (first sweep: exp(-inf) = 0 against zero accumulators)
+    l_run = l_run * alpha + (red[0] + red[1]);
+    m_run = m_new;
+    const int cnt = min(128, kp_hi - base + 1);
+    acc0 *= alpha;
+    acc1 *= alpha;
+    if (tid < Dh) {
+      for (int j = 0; j < cnt; ++j) acc0 = fmaf(ps[j], St<T>::ld(vptr[j] + tid), acc0);
+    }
+    if (tid + 128 < Dh) {
+      for (int j = 0; j < cnt; ++j) acc1 = fmaf(ps[j], St<T>::ld(vptr[j] + tid + 128), acc1);
+    }
+    __syncthreads();  // before the next sweep overwrites ps / vptr / red
+  }
+  T* o = reinterpret_cast<T*>(a.out) + (size_t)t * a.ldo + (size_t)h * Dh;
+  if (tid < Dh) St<T>::st(o + tid, acc0 / l_run);
+  if (tid + 128 < Dh) St<T>::st(o + tid + 128, acc1 / l_run);
+}
+
+// ------------------------------------------------------------------------------------------------ SwiGLU
+// transformer_layers.py:106: silu(w1 x) * w3 x with both intermediates rounded to T.  In place on `a`.
+template <typename T>
+__global__ __launch_bounds__(256) void g_swiglu_kernel(T* a, const T* b, int T_rows, int F, const int32_t* active) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)T_rows * F) return;
+  if (active && !active[gid / F]) return;
+  const float x = St<T>::ld(a + gid);
+  const float sl = St<T>::rnd(x / (1.0f + expf(-x)));
+  St<T>::st(a + gid, sl * St<T>::ld(b + gid));
+}
+
+// ------------------------------------------------------------------------------------------------ MoE
+// moe.py:26-27: top-k of the (T-rounded) router logits, fp32 softmax over the picked ones, rounded to T.  One thread per token;
+// ties go to the lower expert id.
+template <typename T>
+__global__ __launch_bounds__(64) void g_moe_topk_kernel(const T* logits, int T_rows, int E, int k, int32_t* sel_idx, float* sel_w) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T_rows) return;
+  const T* row = logits + (size_t)t * E;
+  float mx = -INFINITY;
+  for (int j = 0; j < k; ++j) {
+    int best = -1;
+    float bv = -INFINITY;
+    for (int e = 0; e < E; ++e) {
+      bool taken = false;
+      for (int q = 0; q < j; ++q) taken = taken || sel_idx[(size_t)t * k + q] == e;
+      const float v = St<T>::ld(row + e);
+      if (!taken && (best < 0 || v > bv)) {
+        best = e;
+        bv = v;
+      }
+    }
+    sel_idx[(size_t)t * k + j] = best;
+    sel_w[(size_t)t * k + j] = bv;
+    mx = fmaxf(mx, bv);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float p = expf(sel_w[(size_t)t * k + j] - mx);
+    sel_w[(size_t)t * k + j] = p;
+    sum += p;
+  }
+  for (int j = 0; j < k; ++j) sel_w[(size_t)t * k + j] = St<T>::rnd(sel_w[(size_t)t * k + j] / sum);
+}
+
+// rows that picked expert e, and their weight
+__global__ __launch_bounds__(256) void g_moe_mask_kernel(const int32_t* sel_idx, const float* sel_w, int T_rows, int k, int e,
+                                                         int32_t* active, float* wt) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T_rows) return;
+  int on = 0;
+  float w = 0.f;
+  for (int j = 0; j < k; ++j)
+    if (sel_idx[(size_t)t * k + j] == e) {
+      on = 1;
+      w = sel_w[(size_t)t * k + j];
+    }
+  active[t] = on;
+  wt[t] = w;
+}
+
+// moe.py:31: results[rows] += weight * expert(rows), product and sum each rounded to T
+template <typename T>
+__global__ __launch_bounds__(256) void g_moe_accum_kernel(T* results, const T* y, const int32_t* active, const float* wt, int T_rows,
+                                                          int D) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)T_rows * D) return;
+  const int t = (int)(gid / D);
+  if (!active[t]) return;
+  const float prod = St<T>::rnd(wt[t] * St<T>::ld(y + gid));
+  St<T>::st(results + gid, St<T>::ld(results + gid) + prod);
+}
+
+// out = a + b, rounded to T (`h + r`, transformer_layers.py:166-168)
+template <typename T>
+__global__ __launch_bounds__(256) void g_add_kernel(T* out, const T* a, const T* b, size_t n) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid < n) St<T>::st(out + gid, St<T>::ld(a + gid) + St<T>::ld(b + gid));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void g_zero_kernel(T* p, size_t n) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid < n) St<T>::st(p + gid, 0.f);
+}
+
+template <typename T, int EPI>
+hipError_t linear_t(const GLinearArgs& g, hipStream_t s) {
+  if (g.M <= 8 && g.K % 8 == 0 && g.ldx % 8 == 0) {
+    hipLaunchKernelGGL((g_gemv_kernel<T, EPI>), dim3((g.N + 3) / 4), dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((g_gemm_kernel<T, EPI>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, s, g);
+  }
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t linear_e(const GLinearArgs& g, hipStream_t s) {
+  switch (g.epi) {
+    case G_EPI_STORE: return linear_t<T, G_EPI_STORE>(g, s);
+    case G_EPI_RESIDUAL: return linear_t<T, G_EPI_RESIDUAL>(g, s);
+    case G_EPI_LOGITS: return linear_t<T, G_EPI_LOGITS>(g, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+#define G_DISPATCH(dt, CALL)                                   \
+  switch (dt) {                                                \
+    case G_DT_BF16: { using T = sbf16; CALL; break; }          \
+    case G_DT_FP16: { using T = _Float16; CALL; break; }       \
+    case G_DT_FP32: { using T = float; CALL; break; }          \
+    default: return hipErrorInvalidValue;                      \
+  }                                                            \
+  return hipGetLastError();
+
+size_t g_elem_bytes(int dt) { return dt == G_DT_FP32 ? 4 : 2; }
+
+hipError_t launch_g_embedding(int dt, void* out, const void* table, const int64_t* ids, int T_rows, int D, int vocab, uint32_t* bad_id,
+                              hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_embedding_kernel<T>), dim3(T_rows), dim3(256), 0, s, (T*)out, (const T*)table, ids, D, vocab, bad_id))
+}
+
+hipError_t launch_g_rmsnorm(int dt, void* out, const void* x, const void* w, int T_rows, int D, float eps, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_rmsnorm_kernel<T>), dim3(T_rows), dim3(256), 0, s, (T*)out, (const T*)x, (const T*)w, D, eps))
+}
+
+hipError_t launch_g_linear(int dt, const GLinearArgs& g, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
+  switch (dt) {
+    case G_DT_BF16: return linear_e<sbf16>(g, s);
+    case G_DT_FP16: return linear_e<_Float16>(g, s);
+    case G_DT_FP32: return linear_e<float>(g, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_g_rope(int dt, void* qkv, int ld, int T_rows, int n_rot_cols, int Dh, const float* rope_cs, const int32_t* tok_pos,
+                         hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_rope_kernel<T>), dim3(blocks_for((size_t)T_rows * (n_rot_cols >> 1))), dim3(256), 0, s, (T*)qkv, ld,
+                                    T_rows, n_rot_cols, Dh, rope_cs, tok_pos))
+}
+
+hipError_t launch_g_kv_write(int dt, void* ck, void* cv, int W, const void* k, const void* v, int ld, int T_rows, int kv_dim,
+                             const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_kv_write_kernel<T>), dim3(blocks_for((size_t)T_rows * kv_dim)), dim3(256), 0, s, (T*)ck, (T*)cv, W,
+                                    (const T*)k, (const T*)v, ld, T_rows, kv_dim, tok_seq, tok_pos, q_start))
+}
+
+hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s) {
+  if (a.Dh > 256 || a.Dh % 8 || a.H % a.Hkv) return hipErrorInvalidValue;
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_attention_kernel<T>), dim3(a.T, a.H), dim3(128), 0, s, a))
+}
+
+hipError_t launch_g_swiglu(int dt, void* a, const void* b, int T_rows, int F, const int32_t* active, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_swiglu_kernel<T>), dim3(blocks_for((size_t)T_rows * F)), dim3(256), 0, s, (T*)a, (const T*)b, T_rows, F,
+                                    active))
+}
+
+hipError_t launch_g_moe_topk(int dt, const void* logits, int T_rows, int E, int k, int32_t* sel_idx, float* sel_w, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_moe_topk_kernel<T>), dim3((T_rows + 63) / 64), dim3(64), 0, s, (const T*)logits, T_rows, E, k, sel_idx,
+                                    sel_w))
+}
+
+hipError_t launch_g_moe_mask(const int32_t* sel_idx, const float* sel_w, int T_rows, int k, int e, int32_t* active, float* wt,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(g_moe_mask_kernel, dim3((T_rows + 255) / 256), dim3(256), 0, s, sel_idx, sel_w, T_rows, k, e, active, wt);
+  return hipGetLastError();
+}
+
+hipError_t launch_g_moe_accum(int dt, void* results, const void* y, const int32_t* active, const float* wt, int T_rows, int D,
+                              hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_moe_accum_kernel<T>), dim3(blocks_for((size_t)T_rows * D)), dim3(256), 0, s, (T*)results, (const T*)y,
+                                    active, wt, T_rows, D))
+}
+
+hipError_t launch_g_add(int dt, void* out, const void* a, const void* b, size_t n, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_add_kernel<T>), dim3(blocks_for(n)), dim3(256), 0, s, (T*)out, (const T*)a, (const T*)b, n))
+}
+
+hipError_t launch_g_zero(int dt, void* p, size_t n, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_zero_kernel<T>), dim3(blocks_for(n)), dim3(256), 0, s, (T*)p, n))
+}

@@ -298,3 +298,52 @@ void decode_engine_forget_census_moe();
 void decode_engine_set_trace_moe(void* dev_buffer);
 void decode_engine_set_knobs_moe(int thin, int depth);
 void decode_engine_set_holders_moe(int on);
+
+// ---------------------------------------------------------------------------------------------- generic storage dtype
+// generic.hip: the operator sequence of the hot path for fp32 / fp16 storage (and for bf16 shapes the tuned kernels
+// decline), every rounding point in the storage dtype as the reference executes it.  mi_forward_generic (api.hip).
+enum { G_DT_BF16 = 0, G_DT_FP16 = 1, G_DT_FP32 = 2 };
+enum { G_EPI_STORE = 0, G_EPI_RESIDUAL = 1, G_EPI_LOGITS = 2 };
+struct GLinearArgs {
+  const void* x;         // [M, K], row stride ldx
+  int ldx;
+  const void* w;         // [N, K] dense
+  void* out;             // [M, N] storage dtype (fp32 for G_EPI_LOGITS), row stride ldo
+  int ldo;
+  const void* residual;  // G_EPI_RESIDUAL: [M, N], row stride ldr (may alias out)
+  int ldr;
+  int M, N, K;
+  int epi;
+  const int32_t* active; // optional [M]: MoE row mask (nothing is done when no row of a tile is active)
+};
+struct GAttnArgs {
+  void* out;             // [T, H * Dh]
+  int ldo;
+  const void* qkv;       // [T, ld]: q | k | v after RoPE
+  int ld;
+  const void* cache_k;   // rings [max_batch, W, Hkv, Dh] (nullptr: cache=None call)
+  const void* cache_v;
+  int W, T, H, Hkv, Dh;
+  const int32_t* q_start;
+  const int32_t* kv_before;
+  const int32_t* tok_seq;
+  const int32_t* tok_pos;
+  int causal;            // 0: the cache=None call (every token sees every token, transformer_layers.py:165)
+  float scale;
+};
+size_t g_elem_bytes(int dt);
+hipError_t launch_g_embedding(int dt, void* out, const void* table, const int64_t* ids, int T, int D, int vocab, uint32_t* bad_id,
+                              hipStream_t s);
+hipError_t launch_g_rmsnorm(int dt, void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s);
+hipError_t launch_g_linear(int dt, const GLinearArgs& g, hipStream_t s);
+hipError_t launch_g_rope(int dt, void* qkv, int ld, int T, int n_rot_cols, int Dh, const float* rope_cs, const int32_t* tok_pos,
+                         hipStream_t s);
+hipError_t launch_g_kv_write(int dt, void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
+                             const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s);
+hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s);
+hipError_t launch_g_swiglu(int dt, void* a, const void* b, int T, int F, const int32_t* active, hipStream_t s);
+hipError_t launch_g_moe_topk(int dt, const void* logits, int T, int E, int k, int32_t* sel_idx, float* sel_w, hipStream_t s);
+hipError_t launch_g_moe_mask(const int32_t* sel_idx, const float* sel_w, int T, int k, int e, int32_t* active, float* wt, hipStream_t s);
+hipError_t launch_g_moe_accum(int dt, void* results, const void* y, const int32_t* active, const float* wt, int T, int D, hipStream_t s);
+hipError_t launch_g_add(int dt, void* out, const void* a, const void* b, size_t n, hipStream_t s);
+hipError_t launch_g_zero(int dt, void* p, size_t n, hipStream_t s);

@@ -21,10 +21,13 @@ def _default_lib() -> str:
 
 LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", _default_lib())
 
-MI_ABI_VERSION = 5
+MI_ABI_VERSION = 6
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
 BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
 GEMV_MAX_T = 8
+MI_ERR_SHAPE = -2
+# storage dtypes of mi_forward_generic (include/mistral_hip.h `enum mi_dtype`)
+DTYPE_CODES = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
 _vp = C.c_void_p
 
@@ -87,6 +90,8 @@ _SIGS = {
                                       C.c_size_t, _vp]),
     "mi_workspace_bytes": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int, C.c_int]),
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
+    "mi_workspace_bytes_generic": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int]),  # ABI v6
+    "mi_forward_generic": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), C.c_int, _vp]),
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_census": (C.c_int, [C.c_int]),
     "mi_decode_engine_reset": (C.c_int, [_vp, _vp]),

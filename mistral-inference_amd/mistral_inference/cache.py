@@ -268,8 +268,9 @@ class BufferCache:
         """ctypes arrays (host) of the per-layer ring pointers and sizes for mi_batch_t."""
         if self._ptr_tables is None:
             import ctypes as C
-            ks = _hip.ptr_array([_hip.dev_ptr(self.cache_k[i]) for i in range(self.n_layers)])
-            vs = _hip.ptr_array([_hip.dev_ptr(self.cache_v[i]) for i in range(self.n_layers)])
+            dt = self.cache_k[0].dtype  # (the model checks it against its own storage dtype: HipStackBackend.run_stack)
+            ks = _hip.ptr_array([_hip.dev_ptr(self.cache_k[i], dt) for i in range(self.n_layers)])
+            vs = _hip.ptr_array([_hip.dev_ptr(self.cache_v[i], dt) for i in range(self.n_layers)])
             ws = (C.c_int32 * self.n_layers)(*self.cache_sizes)
             self._ptr_tables = (ks, vs, ws)
         return self._ptr_tables

@@ -65,6 +65,15 @@ class GreedyBuffers:
     offset: int = 0           # added to the workspace's step counter: the session's draws start at Philox counter 1
 
 
+def tuned_kernels_take(a: TransformerArgs) -> bool:
+    """Shapes the bf16 kernels of `mi_forward` are built for (csrc/api.hip `check_model`); anything else runs on the
+    generic kernels (`mi_forward_generic`) instead of raising."""
+    E = a.moe.num_experts if a.moe is not None else 0
+    k = a.moe.num_experts_per_tok if a.moe is not None else 0
+    return (a.head_dim == 128 and a.n_heads % a.n_kv_heads == 0 and a.dim % 8 == 0 and a.hidden_dim % 8 == 0 and a.dim <= 16384
+            and E <= 16 and k in (0, 1, 2, 4) and (E == 0 or k * a.hidden_dim * 2 <= 65536))
+
+
 class HipStackBackend:
     """Runs the local layer stack through `mi_forward`.  The only backend shipped: the product has no
     CPU or eager path (tests may inject a different object to exercise host-side pipeline logic)."""
@@ -72,6 +81,8 @@ class HipStackBackend:
     def __init__(self) -> None:
         self._plan = None
         self._workspace: Optional[torch.Tensor] = None
+        self.generic = False   # set by _build_plan: this model runs through mi_forward_generic
+        self.dtype_code = 0
 
     # -- one-time: pointer tables of the weights -------------------------------------------------
     def _build_plan(self, model: "Transformer"):
@@ -79,11 +90,19 @@ class HipStackBackend:
         dev = model.device
         if dev.type != "cuda":
             raise RuntimeError(f"mistral_inference needs a HIP device (model is on {dev}); there is no CPU fallback")
-        if model.dtype != torch.bfloat16:
-            raise RuntimeError(f"the gfx950 kernels are bf16-storage only; model dtype is {model.dtype} "
-                               "(pass dtype=torch.bfloat16 to from_folder)")
+        dt = model.dtype
+        if dt not in _hip.DTYPE_CODES:
+            raise RuntimeError(f"storage dtype {dt}: the HIP kernels take bfloat16 (tuned path), float16 and float32 "
+                               "(generic path, csrc/generic.hip)")
+        if dt != torch.bfloat16 and model.vision_encoder is not None:
+            raise RuntimeError(f"the Pixtral vision tower runs on the bf16 kernels only; model dtype is {dt}")
+        # bf16 models of a shape the tuned kernels take go through mi_forward; everything else - fp16 / fp32 storage
+        # (reference transformer.py:303,338 keeps any dtype; its tests build fp32 models, tests/test_generate.py:51) and bf16
+        # shapes mi_forward declines with MI_ERR_SHAPE - through mi_forward_generic with the reference's rounding points
+        self.generic = dt != torch.bfloat16 or not tuned_kernels_take(a)
+        self.dtype_code = _hip.DTYPE_CODES[dt]
         keep = []  # python objects that own memory referenced by raw pointers
-        p = _hip.dev_ptr
+        p = lambda t, d=dt: _hip.dev_ptr(t, d)  # noqa: E731
         E = a.moe.num_experts if a.moe is not None else 0
         layers = (_hip.MiLayer * max(1, model.n_local_layers))()
         for j, blk in enumerate(model.layers.values()):
@@ -162,7 +181,7 @@ class HipStackBackend:
             HipStackBackend._engine_suspended = False
             _hip.check(_hip.lib().mi_decode_engine_census(1), "mi_decode_engine_census")
             _hip.set_decode_engine(True)
-        self._get_workspace(model, self.plan(model), 1, B, max(cache.cache_sizes))
+        self._get_workspace(model, self.plan(model), B, B, max(cache.cache_sizes))  # (a decode step has T == B rows)
 
     def session_disable_engine(self) -> None:
         """After a raised engine status: clear the word (it poisons the workspace) and take the launch path for the rest of this
@@ -172,7 +191,10 @@ class HipStackBackend:
         HipStackBackend._engine_suspended = True
 
     def _get_workspace(self, model: "Transformer", m, T: int, B: int, max_w: int) -> torch.Tensor:
-        need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
+        if self.generic:
+            need = _hip.lib().mi_workspace_bytes_generic(C.byref(m), T, self.dtype_code)
+        else:
+            need = _hip.lib().mi_workspace_bytes(C.byref(m), T, B, max_w)
         ws = self._workspace
         if ws is None or ws.numel() < need or ws.device != model.device:
             # grow geometrically; zero-filled because the first 4 KiB are split-KV arrival counters
@@ -194,12 +216,14 @@ class HipStackBackend:
         bt.tok_seq, bt.tok_pos = _hip.dev_ptr(meta.tok_seq, i32), _hip.dev_ptr(meta.tok_pos, i32)
         max_w = 1
         if cache is not None:
+            if cache.n_layers and cache.cache_k[0].dtype != model.dtype:
+                raise RuntimeError(f"cache dtype {cache.cache_k[0].dtype} != model dtype {model.dtype} (BufferCache.to(device, dtype))")
             ks, vs, ws = cache.pointer_tables()
             bt.cache_k, bt.cache_v = C.cast(ks, C.POINTER(C.c_void_p)), C.cast(vs, C.POINTER(C.c_void_p))
             bt.cache_sizes = C.cast(ws, C.POINTER(C.c_int32))
             bt.kv_seqlens = _hip.dev_ptr(cache.kv_seqlens, torch.long)
             max_w = max(cache.cache_sizes)
-        bt.h = _hip.dev_ptr(h)
+        bt.h = _hip.dev_ptr(h, model.dtype)
         bt.logits = _hip.dev_ptr(logits, torch.float32)
         if greedy is not None:  # ABI v4: sample fused behind the LM head (generate.py:124,134-136 at temperature 0)
             bt.greedy_token, bt.greedy_logprob = _hip.dev_ptr(greedy.tok, torch.long), _hip.dev_ptr(greedy.lp, torch.float32)
@@ -210,11 +234,14 @@ class HipStackBackend:
             bt.sample_offset = int(greedy.offset) & (2 ** 64 - 1)
         wsb = self._get_workspace(model, m, T, B, max_w)
         bt.workspace, bt.workspace_bytes = wsb.data_ptr(), wsb.numel()
-        _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
+        if self.generic:
+            _hip.check(_hip.lib().mi_forward_generic(C.byref(m), C.byref(bt), self.dtype_code, _hip.stream_ptr(h.device)),
+                       "mi_forward_generic")
+        else:
+            _hip.check(_hip.lib().mi_forward(C.byref(m), C.byref(bt), _hip.stream_ptr(h.device)), "mi_forward")
 
 
 class Transformer(ModelBase):
-    supports_prompt_logprobs = True
     greedy_session_pp = True  # generate(): the fused sampling session also runs across pipeline stages (GreedySession)
 
     def __init__(self, args: TransformerArgs, pipeline_rank: int = 0, num_pipeline_ranks: int = 1,
@@ -475,6 +502,18 @@ class Transformer(ModelBase):
                 and (st["graph"] is None or len(seqlens) == st["B"])):
             return self._graphed_step(input_ids, seqlens, cache, st)
         return self._logits(input_ids, seqlens, cache, images)
+
+    @property
+    def supports_prompt_logprobs(self) -> bool:
+        """generate() reduces a prompt chunk's logits inside the LM head GEMM (prompt_logprobs) on the tuned bf16 path; models
+        on the generic kernels return [T, vocab] logits from forward() and generate() takes its log-softmax."""
+        be = self._backend
+        if isinstance(be, HipStackBackend):
+            if self.device.type != "cuda":
+                return False
+            be.plan(self)
+            return not be.generic
+        return bool(getattr(be, "supports_prompt_logprobs", True))
 
     def prompt_logprobs(self, input_ids: torch.Tensor, seqlens: List[int], cache: Optional[BufferCache],
                         targets: torch.Tensor, images: Optional[List[torch.Tensor]] = None):

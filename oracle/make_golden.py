@@ -54,6 +54,13 @@ CASES = {
     "moe_bf16": (dict(moe=dict(num_experts=8, num_experts_per_tok=2)), "bfloat16",
                  [[1, 5, 9, 200, 17, 3, 44], [7, 300, 2]], 5, None),
     "rope_theta_fp32": (dict(rope_theta=10000.0), "float32", [[4, 3, 2, 1, 0, 9, 8, 7, 6, 5, 4, 3]], 4, None),
+    # fp16 storage (from_folder(dtype=torch.float16), reference transformer.py:303,338): replayed on the GPU through
+    # mi_forward_generic (tests/test_gpu_generic.py)
+    "dense_fp16": (dict(), "float16", [[1, 5, 9, 200, 17, 3, 44], [7, 300, 2], [11, 12, 13, 14, 15]], 6, None),
+    "swa_chunk_fp16": (dict(sliding_window=8), "float16",
+                       [[(3 * i + 1) % 512 for i in range(13)], [(7 * i + 2) % 512 for i in range(14)]], 5, 4),
+    "moe_fp16": (dict(moe=dict(num_experts=8, num_experts_per_tok=2)), "float16",
+                 [[1, 5, 9, 200, 17, 3, 44], [7, 300, 2]], 5, None),
     # oracle-only pins (index flag `oracle_only`: not part of the GPU replay list): head layouts and option
     # combinations the cases above do not reach
     "mha_fp32": (dict(n_kv_heads=4), "float32", [[1, 5, 9, 200, 17, 3, 44], [7, 300, 2]], 5, None),

@@ -81,6 +81,43 @@ def test_unsupported_shapes_fail_loudly_before_any_device_work():
     assert L.mi_attn_decode(1, 1, 128, 1, 1, 16, 1, 4, 2, 64, 1, 1, None) == -2   # head_dim 64
 
 
+def test_generic_entry_takes_what_mi_forward_declines():
+    """mi_forward_generic (ABI v6): the shapes above that are MI_ERR_SHAPE for the tuned kernels pass ITS validation (and
+    stop at the empty batch, MI_ERR_ARG); an unknown dtype code, an odd head_dim and top_k > num_experts are refused before any
+    device work.  The host-side predicate that routes a model (`tuned_kernels_take`) agrees with the library on every case."""
+    import ctypes as C
+    from mistral_inference import _hip
+    from mistral_inference.args import MoeArgs, TransformerArgs
+    from mistral_inference.transformer import tuned_kernels_take
+    L = _hip.lib()
+    layers = (_hip.MiLayer * 1)()
+    bt = _hip.MiBatch()
+
+    def both(dim=256, n_heads=4, n_kv_heads=2, head_dim=128, hidden_dim=512, E=0, k=0):
+        m = _hip.MiModel()
+        m.dim, m.n_heads, m.n_kv_heads, m.head_dim, m.hidden_dim, m.vocab_size, m.n_layers = dim, n_heads, n_kv_heads, head_dim, hidden_dim, 100, 1
+        m.num_experts, m.top_k = E, k
+        m.layers = C.cast(layers, C.POINTER(_hip.MiLayer))
+        a = TransformerArgs(dim=dim, n_layers=1, head_dim=head_dim, hidden_dim=hidden_dim, n_heads=n_heads, n_kv_heads=n_kv_heads,
+                            norm_eps=1e-5, vocab_size=100, moe=MoeArgs(num_experts=E, num_experts_per_tok=k) if E else None)
+        tuned = L.mi_forward(C.byref(m), C.byref(bt), None)
+        assert (tuned != _hip.MI_ERR_SHAPE) == tuned_kernels_take(a), (dim, n_heads, n_kv_heads, head_dim, hidden_dim, E, k)
+        return tuned, [L.mi_forward_generic(C.byref(m), C.byref(bt), d, None) for d in (0, 1, 2)], m
+
+    assert both()[:2] == (-1, [-1, -1, -1])
+    assert both(head_dim=64)[:2] == (-2, [-1, -1, -1])
+    assert both(head_dim=256, n_heads=2, n_kv_heads=1)[:2] == (-2, [-1, -1, -1])
+    assert both(E=32, k=2)[:2] == (-2, [-1, -1, -1])
+    assert both(E=8, k=3)[:2] == (-2, [-1, -1, -1])
+    assert both(E=8, k=2)[:2] == (-1, [-1, -1, -1])
+    assert both(head_dim=100)[:2] == (-2, [-2, -2, -2])            # not a multiple of 8
+    assert both(E=2, k=3)[1] == [-2, -2, -2] and b"top_k" in L.mi_last_error_detail()
+    m = both()[2]
+    assert L.mi_forward_generic(C.byref(m), C.byref(bt), 7, None) == -1 and b"dtype" in L.mi_last_error_detail()
+    assert L.mi_workspace_bytes_generic(C.byref(m), 16, 2) > L.mi_workspace_bytes_generic(C.byref(m), 16, 0) > 4096
+    assert L.mi_workspace_bytes_generic(None, 16, 0) == 0
+
+
 def test_header_is_c99_and_a_c_program_can_drive_the_library(tmp_path):
     """include/mistral_hip.h must be consumable from plain C (the boundary a cgo / JNI / ctypes shim binds): compile it
     with gcc -std=c99 -pedantic, then build examples/abi_probe.c and run it against the in-tree library (argument
