@@ -12,13 +12,16 @@
 //
 // These kernels are written for correctness and reasonable streaming behaviour, not for the roofline: BASELINE.json's
 // configurations are all bf16 and run on the tuned kernels (gemv_core.cuh, gemm256.hip, decode_engine.hip, ...).
-//   * linear, more than 8 rows: 64 x 64 output tile, K in slabs of 16 staged through LDS as fp32, 4 x 4 outputs per thread,
-//     one fp32 FMA chain per output in ascending k;
-//   * linear, up to 8 rows (decode): one wave per output column, 16-byte weight loads, lanes stride K, wave reduction;
-//   * attention: one block per (query token, head); a thread scores one key per 128-key sweep, online softmax across
-//     sweeps, a thread owns one (two) output dimension(s).  Keys older than this forward come from the ring at slot
+//   * linear, more than 8 rows: 128 x 128 tiles on the matrix cores (v_mfma_f32_32x32x16 f16 / bf16, v_mfma_f32_32x32x2 f32),
+//     operands staged through LDS in the storage type; rows that are not 16-byte aligned: a 64 x 64 fp32-FMA tile kernel;
+//   * linear, up to 8 rows (decode): one wave per two output columns, 16-byte weight loads (four in flight per lane), lanes
+//     stride K, wave reduction;
+//   * attention: one block per (query token, head); four waves split the visible keys, 64 lanes span the head dimension
+//     (coalesced K / V rows, score by wave reduction), per-wave online softmax merged at the end.  Keys older than this forward come from the ring at slot
 //     position % W, newer ones from the post-RoPE activation rows (same visibility rule as attn_prefill.hip), so the one
 //     kernel serves first prefills, later chunks, decode steps and the cache=None call.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -195,42 +198,208 @@ __global__ __launch_bounds__(256) void g_gemm_kernel(GLinearArgs g) {
   }
 }
 
-// M <= 8 rows, K a multiple of 8: one wave per output column.
+// ---- the same contraction on the matrix cores, for more than 8 rows with 16-byte-aligned rows (K % 8 == 0): 128 x 128
+// output tile per block, four waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32), K in slabs of 32 staged through LDS in the
+// STORAGE type (rows padded to 80 / 132 bytes: conflict-free 16-byte / 4-byte fragment reads); the next slab's global
+// loads are issued before the MFMAs of this one and written to LDS after them (single buffer, two barriers per slab).
+// fp16 / bf16: v_mfma_f32_32x32x16 (products of 16-bit values are exact in fp32, fp32 accumulate: what rocBLAS / torch do
+// for a half GEMM); fp32: v_mfma_f32_32x32x2_f32 (full fp32 products).  C[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col =
+// lane & 31] per 16-register accumulator, A-operand rows = tokens, B-operand rows = output features.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename T>
+struct Mf;
+template <>
+struct Mf<_Float16> {
+  static constexpr int KPI = 16;
+  typedef f16x8 frag;
+  static __device__ __forceinline__ frag ldf(const char* p) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p)); }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mf<sbf16> {
+  static constexpr int KPI = 16;
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ frag ldf(const char* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mf<float> {
+  static constexpr int KPI = 2;
+  typedef float frag;
+  static __device__ __forceinline__ frag ldf(const char* p) { return *reinterpret_cast<const float*>(p); }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void g_gemm_mfma_kernel(GLinearArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 32, ES = (int)sizeof(T);
+  constexpr int EPP = 16 / ES;                   // elements per 16-byte piece
+  constexpr int PPR = BK / EPP;                  // pieces per tile row: 4 (16-bit) / 8 (fp32)
+  constexpr int PPT = BM * PPR / 256;            // pieces per thread and tile: 2 / 4
+  constexpr int ROWB = BK * ES + (ES == 2 ? 16 : 4);
+  constexpr int KPL = Mf<T>::KPI / 2;            // k elements a lane supplies per MFMA: 8 / 1
+  __shared__ __attribute__((aligned(16))) char As[BM * ROWB];
+  __shared__ __attribute__((aligned(16))) char Ws[BN * ROWB];
+  __shared__ int any_active;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (g.active) {
+    if (tid == 0) any_active = 0;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M && g.active[m0 + tid]) any_active = 1;
+    __syncthreads();
+    if (!any_active) return;
+  }
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const T* w = reinterpret_cast<const T*>(g.w);
+  const T* asrc[PPT];
+  const T* wsrc[PPT];
+  int koff[PPT], loff[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int p = tid + 256 * j, row = p / PPR, pc = p % PPR;
+    koff[j] = pc * EPP;
+    loff[j] = row * ROWB + pc * 16;
+    asrc[j] = x + (size_t)min(m0 + row, g.M - 1) * g.ldx + koff[j];
+    wsrc[j] = w + (size_t)min(n0 + row, g.N - 1) * g.K + koff[j];
+  }
+  u32x4 ra[PPT], rw[PPT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const bool in = k0 + koff[j] < g.K;  // (K % 8 == 0: a piece is inside or outside as a whole)
+      const int kc = in ? k0 : 0;
+      ra[j] = ld16(asrc[j] + kc);
+      rw[j] = ld16(wsrc[j] + kc);
+      if (!in) {
+        ra[j] = u32x4{0u, 0u, 0u, 0u};
+        rw[j] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      if (ES == 2) {
+        st16(As + loff[j], ra[j]);
+        st16(Ws + loff[j], rw[j]);
+      } else {  // rows are 132 bytes apart: 4-byte stores
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          *reinterpret_cast<uint32_t*>(As + loff[j] + 4 * c) = ra[j][c];
+          *reinterpret_cast<uint32_t*>(Ws + loff[j] + 4 * c) = rw[j][c];
+        }
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const char* a_base = As + (wr * 64 + (lane & 31)) * ROWB + (lane >> 5) * KPL * ES;
+  const char* w_base = Ws + (wc * 64 + (lane & 31)) * ROWB + (lane >> 5) * KPL * ES;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    const bool more = k0 + BK < g.K;
+    if (more) gload(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / Mf<T>::KPI; ++ks) {
+      typename Mf<T>::frag af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = Mf<T>::ldf(a_base + i * 32 * ROWB + ks * Mf<T>::KPI * ES);
+        bf[i] = Mf<T>::ldf(w_base + i * 32 * ROWB + ks * Mf<T>::KPI * ES);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mf<T>::mma(af[i], bf[j], acc[i][j]);
+    }
+    __syncthreads();
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
+        if (n < g.N) g_store<T, EPI>(g, m, n, acc[i][j][r]);
+      }
+    }
+}
+
+// M <= 8 rows, K a multiple of 8: one wave per TWO output columns, two 512-element slabs of each weight row per iteration
+// (four independent 16-byte weight loads per lane in flight; the activation rows come out of L1 / L2).
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
+  constexpr int NC = 2;
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= g.N) return;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NC;
+  if (n0 >= g.N) return;
   if (g.active) {
     bool any = false;
     for (int m = 0; m < g.M; ++m) any = any || g.active[m] != 0;
     if (!any) return;
   }
   const T* x = reinterpret_cast<const T*>(g.x);
-  const T* wr = reinterpret_cast<const T*>(g.w) + (size_t)n * g.K;
-  float acc[8];
+  const T* wr[NC];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
-  for (int k = lane * 8; k < g.K; k += 64 * 8) {
-    float wv[8];
-    St<T>::ld8(wr + k, wv);
+  for (int c = 0; c < NC; ++c) wr[c] = reinterpret_cast<const T*>(g.w) + (size_t)min(n0 + c, g.N - 1) * g.K;
+  float acc[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[c][m] = 0.f;
+  for (int k = lane * 8; k < g.K; k += 2 * 512) {
+    const bool in1 = k + 512 < g.K;
+    const int k1 = in1 ? k + 512 : k;  // (clamped; its weights are zeroed)
+    float wv[NC][2][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      St<T>::ld8(wr[c] + k, wv[c][0]);
+      St<T>::ld8(wr[c] + k1, wv[c][1]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[c][1][i] = in1 ? wv[c][1][i] : 0.f;
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       if (m < g.M) {
-        float xv[8];
-        St<T>::ld8(x + (size_t)m * g.ldx + k, xv);
+        float x0[8], x1[8];
+        St<T>::ld8(x + (size_t)m * g.ldx + k, x0);
+        St<T>::ld8(x + (size_t)m * g.ldx + k1, x1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[m] = fmaf(xv[i], wv[i], acc[m]);
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[c][m] = fmaf(x0[i], wv[c][0][i], acc[c][m]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[c][m] = fmaf(x1[i], wv[c][1][i], acc[c][m]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    if (m < g.M) {
-      const float v = wave_sum_f(acc[m]);
-      if (lane == 0) g_store<T, EPI>(g, m, n, v);
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < g.M) {
+        const float v = wave_sum_f(acc[c][m]);
+        if (lane == 0 && n0 + c < g.N) g_store<T, EPI>(g, m, n0 + c, v);
+      }
     }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ RoPE
@@ -269,15 +438,59 @@ __global__ __launch_bounds__(256) void g_kv_write_kernel(T* ck, T* cv, int W, co
 }
 
 // ------------------------------------------------------------------------------------------------ attention
-// transformer_layers.py:74-89 for every branch.  Block = (query token, q head), 128 threads.
-template <typename T>
-__global__ __launch_bounds__(128) void g_attention_kernel(GAttnArgs a) {
-  __shared__ float qs[256];
-  __shared__ float ps[128];
-  __shared__ const T* kptr[128];
-  __shared__ const T* vptr[128];
-  __shared__ float red[2];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// transformer_layers.py:74-89 for every branch.  Block = (query token, q head), NW waves; wave w takes the visible keys in
+// groups of four - group w, w + NW, ... - the 64 lanes span the head dimension (EPL = head_dim / 64 adjacent elements per
+// lane: a K / V row is ONE coalesced load instruction; head dims that are not a multiple of 64: lane, lane + 64, ...
+// element by element), the score is a wave reduction, each wave keeps its own online-softmax state and the NW states are
+// merged through LDS at the end.  Two register sets of four K and four V rows are refilled in place (the next group's
+// loads are in flight while this one is reduced).  NW = 4 when the launch has many (token, head) blocks, 16 for the few
+// blocks of a decode step.
+template <int BYTES>
+struct RawN;
+template <>
+struct RawN<2> {
+  typedef uint16_t type;
+};
+template <>
+struct RawN<4> {
+  typedef uint32_t type;
+};
+template <>
+struct RawN<8> {
+  typedef u32x2 type;
+};
+template <>
+struct RawN<16> {
+  typedef u32x4 type;
+};
+
+// EPL > 0: lane's EPL adjacent elements of a row in one load; EPL == 0: elements lane + 64 i, i < 4, below Dh
+template <typename T, int EPL>
+__device__ __forceinline__ void g_row_load(const T* row, int lane, int Dh, float (&o)[EPL > 0 ? EPL : 4]) {
+  if constexpr (EPL > 0) {
+    typedef typename RawN<EPL * (int)sizeof(T)>::type raw_t;
+    const raw_t r = *reinterpret_cast<const raw_t*>(row + lane * EPL);
+    T tmp[EPL];
+    __builtin_memcpy(tmp, &r, sizeof(r));
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) o[i] = St<T>::ld(&tmp[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane + 64 * i;
+      o[i] = d < Dh ? St<T>::ld(row + d) : 0.f;
+    }
+  }
+}
+
+template <typename T, int EPL, int NW>
+__global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
+  constexpr int NI = EPL > 0 ? EPL : 4;  // elements per lane
+  constexpr int U = 4;                   // keys per group
+  __shared__ float sm_m[NW], sm_l[NW];
+  __shared__ float sm_acc[NW][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = blockIdx.x, h = blockIdx.y;
   const int Dh = a.Dh, kvh = h / (a.H / a.Hkv);
   const int nq = a.H * Dh, kv_dim = a.Hkv * Dh;
@@ -299,20 +512,28 @@ __global__ __launch_bounds__(128) void g_attention_kernel(GAttnArgs a) {
   const int n_old = min(p_b, W);
   const int kp_lo = a.causal ? max(p_b - n_old, qp - W + 1) : 0;
   const int kp_hi = qp;
-  for (int d = tid; d < Dh; d += 128) qs[d] = St<T>::ld(qkv + (size_t)t * a.ld + (size_t)h * Dh + d);
-  const T* ring_k = a.cache_k ? reinterpret_cast<const T*>(a.cache_k) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : nullptr;
-  const T* ring_v = a.cache_v ? reinterpret_cast<const T*>(a.cache_v) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : nullptr;
+  float q[NI], acc[NI];
+  g_row_load<T, EPL>(qkv + (size_t)t * a.ld + (size_t)h * Dh, lane, Dh, q);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const T* ring_k = a.cache_k ? reinterpret_cast<const T*>(a.cache_k) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : qkv;
+  const T* ring_v = a.cache_v ? reinterpret_cast<const T*>(a.cache_v) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : qkv;
   const T* act_k = qkv + nq + (size_t)kvh * Dh;
   const T* act_v = act_k + kv_dim;
-  float m_run = -INFINITY, l_run = 0.f, acc0 = 0.f, acc1 = 0.f;
-  __syncthreads();
-  for (int base = kp_lo; base <= kp_hi; base += 128) {
-    const int kp = base + tid;
-    const bool valid = kp <= kp_hi;
-    float s = -INFINITY;
-    if (valid) {
+  float m_run = -INFINITY, l_run = 0.f;
+  const int n_groups = (kp_hi - kp_lo + U) / U;                           // groups of U keys in the visible range
+  const int n_mine = wid < n_groups ? (n_groups - wid + NW - 1) / NW : 0;  // ... of which this wave takes every NW-th
+  struct Set {
+    float k[U][NI], v[U][NI];
+  };
+  Set A, B;
+  auto load = [&](Set& s, int it) {  // always 2 U row loads from clamped (valid) positions; masked in reduce
+    const int base = kp_lo + (wid + NW * it) * U;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kp = min(base + u, kp_hi);
       const T *kr, *vr;
-      if (kp < p_b) {
+      if (kp < p_b) {  // wave-uniform
         const size_t off = (size_t)(kp % W) * kv_dim;
         kr = ring_k + off;
         vr = ring_v + off;
@@ -321,44 +542,81 @@ __global__ __launch_bounds__(128) void g_attention_kernel(GAttnArgs a) {
         kr = act_k + off;
         vr = act_v + off;
       }
-      kptr[tid] = kr;
-      vptr[tid] = vr;
-      float dot = 0.f;
-      for (int d = 0; d < Dh; d += 8) {
-        float kv8[8];
-        St<T>::ld8(kr + d, kv8);
+      g_row_load<T, EPL>(kr, lane, Dh, s.k[u]);
+      g_row_load<T, EPL>(vr, lane, Dh, s.v[u]);
+    }
+  };
+  auto reduce = [&](const Set& s, int it) {
+    if (it >= n_mine) return;  // wave-uniform; (keeps an all-masked group away from m_run = -inf: exp(-inf + inf))
+    const int base = kp_lo + (wid + NW * it) * U;
+    float sc[U], mx = m_run;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dot = fmaf(qs[d + i], kv8[i], dot);
-      }
-      s = dot * a.scale;
+    for (int u = 0; u < U; ++u) {
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) part = fmaf(q[i], s.k[u][i], part);
+      const float sv = wave_sum_f(part) * a.scale;
+      sc[u] = (base + u <= kp_hi) ? sv : -INFINITY;
+      mx = fmaxf(mx, sc[u]);
     }
-    float mx = wave_max_f(s);
-    if (lane == 0) red[wv] = mx;
-    __syncthreads();
-    const float m_new = fmaxf(m_run, fmaxf(red[0], red[1]));
-    const float p = valid ? expf(s - m_new) : 0.f;
-    ps[tid] = p;
-    float sum = wave_sum_f(p);
-    __syncthreads();  // red[] read by everybody, ps / vptr written
-    if (lane == 0) red[wv] = sum;
-    __syncthreads();
-    const float alpha = expf(m_run - m_new);  // (first sweep: exp(-inf) = 0 against zero accumulators)
-    l_run = l_run * alpha + (red[0] + red[1]);
-    m_run = m_new;
-    const int cnt = min(128, kp_hi - base + 1);
-    acc0 *= alpha;
-    acc1 *= alpha;
-    if (tid < Dh) {
-      for (int j = 0; j < cnt; ++j) acc0 = fmaf(ps[j], St<T>::ld(vptr[j] + tid), acc0);
+    const float alpha = expf(m_run - mx);  // (first group: exp(-inf) = 0 against zero accumulators)
+    m_run = mx;
+    l_run *= alpha;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = expf(sc[u] - mx);  // masked key: exp(-inf) = 0
+      l_run += p;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] = fmaf(p, s.v[u][i], acc[i]);
     }
-    if (tid + 128 < Dh) {
-      for (int j = 0; j < cnt; ++j) acc1 = fmaf(ps[j], St<T>::ld(vptr[j] + tid + 128), acc1);
-    }
-    __syncthreads();  // before the next sweep overwrites ps / vptr / red
+  };
+  load(A, 0);
+  load(B, 1);
+  for (int it = 0; it < n_mine; it += 2) {
+    reduce(A, it);
+    load(A, it + 2);
+    reduce(B, it + 1);
+    load(B, it + 3);
   }
-  T* o = reinterpret_cast<T*>(a.out) + (size_t)t * a.ldo + (size_t)h * Dh;
-  if (tid < Dh) St<T>::st(o + tid, acc0 / l_run);
-  if (tid + 128 < Dh) St<T>::st(o + tid + 128, acc1 / l_run);
+  if (lane == 0) {
+    sm_m[wid] = m_run;
+    sm_l[wid] = l_run;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) sm_acc[wid][EPL > 0 ? lane * EPL + i : lane + 64 * i] = acc[i];
+  __syncthreads();
+  if (tid < Dh) {
+    float M = sm_m[0];  // finite: wave 0 always owns the group that starts at kp_lo
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, sm_m[w]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = expf(sm_m[w] - M);  // a wave without keys: exp(-inf) = 0
+      L = fmaf(sm_l[w], f, L);
+      o = fmaf(sm_acc[w][tid], f, o);
+    }
+    St<T>::st(reinterpret_cast<T*>(a.out) + (size_t)t * a.ldo + (size_t)h * Dh + tid, o / L);
+  }
+}
+
+template <typename T, int EPL>
+void attention_nw(const GAttnArgs& a, hipStream_t s) {
+  if ((long)a.T * a.H >= 1024) hipLaunchKernelGGL((g_attention_kernel<T, EPL, 4>), dim3(a.T, a.H), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((g_attention_kernel<T, EPL, 16>), dim3(a.T, a.H), dim3(1024), 0, s, a);
+}
+template <typename T>
+void attention_t(const GAttnArgs& a, hipStream_t s) {
+  // one load per row needs rows that start on a multiple of the lane's load width: every row offset here is a multiple of
+  // Dh elements, so Dh % 64 == 0 and 16-byte aligned bases are enough
+  const bool al = ((reinterpret_cast<size_t>(a.qkv) | reinterpret_cast<size_t>(a.cache_k) | reinterpret_cast<size_t>(a.cache_v)) & 15) == 0 &&
+                  a.ld % 8 == 0;
+  if (al && a.Dh == 64) attention_nw<T, 1>(a, s);
+  else if (al && a.Dh == 128) attention_nw<T, 2>(a, s);
+  else if (al && a.Dh == 256) attention_nw<T, 4>(a, s);
+  else attention_nw<T, 0>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------ SwiGLU
@@ -450,8 +708,16 @@ __global__ __launch_bounds__(256) void g_zero_kernel(T* p, size_t n) {
 
 template <typename T, int EPI>
 hipError_t linear_t(const GLinearArgs& g, hipStream_t s) {
-  if (g.M <= 8 && g.K % 8 == 0 && g.ldx % 8 == 0) {
-    hipLaunchKernelGGL((g_gemv_kernel<T, EPI>), dim3((g.N + 3) / 4), dim3(256), 0, s, g);
+  static int use_mfma = -1;  // MI_GENERIC_MFMA=0: every multi-row contraction on the fp32-FMA tile kernel (A/B, tests)
+  if (use_mfma < 0) {
+    const char* e = getenv("MI_GENERIC_MFMA");
+    use_mfma = e ? atoi(e) : 1;
+  }
+  const bool aligned = g.K % 8 == 0 && g.ldx % 8 == 0 && (reinterpret_cast<size_t>(g.x) & 15) == 0 && (reinterpret_cast<size_t>(g.w) & 15) == 0;
+  if (g.M <= 8 && aligned) {
+    hipLaunchKernelGGL((g_gemv_kernel<T, EPI>), dim3((g.N + 7) / 8), dim3(256), 0, s, g);
+  } else if (aligned && use_mfma) {
+    hipLaunchKernelGGL((g_gemm_mfma_kernel<T, EPI>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
   } else {
     hipLaunchKernelGGL((g_gemm_kernel<T, EPI>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, s, g);
   }
@@ -514,8 +780,8 @@ hipError_t launch_g_kv_write(int dt, void* ck, void* cv, int W, const void* k, c
 }
 
 hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s) {
-  if (a.Dh > 256 || a.Dh % 8 || a.H % a.Hkv) return hipErrorInvalidValue;
-  G_DISPATCH(dt, hipLaunchKernelGGL((g_attention_kernel<T>), dim3(a.T, a.H), dim3(128), 0, s, a))
+  if (a.Dh > 256 || a.H % a.Hkv) return hipErrorInvalidValue;
+  G_DISPATCH(dt, attention_t<T>(a, s))
 }
 
 hipError_t launch_g_swiglu(int dt, void* a, const void* b, int T_rows, int F, const int32_t* active, hipStream_t s) {

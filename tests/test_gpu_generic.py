@@ -3,7 +3,7 @@
 The reference keeps whatever dtype `from_folder(dtype=...)` / `.to(dtype=...)` asks for (transformer.py:303,338) and its own
 tests run fp32 models (tests/test_generate.py:51,100).  Parity here is against
   (a) the outputs of the UNMODIFIED reference stored in tests/golden - every fp32 schedule (ragged prefill, sliding window,
-      chunks, per-layer windows, MoE, decode) and three fp16 schedules - replayed in the case's OWN dtype: fp32 within 2e-4
+      chunks, per-layer windows, MoE, decode) and three fp16 schedules - replayed in the case's OWN dtype: fp32 within 2e-5
       max-abs (no rounding anywhere: what is left is fp32 summation order), fp16 within a few fp16 spacings;
   (b) the CPU oracle in the same dtype;
   (c) the reference's own self-consistency tests (prefill log-probabilities == decode log-probabilities within 5e-4 in fp32,
@@ -108,7 +108,7 @@ def test_golden_schedules_in_their_own_dtype(name, tmp_path):
     keep = _unambiguous_rows(case, trace, [g.shape[0] for g in pre + dec], schedule, gap)
     # fp32: summation order only.  fp16: logits are fp16 VALUES (|x| < 4 here: spacing 2^-9 .. 2^-8); two correct fp16
     # implementations differ by a spacing or two wherever an fp32 sum lands near a rounding boundary, layer after layer.
-    atol = 2e-4 if dtype == F32 else 1.2e-2
+    atol = 2e-5 if dtype == F32 else 5e-3   # measured: 1.8e-6 / 2.0e-3 (two fp16 spacings below 4)
     worst_ref, worst_orc, n_rows, tot_rows, exact, elems = 0.0, 0.0, 0, 0, 0, 0
     for f, (got, ref, orc) in enumerate(zip(pre + dec, refs, o_pre + o_dec)):
         assert got.shape == ref.shape and got.dtype == torch.float32
@@ -127,7 +127,7 @@ def test_golden_schedules_in_their_own_dtype(name, tmp_path):
     assert worst_ref <= atol, (name, "vs the reference's stored logits", worst_ref)
     assert worst_orc <= atol, (name, "vs the oracle", worst_orc)
     if dtype == F16:
-        assert exact >= 0.5 * elems, (name, "bit-equal fraction", exact / elems)
+        assert exact >= 0.4 * elems, (name, "bit-equal fraction", exact / elems)  # measured 0.52 .. 0.86
 
 
 @pytest.mark.parametrize("dtype", [F32, F16])
@@ -179,10 +179,11 @@ def test_reference_selfconsistency_fp32(tmp_path):
 
 @pytest.mark.parametrize("over,dtype", [
     (dict(head_dim=64, n_heads=4, n_kv_heads=2), BF),                             # head_dim the MFMA attention is not built for
-    (dict(head_dim=256, n_heads=2, n_kv_heads=1, dim=512), BF),                   # two output dims per attention thread
+    (dict(head_dim=256, n_heads=2, n_kv_heads=1, dim=512), BF),                   # four elements per attention lane
+    (dict(head_dim=96, n_heads=4, n_kv_heads=4), F16),                            # not a multiple of 64: element-wise row loads
     (dict(moe=dict(num_experts=8, num_experts_per_tok=3)), BF),                   # top_k = 3
     (dict(moe=dict(num_experts=32, num_experts_per_tok=2), hidden_dim=256), F32),  # more than 16 experts (fp32: in bf16 every
-], ids=["head_dim_64", "head_dim_256", "moe_top3", "moe_32_experts"])             # sequence meets a router near-tie at once)
+], ids=["head_dim_64", "head_dim_256", "head_dim_96_fp16", "moe_top3", "moe_32_experts"])  # sequence meets a router near-tie at once)
 def test_shapes_the_tuned_kernels_decline(over, dtype, tmp_path):
     """Models `mi_forward` answers with MI_ERR_SHAPE run on the generic kernels instead of raising: ragged prefill + decode
     steps against the oracle in the same dtype (bf16: same bound as the tuned path's golden replays, tests/test_gpu_model.py)."""
@@ -214,7 +215,25 @@ def test_shapes_the_tuned_kernels_decline(over, dtype, tmp_path):
             worst = max(worst, (got[keep[f]] - orc[keep[f]]).abs().max().item())
             n += len(keep[f])
     assert n >= 0.5 * sum(sum(s) for s in schedule)
-    assert worst <= (4e-2 if dtype == BF else 2e-4), worst
+    assert worst <= {BF: 4e-2, F16: 5e-3, F32: 2e-5}[dtype], worst
+
+
+@pytest.mark.parametrize("dtype", [F32, F16])
+def test_long_ragged_prompt_in_chunks(dtype, tmp_path):
+    """Enough (token, head) blocks for the 4-wave attention launch (the short schedules above all take the 16-wave one), a
+    64-slot window that the 300-token prompt wraps several times, a second chunk that reads the ring, contractions of
+    400 and 150 rows (m-tiles of the MFMA kernel, ragged), then decode steps - against the oracle in the same dtype."""
+    args = mo.OracleArgs(dim=256, n_layers=2, head_dim=128, hidden_dim=512, n_heads=8, n_kv_heads=2, norm_eps=1e-5, vocab_size=512,
+                         sliding_window=64)
+    w = {k: v.to(dtype) for k, v in mo.synth_weights(args, seed=5, dtype=BF).items()}
+    model = _load(tmp_path, args, w, dtype)
+    prompts = [[(3 * i + 1) % 512 for i in range(300)], [(7 * i + 2) % 512 for i in range(250)]]
+    toks = [[(11 * s + b) % 512 for s in range(3)] for b in range(2)]
+    pre, dec = _replay(model, prompts, toks, 200, 3, dtype)
+    o_pre, o_dec = _replay_oracle(args, w, prompts, toks, 200, 3, 4, dtype)
+    worst = max((g - o).abs().max().item() for g, o in zip(pre + dec, o_pre + o_dec))
+    assert all(torch.isfinite(g).all() for g in pre + dec)
+    assert worst <= (2e-5 if dtype == F32 else 5e-3), worst
 
 
 def test_nocache_call_fp32(tmp_path):
@@ -243,3 +262,17 @@ def test_sampling_session_fp32_matches_unfused_loop(tmp_path):
     assert max(abs(x - y) for a, b in zip(lps, lps2) for x, y in zip(a, b)) <= 1e-5
     o_toks, _ = mo.generate(prompts, mo.OracleModel(args, w), max_tokens=12, max_batch_size=4)
     assert toks == o_toks
+
+
+def test_fma_tile_kernel_on_the_same_schedules():
+    """MI_GENERIC_MFMA=0 sends every multi-row contraction to the 64 x 64 fp32-FMA tile kernel (what rows that are not 16-byte
+    aligned take): one dense and one MoE golden schedule per dtype in a process of their own."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MI_GENERIC_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_generic.py"), "-q", "-x", "-k",
+                        "own_dtype and (dense_fp32 or dense_fp16 or moe_fp32 or moe_fp16)"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(here))
+    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
