@@ -813,7 +813,7 @@ struct GWorkspace {
   uint32_t* ctrl;
   char *xn, *qkv, *attn, *a, *b, *y, *res, *glog;
   int32_t *sel_idx, *active;
-  float *sel_w, *wt;
+  float *sel_w, *wt, *attn_partial;
   size_t total;
 };
 
@@ -840,6 +840,7 @@ GWorkspace carve_generic(const mi_model_t* m, int T, size_t es, char* base) {
   w.sel_w = (float*)take(moe ? (size_t)T * m->top_k * 4 : 0);
   w.active = (int32_t*)take(moe ? (size_t)T * 4 : 0);
   w.wt = (float*)take(moe ? (size_t)T * 4 : 0);
+  w.attn_partial = (float*)take(g_attn_partial_floats(T, m->n_heads, m->head_dim) * sizeof(float));
   w.total = off;
   return w;
 }
@@ -899,6 +900,9 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     g.M = T; g.N = N; g.K = K; g.epi = epi; g.active = active;
     return hip_rc(launch_g_linear(dt, g, s), what);
   };
+  // T <= 8 (decode steps, tiny prompts): the row kernel's fused forms - RMSNorm in the prologue, q | k | v in one launch,
+  // gate / up / SiLU / product in one launch: 8 launches per dense layer instead of 13
+  const bool rows = g_gemv_takes(T, D, D);
 
   if (branch == MI_BRANCH_DECODE)
     MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, ws.ctrl, s), "decode_prep"));
@@ -911,10 +915,18 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     void* ck = has_cache ? bt->cache_k[l] : nullptr;
     void* cv = has_cache ? bt->cache_v[l] : nullptr;
     // ---- attention_norm, q | k | v, RoPE (transformer_layers.py:66-70)
-    MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.attention_norm, T, D, m->norm_eps, s), "attention_norm"));
-    MI_TRY(linear(ws.xn, D, L.wq, ws.qkv, qkv_cols, nq, D, G_EPI_STORE, nullptr, nullptr, "wq"));
-    MI_TRY(linear(ws.xn, D, L.wk, ws.qkv + (size_t)nq * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wk"));
-    MI_TRY(linear(ws.xn, D, L.wv, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wv"));
+    if (rows) {
+      GLinearArgs g;
+      memset(&g, 0, sizeof(g));
+      g.x = h; g.ldx = D; g.w = L.wq; g.w1 = L.wk; g.w2 = L.wv; g.n0 = nq; g.n1 = nq + nkv; g.norm_w = L.attention_norm; g.eps = m->norm_eps;
+      g.out = ws.qkv; g.ldo = qkv_cols; g.M = T; g.N = qkv_cols; g.K = D; g.epi = G_EPI_STORE;
+      MI_TRY(hip_rc(launch_g_linear(dt, g, s), "norm + q|k|v"));
+    } else {
+      MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.attention_norm, T, D, m->norm_eps, s), "attention_norm"));
+      MI_TRY(linear(ws.xn, D, L.wq, ws.qkv, qkv_cols, nq, D, G_EPI_STORE, nullptr, nullptr, "wq"));
+      MI_TRY(linear(ws.xn, D, L.wk, ws.qkv + (size_t)nq * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wk"));
+      MI_TRY(linear(ws.xn, D, L.wv, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wv"));
+    }
     MI_TRY(hip_rc(launch_g_rope(dt, ws.qkv, qkv_cols, T, nq + nkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
     // ---- attention over [surviving ring entries ++ this forward's keys], then the ring write (cache.py:83-117)
     GAttnArgs a;
@@ -924,6 +936,7 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     a.q_start = bt->q_start; a.kv_before = bt->kv_before; a.tok_seq = bt->tok_seq; a.tok_pos = bt->tok_pos;
     a.causal = has_cache ? 1 : 0;
     a.scale = 1.0f / sqrtf((float)Dh);
+    a.partial = ws.attn_partial;
     MI_TRY(hip_rc(launch_g_attention(dt, a, s), "attention"));
     if (has_cache)
       MI_TRY(hip_rc(launch_g_kv_write(dt, ck, cv, W, ws.qkv + (size_t)nq * es, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, T, nkv,
@@ -931,14 +944,23 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     // ---- h = h + wo(attn)
     MI_TRY(linear(ws.attn, nq, L.wo, h, D, D, nq, G_EPI_RESIDUAL, h, nullptr, "wo"));
     // ---- h = h + FFN(ffn_norm(h))
-    MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
     if (m->num_experts == 0) {
       if (!L.w1 || !L.w2 || !L.w3) return fail(MI_ERR_ARG, "mi_forward_generic: dense layer without w1/w2/w3");
-      MI_TRY(linear(ws.xn, D, L.w1, ws.a, F, F, D, G_EPI_STORE, nullptr, nullptr, "w1"));
-      MI_TRY(linear(ws.xn, D, L.w3, ws.b, F, F, D, G_EPI_STORE, nullptr, nullptr, "w3"));
-      MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, nullptr, s), "swiglu"));
+      if (rows) {
+        GLinearArgs g;
+        memset(&g, 0, sizeof(g));
+        g.x = h; g.ldx = D; g.w = L.w1; g.w1 = L.w3; g.norm_w = L.ffn_norm; g.eps = m->norm_eps;
+        g.out = ws.a; g.ldo = F; g.M = T; g.N = F; g.K = D; g.epi = G_EPI_SWIGLU;
+        MI_TRY(hip_rc(launch_g_linear(dt, g, s), "norm + w1|w3 + swiglu"));
+      } else {
+        MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
+        MI_TRY(linear(ws.xn, D, L.w1, ws.a, F, F, D, G_EPI_STORE, nullptr, nullptr, "w1"));
+        MI_TRY(linear(ws.xn, D, L.w3, ws.b, F, F, D, G_EPI_STORE, nullptr, nullptr, "w3"));
+        MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, nullptr, s), "swiglu"));
+      }
       MI_TRY(linear(ws.a, F, L.w2, h, D, D, F, G_EPI_RESIDUAL, h, nullptr, "w2"));
     } else {
+      MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
       // moe.py:24-32: experts in ascending id, each adding round(weight * expert(x)) for the rows that picked it
       const int E = m->num_experts, k = m->top_k;
       if (!L.gate || !L.expert_w_host) return fail(MI_ERR_ARG, "mi_forward_generic: MoE layer tables");
@@ -962,8 +984,16 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
 
   if (m->final_norm) {
     if (bt->logits) {
-      MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
-      MI_TRY(linear(ws.xn, D, m->output, bt->logits, m->vocab_size, m->vocab_size, D, G_EPI_LOGITS, nullptr, nullptr, "lm head"));
+      if (rows) {
+        GLinearArgs g;
+        memset(&g, 0, sizeof(g));
+        g.x = h; g.ldx = D; g.w = m->output; g.norm_w = m->final_norm; g.eps = m->norm_eps;
+        g.out = bt->logits; g.ldo = m->vocab_size; g.M = T; g.N = m->vocab_size; g.K = D; g.epi = G_EPI_LOGITS;
+        MI_TRY(hip_rc(launch_g_linear(dt, g, s), "final norm + lm head"));
+      } else {
+        MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        MI_TRY(linear(ws.xn, D, m->output, bt->logits, m->vocab_size, m->vocab_size, D, G_EPI_LOGITS, nullptr, nullptr, "lm head"));
+      }
       if (want_sample) {
         if (want_topp)
           MI_TRY(hip_rc(launch_sample_top_p(bt->logits, m->vocab_size, B, m->vocab_size, bt->sample_temperature, bt->sample_top_p,

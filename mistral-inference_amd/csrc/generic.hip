@@ -342,13 +342,26 @@ __global__ __launch_bounds__(256) void g_gemm_mfma_kernel(GLinearArgs g) {
     }
 }
 
-// M <= 8 rows, K a multiple of 8: one wave per TWO output columns, two 512-element slabs of each weight row per iteration
-// (four independent 16-byte weight loads per lane in flight; the activation rows come out of L1 / L2).
+// M <= 8 rows, K a multiple of 8: one wave per TWO weight rows - two adjacent output columns, or (SwiGLU) the gate and the up
+// row of ONE output column -, two 512-element slabs of each row per iteration (four independent 16-byte weight loads per lane
+// in flight; the activation rows come out of L1 / L2).  Optional prologue: RMSNorm of the rows (transformer_layers.py:115-120,
+// every wave recomputes the 1 / rms of its M rows - 8 KB of L1-resident reads against 16+ KB of streamed weights), which
+// removes a launch and a round trip of the normalised row per contraction.  Output columns may come from up to three weight
+// matrices (q | k | v in one launch).
+template <typename T>
+__device__ __forceinline__ const T* g_seg_row(const GLinearArgs& g, int n) {
+  if (!g.w1 || n < g.n0) return reinterpret_cast<const T*>(g.w) + (size_t)n * g.K;
+  if (!g.w2 || n < g.n1) return reinterpret_cast<const T*>(g.w1) + (size_t)(n - g.n0) * g.K;
+  return reinterpret_cast<const T*>(g.w2) + (size_t)(n - g.n1) * g.K;
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
   constexpr int NC = 2;
+  constexpr bool SW = EPI == G_EPI_SWIGLU;
   const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NC;
+  const int wv_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n0 = SW ? wv_id : wv_id * NC;
   if (n0 >= g.N) return;
   if (g.active) {
     bool any = false;
@@ -356,9 +369,34 @@ __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
     if (!any) return;
   }
   const T* x = reinterpret_cast<const T*>(g.x);
+  const T* nw = reinterpret_cast<const T*>(g.norm_w);
   const T* wr[NC];
+  if (SW) {
+    wr[0] = reinterpret_cast<const T*>(g.w) + (size_t)n0 * g.K;
+    wr[1] = reinterpret_cast<const T*>(g.w1) + (size_t)n0 * g.K;
+  } else {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) wr[c] = reinterpret_cast<const T*>(g.w) + (size_t)min(n0 + c, g.N - 1) * g.K;
+    for (int c = 0; c < NC; ++c) wr[c] = g_seg_row<T>(g, min(n0 + c, g.N - 1));
+  }
+  float inv[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) inv[m] = 1.f;
+  if (nw) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < g.M) {
+        float ss = 0.f;
+        for (int k = lane * 8; k < g.K; k += 512) {
+          float xv[8];
+          St<T>::ld8(x + (size_t)m * g.ldx + k, xv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ss = fmaf(xv[i], xv[i], ss);
+        }
+        ss = wave_sum_f(ss);
+        inv[m] = 1.0f / sqrtf(ss / (float)g.K + g.eps);
+      }
+    }
+  }
   float acc[NC][8];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -375,12 +413,24 @@ __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) wv[c][1][i] = in1 ? wv[c][1][i] : 0.f;
     }
+    float n0v[8], n1v[8];
+    if (nw) {
+      St<T>::ld8(nw + k, n0v);
+      St<T>::ld8(nw + k1, n1v);
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       if (m < g.M) {
         float x0[8], x1[8];
         St<T>::ld8(x + (size_t)m * g.ldx + k, x0);
         St<T>::ld8(x + (size_t)m * g.ldx + k1, x1);
+        if (nw) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            x0[i] = St<T>::rnd(St<T>::rnd(x0[i] * inv[m]) * n0v[i]);
+            x1[i] = St<T>::rnd(St<T>::rnd(x1[i] * inv[m]) * n1v[i]);
+          }
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -392,14 +442,21 @@ __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
     }
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < g.M) {
-        const float v = wave_sum_f(acc[c][m]);
-        if (lane == 0 && n0 + c < g.N) g_store<T, EPI>(g, m, n0 + c, v);
+  for (int m = 0; m < 8; ++m) {
+    if (m < g.M) {
+      const float v0 = wave_sum_f(acc[0][m]), v1 = wave_sum_f(acc[1][m]);
+      if (lane == 0) {
+        if (SW) {  // transformer_layers.py:106: silu(w1 x) * w3 x, every intermediate rounded to T
+          const float a = St<T>::rnd(v0), b = St<T>::rnd(v1);
+          const float sl = St<T>::rnd(a / (1.0f + expf(-a)));
+          St<T>::st(reinterpret_cast<T*>(g.out) + (size_t)m * g.ldo + n0, sl * b);
+        } else {
+          g_store<T, EPI>(g, m, n0, v0);
+          if (n0 + 1 < g.N) g_store<T, EPI>(g, m, n0 + 1, v1);
+        }
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ RoPE
@@ -483,7 +540,7 @@ __device__ __forceinline__ void g_row_load(const T* row, int lane, int Dh, float
   }
 }
 
-template <typename T, int EPL, int NW>
+template <typename T, int EPL, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
   constexpr int NI = EPL > 0 ? EPL : 4;  // elements per lane
   constexpr int U = 4;                   // keys per group
@@ -521,14 +578,17 @@ __global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
   const T* act_k = qkv + nq + (size_t)kvh * Dh;
   const T* act_v = act_k + kv_dim;
   float m_run = -INFINITY, l_run = 0.f;
-  const int n_groups = (kp_hi - kp_lo + U) / U;                           // groups of U keys in the visible range
-  const int n_mine = wid < n_groups ? (n_groups - wid + NW - 1) / NW : 0;  // ... of which this wave takes every NW-th
+  const int n_groups = (kp_hi - kp_lo + U) / U;  // groups of U keys in the visible range
+  // ... of which this wave takes every GS-th: GS = waves of the block x key splits of the launch (SPLIT: gridDim.z blocks
+  // per (token, head), each leaving an un-normalised partial for g_attention_combine_kernel)
+  const int gw = (SPLIT ? (int)blockIdx.z * NW : 0) + wid, GS = (SPLIT ? (int)gridDim.z : 1) * NW;
+  const int n_mine = gw < n_groups ? (n_groups - gw + GS - 1) / GS : 0;
   struct Set {
     float k[U][NI], v[U][NI];
   };
   Set A, B;
   auto load = [&](Set& s, int it) {  // always 2 U row loads from clamped (valid) positions; masked in reduce
-    const int base = kp_lo + (wid + NW * it) * U;
+    const int base = kp_lo + (gw + GS * it) * U;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kp = min(base + u, kp_hi);
@@ -548,7 +608,7 @@ __global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
   };
   auto reduce = [&](const Set& s, int it) {
     if (it >= n_mine) return;  // wave-uniform; (keeps an all-masked group away from m_run = -inf: exp(-inf + inf))
-    const int base = kp_lo + (wid + NW * it) * U;
+    const int base = kp_lo + (gw + GS * it) * U;
     float sc[U], mx = m_run;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -588,24 +648,66 @@ __global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
   for (int i = 0; i < NI; ++i) sm_acc[wid][EPL > 0 ? lane * EPL + i : lane + 64 * i] = acc[i];
   __syncthreads();
   if (tid < Dh) {
-    float M = sm_m[0];  // finite: wave 0 always owns the group that starts at kp_lo
+    float M = sm_m[0];  // (unsplit: finite - wave 0 always owns the group that starts at kp_lo)
 #pragma unroll
     for (int w = 1; w < NW; ++w) M = fmaxf(M, sm_m[w]);
     float L = 0.f, o = 0.f;
+    if (M > -INFINITY) {  // (a split block whose waves found no keys: exp(-inf + inf) must not be formed)
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float f = expf(sm_m[w] - M);  // a wave without keys: exp(-inf) = 0
-      L = fmaf(sm_l[w], f, L);
-      o = fmaf(sm_acc[w][tid], f, o);
+      for (int w = 0; w < NW; ++w) {
+        const float f = expf(sm_m[w] - M);  // a wave without keys: exp(-inf) = 0
+        L = fmaf(sm_l[w], f, L);
+        o = fmaf(sm_acc[w][tid], f, o);
+      }
     }
-    St<T>::st(reinterpret_cast<T*>(a.out) + (size_t)t * a.ldo + (size_t)h * Dh + tid, o / L);
+    if (SPLIT) {  // partial of this key split: [Dh] un-normalised outputs, then (max, sum)
+      float* pp = a.partial + (((size_t)t * a.H + h) * gridDim.z + blockIdx.z) * (Dh + 2);
+      pp[tid] = o;
+      if (tid == 0) {
+        pp[Dh] = M;
+        pp[Dh + 1] = L;
+      }
+    } else {
+      St<T>::st(reinterpret_cast<T*>(a.out) + (size_t)t * a.ldo + (size_t)h * Dh + tid, o / L);
+    }
   }
 }
 
+// merge of the key splits of one (token, head): the same max / rescale / sum as the in-block merge above
+template <typename T>
+__global__ __launch_bounds__(256) void g_attention_combine_kernel(GAttnArgs a, int S) {
+  const int tid = threadIdx.x, t = blockIdx.x, h = blockIdx.y, Dh = a.Dh;
+  if (tid >= Dh) return;
+  const float* pp = a.partial + (((size_t)t * a.H + h) * S) * (Dh + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < S; ++s) M = fmaxf(M, pp[(size_t)s * (Dh + 2) + Dh]);
+  float L = 0.f, o = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float f = expf(pp[(size_t)s * (Dh + 2) + Dh] - M);  // (split 0 always holds the key kp_lo: M is finite)
+    L = fmaf(pp[(size_t)s * (Dh + 2) + Dh + 1], f, L);
+    o = fmaf(pp[(size_t)s * (Dh + 2) + tid], f, o);
+  }
+  St<T>::st(reinterpret_cast<T*>(a.out) + (size_t)t * a.ldo + (size_t)h * Dh + tid, o / L);
+}
+
+constexpr int G_ATTN_SPLIT_BELOW = 256;  // (token, head) pairs under which the keys are also split over blocks
+constexpr int G_ATTN_MAX_SPLITS = 16;
+
 template <typename T, int EPL>
 void attention_nw(const GAttnArgs& a, hipStream_t s) {
-  if ((long)a.T * a.H >= 1024) hipLaunchKernelGGL((g_attention_kernel<T, EPL, 4>), dim3(a.T, a.H), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((g_attention_kernel<T, EPL, 16>), dim3(a.T, a.H), dim3(1024), 0, s, a);
+  const long pairs = (long)a.T * a.H;
+  if (pairs >= 1024) {
+    hipLaunchKernelGGL((g_attention_kernel<T, EPL, 4, false>), dim3(a.T, a.H), dim3(256), 0, s, a);
+  } else if (pairs >= G_ATTN_SPLIT_BELOW || !a.partial) {
+    hipLaunchKernelGGL((g_attention_kernel<T, EPL, 16, false>), dim3(a.T, a.H), dim3(1024), 0, s, a);
+  } else {
+    // a decode step: 32 (token, head) pairs would leave 7/8 of the chip idle and every wave with a long chain of dependent
+    // round trips - split the keys over enough blocks to cover the CUs, merge in a second tiny launch
+    int S = (int)((2 * G_ATTN_SPLIT_BELOW + pairs - 1) / pairs);
+    S = S > G_ATTN_MAX_SPLITS ? G_ATTN_MAX_SPLITS : S;
+    hipLaunchKernelGGL((g_attention_kernel<T, EPL, 4, true>), dim3(a.T, a.H, S), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((g_attention_combine_kernel<T>), dim3(a.T, a.H), dim3(256), 0, s, a, S);
+  }
 }
 template <typename T>
 void attention_t(const GAttnArgs& a, hipStream_t s) {
@@ -714,8 +816,13 @@ hipError_t linear_t(const GLinearArgs& g, hipStream_t s) {
     use_mfma = e ? atoi(e) : 1;
   }
   const bool aligned = g.K % 8 == 0 && g.ldx % 8 == 0 && (reinterpret_cast<size_t>(g.x) & 15) == 0 && (reinterpret_cast<size_t>(g.w) & 15) == 0;
+  const bool special = g.w1 || g.w2 || g.norm_w || EPI == G_EPI_SWIGLU;  // forms of the M <= 8 kernel only
   if (g.M <= 8 && aligned) {
-    hipLaunchKernelGGL((g_gemv_kernel<T, EPI>), dim3((g.N + 7) / 8), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((g_gemv_kernel<T, EPI>), dim3(EPI == G_EPI_SWIGLU ? (g.N + 3) / 4 : (g.N + 7) / 8), dim3(256), 0, s, g);
+  } else if (special) {
+    return hipErrorInvalidValue;
+  } else if constexpr (EPI == G_EPI_SWIGLU) {
+    return hipErrorInvalidValue;
   } else if (aligned && use_mfma) {
     hipLaunchKernelGGL((g_gemm_mfma_kernel<T, EPI>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
   } else {
@@ -729,6 +836,7 @@ hipError_t linear_e(const GLinearArgs& g, hipStream_t s) {
     case G_EPI_STORE: return linear_t<T, G_EPI_STORE>(g, s);
     case G_EPI_RESIDUAL: return linear_t<T, G_EPI_RESIDUAL>(g, s);
     case G_EPI_LOGITS: return linear_t<T, G_EPI_LOGITS>(g, s);
+    case G_EPI_SWIGLU: return linear_t<T, G_EPI_SWIGLU>(g, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -747,6 +855,11 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
   return hipGetLastError();
 
 size_t g_elem_bytes(int dt) { return dt == G_DT_FP32 ? 4 : 2; }
+bool g_gemv_takes(int M, int K, int ldx) { return M <= 8 && K % 8 == 0 && ldx % 8 == 0; }
+size_t g_attn_partial_floats(int T, int H, int Dh) {
+  const long pairs = (long)T * H;
+  return pairs < G_ATTN_SPLIT_BELOW ? (size_t)pairs * G_ATTN_MAX_SPLITS * (Dh + 2) : 0;
+}
 
 hipError_t launch_g_embedding(int dt, void* out, const void* table, const int64_t* ids, int T_rows, int D, int vocab, uint32_t* bad_id,
                               hipStream_t s) {

@@ -303,11 +303,17 @@ void decode_engine_set_holders_moe(int on);
 // generic.hip: the operator sequence of the hot path for fp32 / fp16 storage (and for bf16 shapes the tuned kernels
 // decline), every rounding point in the storage dtype as the reference executes it.  mi_forward_generic (api.hip).
 enum { G_DT_BF16 = 0, G_DT_FP16 = 1, G_DT_FP32 = 2 };
-enum { G_EPI_STORE = 0, G_EPI_RESIDUAL = 1, G_EPI_LOGITS = 2 };
+enum { G_EPI_STORE = 0, G_EPI_RESIDUAL = 1, G_EPI_LOGITS = 2, G_EPI_SWIGLU = 3 };
 struct GLinearArgs {
   const void* x;         // [M, K], row stride ldx
   int ldx;
   const void* w;         // [N, K] dense
+  // --- the forms below exist on the M <= 8 kernel only (launch_g_linear refuses them otherwise; g_gemv_takes())
+  const void* w1;        // optional second / third weight matrix: output columns [n0, n1) are rows of w1, [n1, N) rows of w2
+  const void* w2;        //   (q | k | v in one launch).  G_EPI_SWIGLU: out[m, n] = silu(x . w[n]) * (x . w1[n]), N rows each
+  int n0, n1;
+  const void* norm_w;    // optional fused RMSNorm of x ([K] weights, `eps`): the contraction runs on round(round(x inv) w)
+  float eps;
   void* out;             // [M, N] storage dtype (fp32 for G_EPI_LOGITS), row stride ldo
   int ldo;
   const void* residual;  // G_EPI_RESIDUAL: [M, N], row stride ldr (may alias out)
@@ -330,8 +336,11 @@ struct GAttnArgs {
   const int32_t* tok_pos;
   int causal;            // 0: the cache=None call (every token sees every token, transformer_layers.py:165)
   float scale;
+  float* partial;        // scratch of g_attn_partial_floats(T, H, Dh) floats: launches with few (token, head) pairs split the keys
 };
 size_t g_elem_bytes(int dt);
+size_t g_attn_partial_floats(int T, int H, int Dh);
+bool g_gemv_takes(int M, int K, int ldx);  // the M <= 8 kernel (fused norm / multi-matrix / SwiGLU forms) applies
 hipError_t launch_g_embedding(int dt, void* out, const void* table, const int64_t* ids, int T, int D, int vocab, uint32_t* bad_id,
                               hipStream_t s);
 hipError_t launch_g_rmsnorm(int dt, void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s);
