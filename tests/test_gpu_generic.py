@@ -276,3 +276,48 @@ def test_fma_tile_kernel_on_the_same_schedules():
                         "own_dtype and (dense_fp32 or dense_fp16 or moe_fp32 or moe_fp16)"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(here))
     assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_fuzz_whole_models(seed, tmp_path):
+    """Seeded random models nobody picked by hand - dims, head layouts (MHA / GQA / MQA), head dims 32 .. 128 including ones
+    that are not a multiple of 64, dense and MoE (top-1 / 2 / 3 of 4 .. 12), global / per-layer / no sliding window, vocabularies
+    that are not a tile multiple, ragged batches, chunked prompts, decode steps - in a random storage dtype against the oracle in
+    that dtype (MoE in fp32 only: no router near-ties to argue about)."""
+    import random
+    rng = random.Random(1000 + seed)
+    Dh = rng.choice([32, 64, 80, 96, 128])
+    Hkv = rng.choice([1, 2, 4])
+    H = Hkv * rng.choice([1, 2, 3, 4])
+    moe = rng.random() < 0.4
+    dtype = F32 if moe else rng.choice([F32, F16, BF])
+    L = rng.randint(1, 3)
+    p = dict(dim=8 * rng.randint(8, 48), n_layers=L, head_dim=Dh, hidden_dim=8 * rng.randint(8, 80), n_heads=H, n_kv_heads=Hkv,
+             norm_eps=1e-5, vocab_size=rng.randint(100, 900), rope_theta=rng.choice([1e4, 1e6]))
+    if moe:
+        E = rng.choice([4, 6, 8, 12])
+        p["moe"] = dict(num_experts=E, num_experts_per_tok=rng.randint(1, 3))
+    win = rng.choice(["none", "one", "list"])
+    if win == "one":
+        p["sliding_window"] = rng.randint(3, 24)
+    elif win == "list":
+        p["sliding_window"] = [rng.choice([None, rng.randint(3, 24)]) for _ in range(L)]
+    args = mo.OracleArgs.from_params(p)
+    w = {k: v.to(dtype) for k, v in mo.synth_weights(args, seed=seed, dtype=BF).items()}
+    model = _load(tmp_path, args, w, dtype)
+    assert model._backend.plan(model) is not None and (model._backend.generic or (dtype == BF and Dh == 128))
+    B = rng.randint(1, 4)
+    prompts = [[rng.randrange(p["vocab_size"]) for _ in range(rng.randint(1, 40))] for _ in range(B)]
+    chunk = rng.choice([None, None, 7, 16])
+    if chunk is not None:  # (every prompt needs a token in every chunk, reference generate.py:94)
+        n_chunks = -(-max(len(q) for q in prompts) // chunk)
+        prompts = [q + [rng.randrange(p["vocab_size"]) for _ in range(max(0, (n_chunks - 1) * chunk + 1 - len(q)))] for q in prompts]
+    n_dec = 3
+    toks = [[rng.randrange(p["vocab_size"]) for _ in range(n_dec)] for _ in range(B)]
+    pre, dec = _replay(model, prompts, toks, chunk, n_dec, dtype)
+    o_pre, o_dec = _replay_oracle(args, w, prompts, toks, chunk, n_dec, 4, dtype)
+    tol = {F32: 2e-5, F16: 6e-3, BF: 5e-2}[dtype]
+    for f, (g, o) in enumerate(zip(pre + dec, o_pre + o_dec)):
+        assert g.shape == o.shape and torch.isfinite(g).all(), (seed, p, f)
+        err = (g - o).abs().max().item()
+        assert err <= tol * max(1.0, o.abs().max().item()), (seed, p, str(dtype), chunk, [len(q) for q in prompts], f, err)
