@@ -343,6 +343,39 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
     return model, cache, nxt, dt, prefill_s
 
 
+def interleaved_run(opt, model, rank: int, world: int, dev: str, T0: int, K: int, Wm: int, sync):
+    """N > 1: the pipeline's THROUGHPUT - `world` independent sequences, one per stage at any time
+    (mistral_inference/pipeline_decode.py): every stage runs one batch-1 decode call per tick on a different sequence, the
+    results move one stage along the ring.  Every sequence gets its own K/V rings and the same T0-token prefill as the
+    single-stream run; W untimed rounds, then exactly K timed rounds (a round = one new token for every sequence) between
+    two barriers + synchronisations.  Returns (seconds, maximum over ranks)."""
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.pipeline_decode import InterleavedDecoder
+    a = model.args
+    prompt = torch.randint(0, a.vocab_size, (T0,), generator=torch.Generator().manual_seed(0)).to(dev)
+    caches, first = [], []
+    with torch.inference_mode():
+        for j in range(world):
+            c = BufferCache(model.n_local_layers, 1, T0 + K + max(Wm, 2) + 64, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
+                            dtype=torch.bfloat16)
+            c.reset()
+            logits = model.forward(prompt, [T0], c)
+            first.append(torch.argmax(logits[-1:], dim=-1))
+            del logits
+            caches.append(c)
+        dec = InterleavedDecoder(model, caches, torch.cat(first))
+        dec.run(max(Wm, 2))
+        sync()
+        t0 = time.perf_counter()
+        dec.run(K)
+        sync()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    del dec, caches
+    return float(tmax.item())
+
+
 def respawn_under_torchrun(n: int) -> int:
     import socket
     import subprocess
@@ -401,6 +434,10 @@ def main() -> None:
         torch.cuda.synchronize()
 
     model, cache, nxt, dt, prefill_s = timed_run(opt, params, rank, world, dev, T0, K, Wm, sync)
+    # N > 1: a single sequence is a relay through the stages (dt above: N GPUs decode no faster than one); the pipeline's
+    # throughput is measured with one sequence per stage in flight.  MI_BENCH_INTERLEAVE=0 skips it.
+    interleave = world > 1 and opt.loop == "greedy" and os.environ.get("MI_BENCH_INTERLEAVE", "1") != "0"
+    dt_il = interleaved_run(opt, model, rank, world, dev, T0, K, Wm, sync) if interleave else None
 
     from mistral_inference import _hip
     engine = _hip.decode_engine_status(model._backend._workspace)
@@ -443,6 +480,20 @@ def main() -> None:
         if opt.loop == "greedy":
             # not inside the K-step bracket: the once-per-chunk read-back of the samples (status copy + host sync + gather)
             out["collect_ms_per_chunk"] = round(getattr(timed_run, "collect_s", 0.0) * 1e3, 3)
+        if dt_il is not None:
+            # N > 1 headline = the pipeline's throughput: `world` sequences in flight, one per stage (each call still batch 1,
+            # seq 1 on that sequence's own rings); a step = one round = one new token for EVERY sequence.  The relay figure of
+            # ONE sequence through the same stages (what the reference's pipeline does: N GPUs, the speed of one) stays beside it.
+            rate = K * world / dt_il
+            out["single_stream"] = {"tokens_per_s": out["value"], "ms_per_step": out["ms_per_step"],
+                                    "hbm_roofline_frac_of_one_gpu": out["hbm_roofline_step"]["frac"],
+                                    "note": "one sequence relayed through the stages (reference transformer.py:195-237)"}
+            out["value"], out["ms_per_step"], out["scaling"] = round(rate, 2), round(dt_il / K * 1e3, 4), "weak"
+            agg = step_bytes * rate / 1e9
+            out["hbm_roofline_step"] = {"bytes_per_token": step_bytes, "achieved_GBs": round(agg, 1), "peak_GBs": HBM_PEAK_GBS * world,
+                                        "frac": round(agg / (HBM_PEAK_GBS * world), 4), "note": f"aggregate over {world} GPUs"}
+            out["config"]["sequences_in_flight"] = world
+            out["config"]["parallelism"] += f"; decode throughput: {world} sequences in flight, one per stage, ring of grouped send+recv per tick"
         # the dominant kernel is timed on this rank's own layers (any N)
         if engine["engine_launches"] > 0 and world == 1:
             with torch.inference_mode():
@@ -473,6 +524,7 @@ def main() -> None:
         if opt.mixtral_layers:
             mx_params["n_layers"] = opt.mixtral_layers
         m2, c2, _, dt2, pre2 = timed_run(opt, mx_params, rank, world, dev, T0, K, Wm, sync)
+        dt2_il = interleaved_run(opt, m2, rank, world, dev, T0, K, Wm, sync) if interleave else None
         if rank == 0:
             ctx_len = T0 + Wm + K // 2
             b2 = decode_bytes_per_token(mx_params, ctx_len)
@@ -482,6 +534,11 @@ def main() -> None:
                               "prefill_tokens_per_s": round(T0 / pre2, 1),
                               "prefill_mfma_frac": round(prefill_flops(mx_params, T0) / pre2 / 2.5e15 / world, 4),
                               "transport": type(m2.pp_comm).__name__}
+            if dt2_il is not None:  # the pipeline's throughput (one sequence per stage in flight) next to the single-sequence relay
+                r2 = K * world / dt2_il
+                out["mixtral"].update({"single_stream_tokens_per_s": out["mixtral"]["tokens_per_s"], "tokens_per_s": round(r2, 2),
+                                       "ms_per_step": round(dt2_il / K * 1e3, 4), "sequences_in_flight": world,
+                                       "hbm_roofline_frac": round(b2 * r2 / 1e9 / (HBM_PEAK_GBS * world), 4)})
         del m2, c2
     if world > 1:
         torch.distributed.barrier()

@@ -60,6 +60,17 @@ class RcclComm:
         _hip.check(_hip.lib().mi_rccl_bcast(self._h, t.data_ptr(), t.numel() * t.element_size(), src, _hip.stream_ptr(t.device)),
                    "mi_rccl_bcast")
 
+    def exchange(self, send_t: Optional[torch.Tensor], dst: int, recv_t: Optional[torch.Tensor], src: int) -> None:
+        """One grouped send + recv (ncclGroupStart / End): the two progress together, so a ring of ranks that all send
+        forward and receive from behind cannot deadlock on rendezvous (pipeline_decode.InterleavedDecoder)."""
+        L = _hip.lib()
+        _hip.check(L.mi_rccl_group_start(), "mi_rccl_group_start")
+        if send_t is not None:
+            self.send(send_t, dst)
+        if recv_t is not None:
+            self.recv(recv_t, src)
+        _hip.check(L.mi_rccl_group_end(), "mi_rccl_group_end")
+
     def exchange_with_self(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         """Grouped send + recv to this very rank (the single-GPU test of the transport)."""
         L = _hip.lib()
@@ -86,6 +97,23 @@ class TorchDistComm:
 
     def broadcast(self, t: torch.Tensor, src: int) -> None:
         torch.distributed.broadcast(t, src=src)
+
+    def exchange(self, send_t: Optional[torch.Tensor], dst: int, recv_t: Optional[torch.Tensor], src: int) -> None:
+        """Grouped send + recv (`batch_isend_irecv`: one NCCL group on a GPU, two non-blocking requests over gloo)."""
+        dist = torch.distributed
+        t = send_t if send_t is not None else recv_t
+        if t is not None and t.is_cuda and dist.get_backend() != "nccl":
+            # test rigs only (two ranks sharing one GPU over gloo): gloo moves device tensors without ordering itself behind the
+            # stream that produces them - the data of this tick must be complete before it is read
+            torch.cuda.current_stream(t.device).synchronize()
+        ops = []
+        if send_t is not None:
+            ops.append(dist.P2POp(dist.isend, send_t, dst))
+        if recv_t is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_t, src))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()  # (NCCL: orders the current stream behind the transfer; gloo: blocks until the data is there)
 
 
 def pipeline_comm(device: torch.device):

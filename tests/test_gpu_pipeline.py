@@ -105,7 +105,9 @@ def test_bench_two_ranks_prints_one_json_line():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MI_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    # (two ranks on ONE GPU: the persistent engine of one rank cannot be resident beside the other's when both decode at the
+    # same time - the interleaved measurement - so this rig takes the launch path; one rank per GPU keeps the engine)
+    env = dict(os.environ, MI_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MI_DECODE_ENGINE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29377", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--layers", "4", "--prefill", "256", "--mixtral-layers", "2"]
@@ -114,11 +116,14 @@ def test_bench_two_ranks_prints_one_json_line():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    # N > 1 headline: the pipeline's throughput, one sequence per stage in flight (weak scaling); the single-sequence relay beside it
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["sequences_in_flight"] == 2 and d["single_stream"]["tokens_per_s"] > 0
     assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
     # north_star's multi-GPU model: a Mixtral sub-measurement over the same stages (8x7B dims for N < 8, layer-truncated here)
     mx = d["mixtral"]
     assert "Mixtral-8x7B" in mx["model"] and mx["tokens_per_s"] > 0 and 0 < mx["hbm_roofline_frac"] < 1 and mx["prefill_tokens_per_s"] > 0
+    assert mx["sequences_in_flight"] == 2 and mx["single_stream_tokens_per_s"] > 0
 
 
 def test_plain_bench_invocation_spawns_its_own_ranks():
@@ -130,6 +135,7 @@ def test_plain_bench_invocation_spawns_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["MI_DIST_BACKEND"] = "gloo"  # two ranks on this box's one GPU (RCCL refuses that); "nccl" on a multi-GPU node
+    env["MI_DECODE_ENGINE"] = "0"    # (see above: two engines cannot share one GPU)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--layers", "2",
            "--prefill", "128", "--no-mixtral"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -138,3 +144,85 @@ def test_plain_bench_invocation_spawns_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "pp2" in d["config"]["parallelism"]
+
+
+def _interleaved_worker(rank, world, port, name, tmp, q, backend, n_dec):
+    for p in (os.path.join(ROOT, "mistral-inference_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MI_PP_TRANSPORT="torch", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":
+        os.environ["MI_DECODE_ENGINE"] = "0"  # both stages decode at the same time on ONE GPU here: no room for two engines
+    dev = "cuda:0" if backend == "gloo" else f"cuda:{rank}"
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from golden_util import Case
+        from hip_util import write_checkpoint
+        from mistral_inference.cache import BufferCache
+        from mistral_inference.pipeline_decode import InterleavedDecoder
+        from mistral_inference.transformer import Transformer
+        case = Case(name)
+        folder = os.path.join(tmp, "ckpt")
+        if rank == 0:
+            write_checkpoint(folder, case.args, case.weights())
+        dist.barrier()
+        m = Transformer.from_folder(folder, max_batch_size=1, num_pipeline_ranks=world, device=dev, dtype=torch.bfloat16)
+        a = m.args
+        caches, first = [], []
+        for pr in case.prompts[:world]:
+            c = BufferCache(m.n_local_layers, 1, len(pr) + n_dec + 4, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
+                            dtype=torch.bfloat16)
+            c.reset()
+            ids = torch.tensor(pr if rank == 0 else [0] * len(pr), dtype=torch.long)
+            logits = m.forward(ids, [len(pr)], c)
+            first.append(torch.argmax(logits[-1:], dim=-1))
+            caches.append(c)
+        dec = InterleavedDecoder(m, caches, torch.cat(first))
+        toks, lps = dec.run(n_dec)
+        q.put((rank, [int(f) for f in first], toks.tolist(), lps.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", [
+    "gloo",
+    pytest.param("nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs 2 GPUs (RCCL refuses two ranks on one device)")),
+])
+@pytest.mark.parametrize("name", ["dense_bf16", "swa_bf16"])
+def test_interleaved_decoder_on_hip(name, backend, tmp_path):
+    """pipeline_decode.InterleavedDecoder on the real kernels: two sequences through two stages, both stages busy every tick.
+    Every sequence's tokens and log-probabilities equal decoding it ALONE on one stage (generate() on the whole model, same
+    kernels per layer: the stage boundary moves bf16 activations, nothing is recomputed differently)."""
+    from golden_util import Case
+    from hip_util import write_checkpoint
+    from mistral_inference.generate import generate
+    from mistral_inference.transformer import Transformer
+    case = Case(name)
+    n_dec = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30300 + (os.getpid() % 500) + (sum(map(ord, name + backend)) % 97)
+    procs = [ctx.Process(target=_interleaved_worker, args=(r, 2, port, name, str(tmp_path), q, backend, n_dec)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from mistral_inference import _hip
+    folder = write_checkpoint(tmp_path / "single", case.args, case.weights())
+    single = Transformer.from_folder(folder, max_batch_size=1, device="cuda", dtype=torch.bfloat16)
+    (_, f0, t0, lp0), (_, f1, t1, lp1) = res
+    assert f0 == f1 and t0 == t1  # every stage returns the same tokens
+    prev = _hip.set_decode_engine(False) if backend == "gloo" else None  # the same path as the workers took
+    try:
+        for j, pr in enumerate(case.prompts[:2]):
+            ref_t, ref_lp = generate([pr], single, max_tokens=n_dec + 1, temperature=0.0)
+            assert f0[j] == ref_t[0][0], (j, f0, ref_t)
+            assert [row[j] for row in t0] == ref_t[0][1:], (j, t0, ref_t)
+            gen_lp = ref_lp[0][len(pr) - 1:]
+            assert max(abs(row[j] - x) for row, x in zip(lp0, gen_lp[1:])) <= 1e-5
+    finally:
+        if prev is not None:
+            _hip.set_decode_engine(bool(prev))

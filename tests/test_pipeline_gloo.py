@@ -121,3 +121,104 @@ def test_greedy_session_across_two_stages_carries_the_sample_not_the_logits(name
             assert len(act_hops) == gen - 1
         hist = [t for t in traffic if t[0] == "bcast" and len(t[1]) == 2 and t[1][1] == B and t[1][0] <= gen]
         assert len(hist) == 2   # tokens + logprobs, ONE collect for the whole generation (no eos_id)
+
+
+def _interleaved_worker(rank, world, port, q, n_dec):
+    for p in (os.path.join(ROOT, "mistral-inference_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mistral_oracle as mo
+        from mistral_inference.args import TransformerArgs
+        from mistral_inference.cache import BufferCache
+        from mistral_inference.pipeline_decode import InterleavedDecoder
+        from mistral_inference.transformer import Transformer
+        from oracle_backend import OracleStackBackend
+        params, w, prompts = _interleaved_case(world)
+        a = TransformerArgs.from_dict(params)
+        a.max_batch_size = 1
+        m = Transformer(a, pipeline_rank=rank, num_pipeline_ranks=world, backend=OracleStackBackend())
+        m.load_state_dict(w, assign=True)
+        comm = m.pp_comm
+        traffic = []
+
+        class Recorder:
+            def send(self, t, dst):
+                comm.send(t, dst)
+
+            def recv(self, t, src):
+                comm.recv(t, src)
+
+            def broadcast(self, t, src):
+                comm.broadcast(t, src)
+
+            def exchange(self, send_t, dst, recv_t, src):
+                traffic.append((None if send_t is None else (dst, send_t.numel() * send_t.element_size()),
+                                None if recv_t is None else (src, recv_t.numel() * recv_t.element_size())))
+                comm.exchange(send_t, dst, recv_t, src)
+        m._pp_comm = Recorder()
+        caches, first = [], []
+        for pr in prompts:  # every sequence prefilled through the ordinary pipeline forward, into its own rings
+            c = BufferCache(m.n_local_layers, 1, len(pr) + n_dec + 2, a.n_kv_heads, a.head_dim, a.sliding_window, dtype=torch.float32)
+            c.reset()
+            ids = torch.tensor(pr if rank == 0 else [0] * len(pr), dtype=torch.long)
+            logits = m.forward(ids, [len(pr)], c)
+            caches.append(c)
+            first.append(int(torch.argmax(logits[-1])))
+        dec = InterleavedDecoder(m, caches, torch.tensor(first))
+        toks, lps = dec.run(n_dec)
+        toks2, _ = dec.run(2)  # a second call continues every sequence
+        q.put((rank, first, toks.tolist(), lps.tolist(), toks2.tolist(), traffic))
+    finally:
+        dist.destroy_process_group()
+
+
+def _interleaved_case(world):
+    import mistral_oracle as mo
+    params = dict(dim=64, n_layers=2 * world - 1, head_dim=32, hidden_dim=128, n_heads=4, n_kv_heads=2, norm_eps=1e-5, vocab_size=97,
+                  sliding_window=6)
+    args = mo.OracleArgs.from_params(params)
+    w = {k: v.float() for k, v in mo.synth_weights(args, seed=11, dtype=torch.bfloat16).items()}
+    prompts = [[(5 * i + 3 * j + 1) % 97 for i in range(4 + 3 * j)] for j in range(world)]
+    return params, w, prompts
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_interleaved_decoder_one_sequence_per_stage(world):
+    """pipeline_decode.InterleavedDecoder over gloo: `world` sequences through `world` stages, every stage busy on a different
+    sequence each tick.  Tokens and log-probabilities of EVERY sequence equal decoding it alone in one process (the oracle's
+    generate), on every rank; per tick a stage posts exactly one grouped exchange carrying at most one [1, dim] activation
+    forward and - on the ring's closing link - 8 bytes of sample; uneven layer split (2 world - 1 layers), a window that wraps."""
+    import mistral_oracle as mo
+    n_dec = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 1500) + world
+    procs = [ctx.Process(target=_interleaved_worker, args=(r, world, port, q, n_dec)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params, w, prompts = _interleaved_case(world)
+    args = mo.OracleArgs.from_params(params)
+    ref_t, ref_lp = [], []
+    for pr in prompts:
+        t, lp = mo.generate([pr], mo.OracleModel(args, w), max_tokens=n_dec + 3, max_batch_size=1)
+        ref_t.append(t[0])
+        ref_lp.append(lp[0][len(pr) - 1:])
+    D = params["dim"]
+    for rank, first, toks, lps, toks2, traffic in res:
+        for j in range(world):
+            assert first[j] == ref_t[j][0], (rank, j)
+            assert [row[j] for row in toks] == ref_t[j][1:n_dec + 1], (rank, j)
+            assert [row[j] for row in toks2] == ref_t[j][n_dec + 1:n_dec + 3], (rank, j)
+            assert max(abs(row[j] - x) for row, x in zip(lps, ref_lp[j][1:n_dec + 1])) < 2e-5
+        # one exchange per tick; what leaves: activations (4 * D bytes, fp32 here) or, from the last stage, the 8-byte sample
+        assert len(traffic) == (n_dec + 2) * world + 2 * (world - 1)
+        sends = [s for s, _ in traffic if s is not None]
+        assert len(sends) == (n_dec + 2) * world
+        assert all(b == (8 if rank == world - 1 else 4 * D) and d == (rank + 1) % world for d, b in sends)
