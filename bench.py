@@ -8,7 +8,12 @@ with the ring full (4096 keys per layer).  Inputs (weights, K/V rings, token ids
 
     python bench.py --gpus 1 --steps 64 --warmup 8
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W        # pipeline stages over RCCL (strong scaling)
+        bench.py --gpus N --steps K --warmup W        # pipeline stages over RCCL
+
+N > 1 (one rank per GPU, layer ranges as pipeline stages): the headline `value` is the pipeline's THROUGHPUT - N independent
+sequences in flight, one per stage at any time, every call still batch 1 / seq 1 on that sequence's own K/V rings ("scaling":
+"weak": a step = one new token for every sequence; mistral_inference/pipeline_decode.py).  The relay of ONE sequence through the
+same stages - what the reference's pipeline does, N GPUs at the speed of one - is reported beside it as `single_stream`.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md section 6 for the roofline / cpu_baseline definitions).
 """
