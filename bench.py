@@ -442,7 +442,14 @@ def main() -> None:
     # N > 1: a single sequence is a relay through the stages (dt above: N GPUs decode no faster than one); the pipeline's
     # throughput is measured with one sequence per stage in flight.  MI_BENCH_INTERLEAVE=0 skips it.
     interleave = world > 1 and opt.loop == "greedy" and os.environ.get("MI_BENCH_INTERLEAVE", "1") != "0"
-    dt_il = interleaved_run(opt, model, rank, world, dev, T0, K, Wm, sync) if interleave else None
+    dt_il = None
+    if interleave:
+        try:
+            dt_il = interleaved_run(opt, model, rank, world, dev, T0, K, Wm, sync)
+        except Exception as e:  # an error every rank raises alike (API / shape): keep the single-stream line instead of no line
+            print(f"[bench] rank {rank}: interleaved measurement failed ({type(e).__name__}: {e}); reporting the single-stream relay",
+                  file=sys.stderr, flush=True)
+            interleave = False
 
     from mistral_inference import _hip
     engine = _hip.decode_engine_status(model._backend._workspace)
