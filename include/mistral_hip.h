@@ -279,6 +279,21 @@ int mi_forward(const mi_model_t* model, const mi_batch_t* batch, mi_stream_t str
 enum mi_dtype { MI_DTYPE_BF16 = 0, MI_DTYPE_FP16 = 1, MI_DTYPE_FP32 = 2 };
 size_t mi_workspace_bytes_generic(const mi_model_t* model, int T, int dtype);
 int mi_forward_generic(const mi_model_t* model, const mi_batch_t* batch, int dtype, mi_stream_t stream);
+/* Leaf operators in any storage dtype - what module-level callers of an fp16 / fp32 model bind (the Pixtral tower of
+ * vision_encoder.py:76-204, RMSNorm / FeedForward used stand-alone); argument meaning as the bf16 entry points above.
+ * mi_linear_generic: one launch per weight matrix, epilogues STORE / RESIDUAL / LOGITS (SwiGLU = two calls +
+ * mi_swiglu_generic: a <- silu(a) * b).  mi_attention_nocache_generic: the cache=None attention, every token sees every
+ * token (transformer_layers.py:72-73,165), any head_dim <= 256, softmax_scale <= 0 = head_dim^-1/2. */
+int mi_embedding_generic(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, int dtype, mi_stream_t stream);
+int mi_rmsnorm_generic(void* out, const void* x, const void* w, int T, int D, float eps, int dtype, mi_stream_t stream);
+int mi_linear_generic(void* out, int ldo, const void* x, int ldx, int M, int K, const void* const w[3], const int n_rows[3],
+                      int epilogue, const void* residual, int dtype, mi_stream_t stream);
+int mi_rope_inplace_generic(void* qkv, int ld, int T, int n_rot_cols, int head_dim, const float* rope_cs, const int32_t* tok_pos,
+                            int dtype, mi_stream_t stream);
+int mi_attention_nocache_generic(void* out, const void* qkv, int ld, int T, int n_heads, int n_kv_heads, int head_dim,
+                                 float softmax_scale, int dtype, mi_stream_t stream);
+int mi_swiglu_generic(void* a, const void* b, int T, int F, int dtype, mi_stream_t stream);
+int mi_gelu_generic(void* x, int ldx, int T, int N, int dtype, mi_stream_t stream);
 
 /* Persistent decode engine (csrc/decode_engine.hip).  A DECODE-branch mi_forward with T == B == 1 on a dense model runs
  * all local layers - TransformerBlock.forward (transformer_layers.py:158-169) x n_layers, the ring write (cache.py:83-92)

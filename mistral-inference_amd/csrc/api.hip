@@ -859,6 +859,90 @@ int check_model_generic(const mi_model_t* m, int dtype) {
 
 extern "C" {
 
+// ---- leaf operators in any storage dtype (ABI v6): what module-level callers of an fp16 / fp32 model bind - the Pixtral tower
+// (vision_encoder.py), RMSNorm / FeedForward modules used stand-alone.  Same kernels as mi_forward_generic.
+static int check_dt(int dtype, const char* what) {
+  if (dtype != G_DT_BF16 && dtype != G_DT_FP16 && dtype != G_DT_FP32) return fail(MI_ERR_ARG, "%s: storage dtype %d", what, dtype);
+  return MI_OK;
+}
+
+int mi_embedding_generic(void* out, const void* table, const int64_t* ids, int T, int D, int vocab, int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_embedding_generic"));
+  if (!out || !table || !ids || T <= 0 || D <= 0) return fail(MI_ERR_ARG, "mi_embedding_generic");
+  return hip_rc(launch_g_embedding(dtype, out, table, ids, T, D, vocab, nullptr, (hipStream_t)stream), "embedding");
+}
+
+int mi_rmsnorm_generic(void* out, const void* x, const void* w, int T, int D, float eps, int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_rmsnorm_generic"));
+  if (!out || !x || !w || T <= 0 || D <= 0) return fail(MI_ERR_ARG, "mi_rmsnorm_generic");
+  return hip_rc(launch_g_rmsnorm(dtype, out, x, w, T, D, eps, (hipStream_t)stream), "rmsnorm");
+}
+
+/* out[:, columns of w[i]] = epilogue(x @ w[i]^T), i < 3 (w[i] == NULL ends the list): MI_EPI_STORE, MI_EPI_RESIDUAL (residual
+ * [M, N] with row stride ldo) or MI_EPI_LOGITS (fp32 out).  One launch per matrix. */
+int mi_linear_generic(void* out, int ldo, const void* x, int ldx, int M, int K, const void* const w[3], const int n_rows[3],
+                      int epilogue, const void* residual, int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_linear_generic"));
+  if (!out || !x || !w || !n_rows || !w[0] || M <= 0 || K <= 0) return fail(MI_ERR_ARG, "mi_linear_generic");
+  int epi;
+  switch (epilogue) {
+    case MI_EPI_STORE: epi = G_EPI_STORE; break;
+    case MI_EPI_RESIDUAL: epi = G_EPI_RESIDUAL; break;
+    case MI_EPI_LOGITS: epi = G_EPI_LOGITS; break;
+    default: return fail(MI_ERR_UNSUPPORTED, "mi_linear_generic: epilogue %d (SwiGLU: two calls + mi_swiglu_generic)", epilogue);
+  }
+  if (epi == G_EPI_RESIDUAL && !residual) return fail(MI_ERR_ARG, "mi_linear_generic: residual");
+  const size_t es = g_elem_bytes(dtype), oes = epi == G_EPI_LOGITS ? 4 : es;
+  int col = 0;
+  for (int i = 0; i < 3 && w[i]; ++i) {
+    if (n_rows[i] <= 0) return fail(MI_ERR_ARG, "mi_linear_generic: n_rows[%d]", i);
+    GLinearArgs g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.ldx = ldx; g.w = w[i]; g.out = (char*)out + (size_t)col * oes; g.ldo = ldo;
+    g.residual = residual ? (const char*)residual + (size_t)col * es : nullptr; g.ldr = ldo;
+    g.M = M; g.N = n_rows[i]; g.K = K; g.epi = epi;
+    MI_TRY(hip_rc(launch_g_linear(dtype, g, (hipStream_t)stream), "linear"));
+    col += n_rows[i];
+  }
+  return MI_OK;
+}
+
+/* rope.py:13-23 in place on the first n_rot_cols columns (heads of head_dim): pair i of a head turns by rope_cs[tok_pos[t], i] */
+int mi_rope_inplace_generic(void* qkv, int ld, int T, int n_rot_cols, int head_dim, const float* rope_cs, const int32_t* tok_pos,
+                            int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_rope_inplace_generic"));
+  if (!qkv || !rope_cs || !tok_pos || T <= 0 || head_dim <= 0 || head_dim % 2 || n_rot_cols % head_dim || n_rot_cols > ld)
+    return fail(MI_ERR_ARG, "mi_rope_inplace_generic");
+  return hip_rc(launch_g_rope(dtype, qkv, ld, T, n_rot_cols, head_dim, rope_cs, tok_pos, (hipStream_t)stream), "rope");
+}
+
+/* the cache=None attention (transformer_layers.py:72-73,165: every token sees every token): qkv [T, ld] = q | k | v after RoPE */
+int mi_attention_nocache_generic(void* out, const void* qkv, int ld, int T, int n_heads, int n_kv_heads, int head_dim,
+                                 float softmax_scale, int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_attention_nocache_generic"));
+  if (!out || !qkv || T <= 0 || n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads || head_dim <= 0 || head_dim > 256)
+    return fail(MI_ERR_ARG, "mi_attention_nocache_generic");
+  GAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out = out; a.ldo = n_heads * head_dim; a.qkv = qkv; a.ld = ld; a.W = T; a.T = T; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim;
+  a.causal = 0;
+  a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)head_dim);
+  return hip_rc(launch_g_attention(dtype, a, (hipStream_t)stream), "attention");
+}
+
+/* a <- silu(a) * b on [T, F] dense rows (transformer_layers.py:106) */
+int mi_swiglu_generic(void* a, const void* b, int T, int F, int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_swiglu_generic"));
+  if (!a || !b || T <= 0 || F <= 0) return fail(MI_ERR_ARG, "mi_swiglu_generic");
+  return hip_rc(launch_g_swiglu(dtype, a, b, T, F, nullptr, (hipStream_t)stream), "swiglu");
+}
+
+int mi_gelu_generic(void* x, int ldx, int T, int N, int dtype, mi_stream_t stream) {
+  MI_TRY(check_dt(dtype, "mi_gelu_generic"));
+  if (!x || T <= 0 || N <= 0 || ldx < N) return fail(MI_ERR_ARG, "mi_gelu_generic");
+  return hip_rc(launch_g_gelu(dtype, x, ldx, T, N, (hipStream_t)stream), "gelu");
+}
+
 size_t mi_workspace_bytes_generic(const mi_model_t* model, int T, int dtype) {
   if (!model || T <= 0) return 0;
   return carve_generic(model, T, g_elem_bytes(dtype), nullptr).total;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void g_gemm_mfma_kernel(GLinearArgs g) {
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const bool in = k0 + koff[j] < g.K;  // (K % 8 == 0: a piece is inside or outside as a whole)
-      const int kc = in ? k0 : 0;
+      const int kc = in ? k0 : -koff[j];   // outside: the row's first piece (always there), zeroed below
       ra[j] = ld16(asrc[j] + kc);
       rw[j] = ld16(wsrc[j] + kc);
       if (!in) {
@@ -802,6 +802,16 @@ __global__ __launch_bounds__(256) void g_add_kernel(T* out, const T* a, const T*
   if (gid < n) St<T>::st(out + gid, St<T>::ld(a + gid) + St<T>::ld(b + gid));
 }
 
+// nn.GELU() (exact erf form), fp32 evaluation rounded once (vision_encoder.py:112-116), in place on rows of N elements
+template <typename T>
+__global__ __launch_bounds__(256) void g_gelu_kernel(T* x, int ldx, int N) {
+  T* row = x + (size_t)blockIdx.x * ldx;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float v = St<T>::ld(row + i);
+    St<T>::st(row + i, 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void g_zero_kernel(T* p, size_t n) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -921,6 +931,10 @@ hipError_t launch_g_moe_accum(int dt, void* results, const void* y, const int32_
 
 hipError_t launch_g_add(int dt, void* out, const void* a, const void* b, size_t n, hipStream_t s) {
   G_DISPATCH(dt, hipLaunchKernelGGL((g_add_kernel<T>), dim3(blocks_for(n)), dim3(256), 0, s, (T*)out, (const T*)a, (const T*)b, n))
+}
+
+hipError_t launch_g_gelu(int dt, void* x, int ldx, int T_rows, int N, hipStream_t s) {
+  G_DISPATCH(dt, hipLaunchKernelGGL((g_gelu_kernel<T>), dim3(T_rows), dim3(256), 0, s, (T*)x, ldx, N))
 }
 
 hipError_t launch_g_zero(int dt, void* p, size_t n, hipStream_t s) {

@@ -356,3 +356,4 @@ hipError_t launch_g_moe_mask(const int32_t* sel_idx, const float* sel_w, int T, 
 hipError_t launch_g_moe_accum(int dt, void* results, const void* y, const int32_t* active, const float* wt, int T, int D, hipStream_t s);
 hipError_t launch_g_add(int dt, void* out, const void* a, const void* b, size_t n, hipStream_t s);
 hipError_t launch_g_zero(int dt, void* p, size_t n, hipStream_t s);
+hipError_t launch_g_gelu(int dt, void* x, int ldx, int T, int N, hipStream_t s);

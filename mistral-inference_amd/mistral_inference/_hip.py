@@ -92,6 +92,14 @@ _SIGS = {
     "mi_forward": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), _vp]),
     "mi_workspace_bytes_generic": (C.c_size_t, [C.POINTER(MiModel), C.c_int, C.c_int]),  # ABI v6
     "mi_forward_generic": (C.c_int, [C.POINTER(MiModel), C.POINTER(MiBatch), C.c_int, _vp]),
+    "mi_embedding_generic": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "mi_rmsnorm_generic": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
+    "mi_linear_generic": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, _vp,
+                                    C.c_int, _vp]),
+    "mi_rope_inplace_generic": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "mi_attention_nocache_generic": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
+    "mi_swiglu_generic": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "mi_gelu_generic": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "mi_set_decode_engine": (C.c_int, [C.c_int]),
     "mi_decode_engine_census": (C.c_int, [C.c_int]),
     "mi_decode_engine_reset": (C.c_int, [_vp, _vp]),
@@ -164,6 +172,12 @@ def dev_ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = torch.bflo
 # ------------------------------------------------------------------------------------------------
 # leaf operator wrappers (torch tensors in, torch tensors out; all work done by the library)
 # ------------------------------------------------------------------------------------------------
+def _generic_code(dt: torch.dtype) -> int:
+    if dt not in DTYPE_CODES:
+        raise RuntimeError(f"storage dtype {dt}: the HIP kernels take bfloat16, float16 and float32")
+    return DTYPE_CODES[dt]
+
+
 def check_ids_on_host(ids: torch.Tensor, vocab: int) -> None:
     """nn.Embedding's IndexError for ids the host can see without a device synchronisation."""
     if ids.device.type == "cpu" and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= vocab):
@@ -175,6 +189,11 @@ def embedding(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     check_ids_on_host(ids, V)
     out = torch.empty((T, D), dtype=table.dtype, device=table.device)
     ids = ids.to(device=table.device, dtype=torch.long).contiguous()
+    dt = table.dtype
+    if dt != torch.bfloat16:  # fp16 / fp32 storage: the generic kernels (csrc/generic.hip)
+        check(lib().mi_embedding_generic(dev_ptr(out, dt), dev_ptr(table, dt), dev_ptr(ids, torch.long), T, D, V, _generic_code(dt),
+                                         stream_ptr(table.device)), "mi_embedding_generic")
+        return out
     check(lib().mi_embedding(dev_ptr(out), dev_ptr(table), dev_ptr(ids, torch.long), T, D, V, stream_ptr(table.device)),
           "mi_embedding")
     return out
@@ -185,6 +204,11 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Te
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     o = torch.empty_like(x2) if out is None else out
+    dt = x.dtype
+    if dt != torch.bfloat16:
+        check(lib().mi_rmsnorm_generic(dev_ptr(o, dt), dev_ptr(x2, dt), dev_ptr(w, dt), x2.shape[0], x2.shape[1], float(eps),
+                                       _generic_code(dt), stream_ptr(x.device)), "mi_rmsnorm_generic")
+        return o.view(x.shape)
     check(lib().mi_rmsnorm(dev_ptr(o), dev_ptr(x2), dev_ptr(w), x2.shape[0], x2.shape[1], float(eps),
                            stream_ptr(x.device)), "mi_rmsnorm")
     return o.view(x.shape)
@@ -200,6 +224,8 @@ def linear(x: torch.Tensor, weights: Sequence[torch.Tensor], epilogue: int = EPI
     for w in weights:
         assert w.shape[1] == K and w.is_contiguous()
     N = n_rows[0] if epilogue == EPI_SWIGLU else sum(n_rows)
+    if x.dtype != torch.bfloat16:
+        return _linear_generic(x, weights, n_rows, N, epilogue, residual, norm_w, eps, out)
     odt = torch.float32 if epilogue == EPI_LOGITS else torch.bfloat16
     if out is None:
         out = torch.empty((M, N), dtype=odt, device=x.device)
@@ -210,9 +236,46 @@ def linear(x: torch.Tensor, weights: Sequence[torch.Tensor], epilogue: int = EPI
     return out
 
 
+def _linear_generic(x, weights, n_rows, N, epilogue, residual, norm_w, eps, out):
+    """`linear` for fp16 / fp32 storage (csrc/generic.hip): the same epilogues composed from mi_*_generic calls."""
+    dt, dev = x.dtype, x.device
+    code, st = _generic_code(dt), stream_ptr(dev)
+    M, K = x.shape
+    L = lib()
+    if norm_w is not None:
+        x = rmsnorm(x, norm_w, eps)
+    if not x.is_contiguous():
+        x = x.contiguous()
+
+    def run(ws, rows, epi, o, res=None):
+        wp = (_vp * 3)(*[dev_ptr(w, dt) for w in ws], *([None] * (3 - len(ws))))
+        nr = (C.c_int * 3)(*rows, *([0] * (3 - len(ws))))
+        odt = torch.float32 if epi == EPI_LOGITS else dt
+        check(L.mi_linear_generic(dev_ptr(o, odt), o.stride(0), dev_ptr(x, dt), x.stride(0), M, K, wp, nr, epi, dev_ptr(res, dt), code, st),
+              "mi_linear_generic")
+        return o
+    if epilogue == EPI_SWIGLU:
+        a = run(weights[:1], n_rows[:1], EPI_STORE, torch.empty((M, N), dtype=dt, device=dev) if out is None else out)
+        b = run(weights[1:2], n_rows[1:2], EPI_STORE, torch.empty((M, N), dtype=dt, device=dev))
+        assert a.is_contiguous()
+        check(L.mi_swiglu_generic(dev_ptr(a, dt), dev_ptr(b, dt), M, N, code, st), "mi_swiglu_generic")
+        return a
+    odt = torch.float32 if epilogue == EPI_LOGITS else dt
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=dev)
+    if epilogue == EPI_RESIDUAL:
+        assert residual is not None and residual.stride(0) == out.stride(0), "residual rows must have the output's stride"
+    return run(weights, n_rows, epilogue, out, residual if epilogue == EPI_RESIDUAL else None)
+
+
 def rope_inplace(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int, rope_cs: torch.Tensor,
                  tok_pos: torch.Tensor) -> None:
     assert rope_cs.dtype == torch.float32 and rope_cs.is_contiguous() and tok_pos.dtype == torch.int32
+    if qkv.dtype != torch.bfloat16:
+        check(lib().mi_rope_inplace_generic(dev_ptr(qkv, qkv.dtype), qkv.stride(0), qkv.shape[0], (n_heads + n_kv_heads) * head_dim,
+                                            head_dim, dev_ptr(rope_cs, torch.float32), dev_ptr(tok_pos, torch.int32),
+                                            _generic_code(qkv.dtype), stream_ptr(qkv.device)), "mi_rope_inplace_generic")
+        return
     check(lib().mi_rope_inplace(dev_ptr(qkv), qkv.stride(0), qkv.shape[0], n_heads, n_kv_heads, head_dim,
                                 dev_ptr(rope_cs, torch.float32), rope_cs.shape[0], dev_ptr(tok_pos, torch.int32),
                                 stream_ptr(qkv.device)), "mi_rope_inplace")
@@ -253,6 +316,14 @@ def attn_prefill(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int
     """softmax_scale <= 0: head_dim ** -0.5."""
     T = qkv.shape[0]
     out = torch.empty((T, n_heads * head_dim), dtype=qkv.dtype, device=qkv.device)
+    if qkv.dtype != torch.bfloat16:
+        if causal or cache_k is not None:
+            raise RuntimeError("fp16 / fp32 storage: the stand-alone attention operator exists for the cache=None form only "
+                               "(cached attention runs inside mi_forward_generic)")
+        check(lib().mi_attention_nocache_generic(dev_ptr(out, qkv.dtype), dev_ptr(qkv, qkv.dtype), qkv.stride(0), T, n_heads, n_kv_heads,
+                                                 head_dim, float(softmax_scale), _generic_code(qkv.dtype), stream_ptr(qkv.device)),
+              "mi_attention_nocache_generic")
+        return out
     check(lib().mi_attn_prefill(dev_ptr(out), dev_ptr(qkv), qkv.stride(0), dev_ptr(cache_k), dev_ptr(cache_v), W, B,
                                 max_q_len, n_heads, n_kv_heads, head_dim, dev_ptr(q_start, torch.int32),
                                 dev_ptr(kv_before, torch.int32), 1 if causal else 0, float(softmax_scale),
@@ -307,6 +378,10 @@ def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: i
 def gelu_(x: torch.Tensor) -> torch.Tensor:
     """In-place exact GELU on a 2-D bf16 tensor."""
     assert x.dim() == 2
+    if x.dtype != torch.bfloat16:
+        check(lib().mi_gelu_generic(dev_ptr(x, x.dtype), x.stride(0), x.shape[0], x.shape[1], _generic_code(x.dtype),
+                                    stream_ptr(x.device)), "mi_gelu_generic")
+        return x
     check(lib().mi_gelu(dev_ptr(x), x.stride(0), x.shape[0], x.shape[1], stream_ptr(x.device)), "mi_gelu")
     return x
 

@@ -94,8 +94,6 @@ class HipStackBackend:
         if dt not in _hip.DTYPE_CODES:
             raise RuntimeError(f"storage dtype {dt}: the HIP kernels take bfloat16 (tuned path), float16 and float32 "
                                "(generic path, csrc/generic.hip)")
-        if dt != torch.bfloat16 and model.vision_encoder is not None:
-            raise RuntimeError(f"the Pixtral vision tower runs on the bf16 kernels only; model dtype is {dt}")
         # bf16 models of a shape the tuned kernels take go through mi_forward; everything else - fp16 / fp32 storage
         # (reference transformer.py:303,338 keeps any dtype; its tests build fp32 models, tests/test_generate.py:51) and bf16
         # shapes mi_forward declines with MI_ERR_SHAPE - through mi_forward_generic with the reference's rounding points

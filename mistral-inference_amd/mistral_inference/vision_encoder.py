@@ -81,8 +81,7 @@ class VisionTransformer(nn.Module):
         self.transformer = VisionTransformerBlocks(args)
         head_dim = args.hidden_size // args.num_attention_heads
         assert head_dim % 2 == 0, "ROPE requires even head_dim"
-        if head_dim not in (64, 128):
-            raise NotImplementedError(f"vision head_dim {head_dim}: the attention kernels take 128 (or 64, zero-padded)")
+        self._head_dim = head_dim  # bf16: the MFMA attention takes 128 (64 zero-padded); fp16 / fp32: any head dim <= 256
         self._rope_cs: Optional[torch.Tensor] = None
         self._conv_w: Optional[torch.Tensor] = None  # K-padded image of patch_conv.weight (rebuilt after a reload)
 
@@ -100,16 +99,21 @@ class VisionTransformer(nn.Module):
         side = self.max_patches_per_side
         return precompute_freqs_cis_2d(a.hidden_size // a.num_attention_heads, side, side, a.rope_theta).to(self.device)
 
-    def _rope_table(self) -> torch.Tensor:
-        """fp32 [side*side, 64, 2]: (cos, sin) of the head's real pairs, identity for the zero-padded ones."""
-        if self._rope_cs is None or self._rope_cs.device != self.device:
+    def _rope_table(self, padded: bool = True) -> torch.Tensor:
+        """fp32 [side*side, 64, 2]: (cos, sin) of the head's real pairs, identity for the zero-padded ones (bf16 kernels);
+        `padded=False`: [side*side, head_dim/2, 2], the real pairs only (generic kernels: heads keep their own width)."""
+        key = "p" if padded else "r"
+        if self._rope_cs is None or self._rope_cs[0] != (key, self.device):
             side = self.max_patches_per_side
             real = torch.view_as_real(self.freqs_cis).reshape(side * side, -1, 2)  # [side^2, head_dim/2, 2]
-            cs = torch.zeros((side * side, 64, 2), dtype=torch.float32, device=self.device)
-            cs[:, :, 0] = 1.0
-            cs[:, : real.shape[1]] = real
-            self._rope_cs = cs.contiguous()
-        return self._rope_cs
+            if padded:
+                cs = torch.zeros((side * side, 64, 2), dtype=torch.float32, device=self.device)
+                cs[:, :, 0] = 1.0
+                cs[:, : real.shape[1]] = real
+            else:
+                cs = real.to(torch.float32)
+            self._rope_cs = ((key, self.device), cs.contiguous())
+        return self._rope_cs[1]
 
     def forward(self, images: List[torch.Tensor]) -> torch.Tensor:
         """images: list of [C, H, W] tensors (H, W multiples of the patch size) -> [sum of patches, hidden]."""
@@ -138,20 +142,27 @@ class VisionTransformer(nn.Module):
         T = x.shape[0]
         pos = position_meshgrid(grids)
         pos_id = (pos[:, 0] * self.max_patches_per_side + pos[:, 1]).to(device=dev, dtype=torch.int32)
-        cs = self._rope_table()
+        generic = x.dtype != torch.bfloat16   # fp16 / fp32 storage: csrc/generic.hip takes the heads as they are
+        if not generic and dh not in (64, 128):
+            raise NotImplementedError(f"vision head_dim {dh}: the bf16 attention kernels take 128 (or 64, zero-padded)")
+        cs = self._rope_table(padded=not generic)
         for blk in self.transformer.layers:
             at = blk.attention
             xn = _hip.rmsnorm(x, blk.attention_norm.weight, 1e-5)
             qkv = _hip.linear(xn, (at.wq.weight, at.wk.weight, at.wv.weight), _hip.EPI_STORE)  # [T, 3*H*dh]
-            if dh != 128:  # zero-pad every head to the kernels' 128 columns
-                pad = torch.zeros((T, 3 * H, 128), dtype=qkv.dtype, device=dev)
-                pad[:, :, :dh] = qkv.view(T, 3 * H, dh)
-                qkv = pad.view(T, 3 * H * 128)
-            _hip.rope_inplace(qkv, H, H, 128, cs, pos_id)
-            att = _hip.attn_prefill(qkv, H, H, 128, None, None, T, None, None, 1, T, causal=False,
-                                    softmax_scale=dh ** -0.5)
-            if dh != 128:
-                att = att.view(T, H, 128)[:, :, :dh].reshape(T, H * dh).contiguous()
+            if generic:
+                _hip.rope_inplace(qkv, H, H, dh, cs, pos_id)
+                att = _hip.attn_prefill(qkv, H, H, dh, None, None, T, None, None, 1, T, causal=False, softmax_scale=dh ** -0.5)
+            else:
+                if dh != 128:  # zero-pad every head to the kernels' 128 columns
+                    pad = torch.zeros((T, 3 * H, 128), dtype=qkv.dtype, device=dev)
+                    pad[:, :, :dh] = qkv.view(T, 3 * H, dh)
+                    qkv = pad.view(T, 3 * H * 128)
+                _hip.rope_inplace(qkv, H, H, 128, cs, pos_id)
+                att = _hip.attn_prefill(qkv, H, H, 128, None, None, T, None, None, 1, T, causal=False,
+                                        softmax_scale=dh ** -0.5)
+                if dh != 128:
+                    att = att.view(T, H, 128)[:, :, :dh].reshape(T, H * dh).contiguous()
             x = _hip.linear(att, (at.wo.weight,), _hip.EPI_RESIDUAL, residual=x)
             ff = blk.feed_forward
             xn = _hip.rmsnorm(x, blk.ffn_norm.weight, 1e-5)
