@@ -221,9 +221,11 @@ def test_fails_loudly_off_device(tmp_path):
     m = Transformer.from_folder(folder, max_batch_size=2, device="cpu", dtype=BF)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.forward(torch.tensor([1, 2, 3]), [3])
-    m32 = Transformer.from_folder(folder, max_batch_size=2, device="cuda", dtype=torch.float32)
-    with pytest.raises(RuntimeError, match="bf16"):
-        m32.forward(torch.tensor([1, 2, 3], device="cuda"), [3])
+    # storage dtypes: bf16 (tuned kernels), fp16 and fp32 (generic kernels, tests/test_gpu_generic.py) run; anything else is
+    # refused at the first forward instead of being converted behind the caller's back
+    m64 = Transformer.from_folder(folder, max_batch_size=2, device="cuda", dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="storage dtype"):
+        m64.forward(torch.tensor([1, 2, 3], device="cuda"), [3])
 
 
 def test_decode_batch_larger_than_gemv_limit(tmp_path):
