@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void g_gemm_mfma_kernel(GLinearArgs g) {
 }
 
 // M <= 8 rows, K a multiple of 8: one wave per TWO weight rows - two adjacent output columns, or (SwiGLU) the gate and the up
-// row of ONE output column -, two 512-element slabs of each row per iteration (four independent 16-byte weight loads per lane
-// in flight; the activation rows come out of L1 / L2).  Optional prologue: RMSNorm of the rows (transformer_layers.py:115-120,
+// row of ONE output column -, rows walked in chunks of 4 pieces per lane (eight independent 16-byte weight loads per lane
+// in flight before anything waits; the activation rows come out of L1 / L2).  Optional prologue: RMSNorm of the rows (transformer_layers.py:115-120,
 // every wave recomputes the 1 / rms of its M rows - 8 KB of L1-resident reads against 16+ KB of streamed weights), which
 // removes a launch and a round trip of the normalised row per contraction.  Output columns may come from up to three weight
 // matrices (q | k | v in one launch).
@@ -355,10 +355,22 @@ __device__ __forceinline__ const T* g_seg_row(const GLinearArgs& g, int n) {
   return reinterpret_cast<const T*>(g.w2) + (size_t)(n - g.n1) * g.K;
 }
 
-template <typename T, int EPI>
+// 16-byte pieces: EPP elements of T (8 of a 16-bit type, 4 floats)
+template <typename T>
+__device__ __forceinline__ void g_cvt_piece(const u32x4& raw, float (&o)[16 / sizeof(T)]) {
+  constexpr int EPP = 16 / (int)sizeof(T);
+  T tmp[EPP];
+  __builtin_memcpy(tmp, &raw, 16);
+#pragma unroll
+  for (int i = 0; i < EPP; ++i) o[i] = St<T>::ld(&tmp[i]);
+}
+
+template <typename T, int EPI, int MR>  // MR = rows compiled in (1, 2, 4, 8 >= M; the surplus rows repeat row M - 1 and are not stored)
 __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
   constexpr int NC = 2;
   constexpr bool SW = EPI == G_EPI_SWIGLU;
+  constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  constexpr int UNR = MR <= 2 ? 4 : 2;      // pieces per lane and row in flight: 2 x UNR x 16 B of weights per lane
   const int lane = threadIdx.x & 63;
   const int wv_id = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n0 = SW ? wv_id : wv_id * NC;
@@ -378,71 +390,87 @@ __global__ __launch_bounds__(256) void g_gemv_kernel(GLinearArgs g) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) wr[c] = g_seg_row<T>(g, min(n0 + c, g.N - 1));
   }
-  float inv[8];
+  const int PR = g.K / EPP;  // pieces per row (K % 8 == 0)
+  // ---- 1 / rms of every row (fused RMSNorm): UNR independent loads per lane and round trip
+  float inv[MR];
+  const T* xrow[MR];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) inv[m] = 1.f;
+  for (int m = 0; m < MR; ++m) {
+    inv[m] = 1.f;
+    xrow[m] = x + (size_t)min(m, g.M - 1) * g.ldx;
+  }
   if (nw) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < g.M) {
+    for (int m = 0; m < MR; ++m) {
+      {
         float ss = 0.f;
-        for (int k = lane * 8; k < g.K; k += 512) {
-          float xv[8];
-          St<T>::ld8(x + (size_t)m * g.ldx + k, xv);
+        for (int p0 = lane; p0 < PR; p0 += 64 * UNR) {
+          u32x4 raw[UNR];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ss = fmaf(xv[i], xv[i], ss);
+          for (int u = 0; u < UNR; ++u) raw[u] = ld16(xrow[m] + (size_t)min(p0 + 64 * u, PR - 1) * EPP);
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            float xv[EPP];
+            g_cvt_piece<T>(raw[u], xv);
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) s1 = fmaf(xv[i], xv[i], s1);
+            ss += (p0 + 64 * u < PR) ? s1 : 0.f;
+          }
         }
         ss = wave_sum_f(ss);
         inv[m] = 1.0f / sqrtf(ss / (float)g.K + g.eps);
       }
     }
   }
-  float acc[NC][8];
+  float acc[NC][MR];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc[c][m] = 0.f;
-  for (int k = lane * 8; k < g.K; k += 2 * 512) {
-    const bool in1 = k + 512 < g.K;
-    const int k1 = in1 ? k + 512 : k;  // (clamped; its weights are zeroed)
-    float wv[NC][2][8];
+    for (int m = 0; m < MR; ++m) acc[c][m] = 0.f;
+  // ---- the contraction: all 2 x UNR weight pieces of a chunk are issued before anything waits (clamped addresses, the
+  // pieces past the row's end contribute zero), then the activation pieces row by row out of L1 / L2
+  for (int p0 = lane; p0 < PR; p0 += 64 * UNR) {
+    u32x4 wraw[NC][UNR], nraw[UNR];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      St<T>::ld8(wr[c] + k, wv[c][0]);
-      St<T>::ld8(wr[c] + k1, wv[c][1]);
+    for (int u = 0; u < UNR; ++u) {
+      const size_t off = (size_t)min(p0 + 64 * u, PR - 1) * EPP;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) wv[c][1][i] = in1 ? wv[c][1][i] : 0.f;
-    }
-    float n0v[8], n1v[8];
-    if (nw) {
-      St<T>::ld8(nw + k, n0v);
-      St<T>::ld8(nw + k1, n1v);
+      for (int c = 0; c < NC; ++c) wraw[c][u] = ld16_nt(wr[c] + off);
+      if (nw) nraw[u] = ld16(nw + off);
     }
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < g.M) {
-        float x0[8], x1[8];
-        St<T>::ld8(x + (size_t)m * g.ldx + k, x0);
-        St<T>::ld8(x + (size_t)m * g.ldx + k1, x1);
-        if (nw) {
+    for (int m = 0; m < MR; ++m) {
+      {
+        u32x4 xraw[UNR];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            x0[i] = St<T>::rnd(St<T>::rnd(x0[i] * inv[m]) * n0v[i]);
-            x1[i] = St<T>::rnd(St<T>::rnd(x1[i] * inv[m]) * n1v[i]);
+        for (int u = 0; u < UNR; ++u) xraw[u] = ld16(xrow[m] + (size_t)min(p0 + 64 * u, PR - 1) * EPP);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          float xv[EPP];
+          g_cvt_piece<T>(xraw[u], xv);
+          if (nw) {
+            float nv[EPP];
+            g_cvt_piece<T>(nraw[u], nv);
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) xv[i] = St<T>::rnd(St<T>::rnd(xv[i] * inv[m]) * nv[i]);
           }
-        }
+          const bool in = p0 + 64 * u < PR;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+          for (int i = 0; i < EPP; ++i) xv[i] = in ? xv[i] : 0.f;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[c][m] = fmaf(x0[i], wv[c][0][i], acc[c][m]);
+          for (int c = 0; c < NC; ++c) {
+            float wv[EPP];
+            g_cvt_piece<T>(wraw[c][u], wv);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[c][m] = fmaf(x1[i], wv[c][1][i], acc[c][m]);
+            for (int i = 0; i < EPP; ++i) acc[c][m] = fmaf(xv[i], wv[i], acc[c][m]);
+          }
         }
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < MR; ++m) {
     if (m < g.M) {
       const float v0 = wave_sum_f(acc[0][m]), v1 = wave_sum_f(acc[1][m]);
       if (lane == 0) {
@@ -828,7 +856,11 @@ hipError_t linear_t(const GLinearArgs& g, hipStream_t s) {
   const bool aligned = g.K % 8 == 0 && g.ldx % 8 == 0 && (reinterpret_cast<size_t>(g.x) & 15) == 0 && (reinterpret_cast<size_t>(g.w) & 15) == 0;
   const bool special = g.w1 || g.w2 || g.norm_w || EPI == G_EPI_SWIGLU;  // forms of the M <= 8 kernel only
   if (g.M <= 8 && aligned) {
-    hipLaunchKernelGGL((g_gemv_kernel<T, EPI>), dim3(EPI == G_EPI_SWIGLU ? (g.N + 3) / 4 : (g.N + 7) / 8), dim3(256), 0, s, g);
+    const dim3 grid(EPI == G_EPI_SWIGLU ? (g.N + 3) / 4 : (g.N + 7) / 8);
+    if (g.M == 1) hipLaunchKernelGGL((g_gemv_kernel<T, EPI, 1>), grid, dim3(256), 0, s, g);
+    else if (g.M == 2) hipLaunchKernelGGL((g_gemv_kernel<T, EPI, 2>), grid, dim3(256), 0, s, g);
+    else if (g.M <= 4) hipLaunchKernelGGL((g_gemv_kernel<T, EPI, 4>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((g_gemv_kernel<T, EPI, 8>), grid, dim3(256), 0, s, g);
   } else if (special) {
     return hipErrorInvalidValue;
   } else if constexpr (EPI == G_EPI_SWIGLU) {
