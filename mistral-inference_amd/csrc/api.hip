@@ -1007,9 +1007,17 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
       MI_TRY(hip_rc(launch_g_linear(dt, g, s), "norm + q|k|v"));
     } else {
       MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.attention_norm, T, D, m->norm_eps, s), "attention_norm"));
-      MI_TRY(linear(ws.xn, D, L.wq, ws.qkv, qkv_cols, nq, D, G_EPI_STORE, nullptr, nullptr, "wq"));
-      MI_TRY(linear(ws.xn, D, L.wk, ws.qkv + (size_t)nq * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wk"));
-      MI_TRY(linear(ws.xn, D, L.wv, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wv"));
+      GLinearArgs g;
+      memset(&g, 0, sizeof(g));
+      g.x = ws.xn; g.ldx = D; g.w = L.wq; g.w1 = L.wk; g.w2 = L.wv; g.n0 = nq; g.n1 = nq + nkv;
+      g.out = ws.qkv; g.ldo = qkv_cols; g.M = T; g.N = qkv_cols; g.K = D; g.epi = G_EPI_STORE;
+      if (g_linear_fused_ok(dt, g)) {  // (fp16, at least 256 rows: one launch of the 256-tile kernel)
+        MI_TRY(hip_rc(launch_g_linear(dt, g, s), "q|k|v"));
+      } else {
+        MI_TRY(linear(ws.xn, D, L.wq, ws.qkv, qkv_cols, nq, D, G_EPI_STORE, nullptr, nullptr, "wq"));
+        MI_TRY(linear(ws.xn, D, L.wk, ws.qkv + (size_t)nq * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wk"));
+        MI_TRY(linear(ws.xn, D, L.wv, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wv"));
+      }
     }
     MI_TRY(hip_rc(launch_g_rope(dt, ws.qkv, qkv_cols, T, nq + nkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
     // ---- attention over [surviving ring entries ++ this forward's keys], then the ring write (cache.py:83-117)
@@ -1021,6 +1029,7 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     a.causal = has_cache ? 1 : 0;
     a.scale = 1.0f / sqrtf((float)Dh);
     a.partial = ws.attn_partial;
+    a.B = has_cache ? B : 1; a.max_q_len = has_cache ? bt->max_q_len : T;
     MI_TRY(hip_rc(launch_g_attention(dt, a, s), "attention"));
     if (has_cache)
       MI_TRY(hip_rc(launch_g_kv_write(dt, ck, cv, W, ws.qkv + (size_t)nq * es, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, T, nkv,
@@ -1038,9 +1047,16 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
         MI_TRY(hip_rc(launch_g_linear(dt, g, s), "norm + w1|w3 + swiglu"));
       } else {
         MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
-        MI_TRY(linear(ws.xn, D, L.w1, ws.a, F, F, D, G_EPI_STORE, nullptr, nullptr, "w1"));
-        MI_TRY(linear(ws.xn, D, L.w3, ws.b, F, F, D, G_EPI_STORE, nullptr, nullptr, "w3"));
-        MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, nullptr, s), "swiglu"));
+        GLinearArgs g;
+        memset(&g, 0, sizeof(g));
+        g.x = ws.xn; g.ldx = D; g.w = L.w1; g.w1 = L.w3; g.out = ws.a; g.ldo = F; g.M = T; g.N = F; g.K = D; g.epi = G_EPI_SWIGLU;
+        if (g_linear_fused_ok(dt, g)) {
+          MI_TRY(hip_rc(launch_g_linear(dt, g, s), "w1|w3 + swiglu"));
+        } else {
+          MI_TRY(linear(ws.xn, D, L.w1, ws.a, F, F, D, G_EPI_STORE, nullptr, nullptr, "w1"));
+          MI_TRY(linear(ws.xn, D, L.w3, ws.b, F, F, D, G_EPI_STORE, nullptr, nullptr, "w3"));
+          MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, nullptr, s), "swiglu"));
+        }
       }
       MI_TRY(linear(ws.a, F, L.w2, h, D, D, F, G_EPI_RESIDUAL, h, nullptr, "w2"));
     } else {

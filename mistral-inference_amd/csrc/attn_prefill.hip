@@ -26,6 +26,28 @@
 #include "common.cuh"
 #include "kernels.h"
 
+// A second compile with -DATTN_F16=1 (build_native.py: attn_prefill_f16.o) is the same kernel for fp16 storage: the MFMA
+// opcode (v_mfma_f32_32x32x16_f16), P rounded to fp16 instead of bf16 for P.V (what fp16 flash kernels do), fp16 output
+// packing; entry point launch_attn_prefill_f16 (generic.hip: prefills of fp16 models with 128-wide heads).  The default
+// compile is untouched by this block.
+#ifndef ATTN_F16
+#define ATTN_F16 0
+#endif
+#if ATTN_F16
+typedef _Float16 attn_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t attn_h_pack2(float lo, float hi) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)hi) << 16);
+}
+#define bf16x8 attn_f16x8
+#define cvt_pk_bf16 attn_h_pack2
+#define pack_bf2 attn_h_pack2
+#define ATTN_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define launch_attn_prefill launch_attn_prefill_f16
+#define attn_prefill_set_mode attn_prefill_set_mode_f16
+#else
+#define ATTN_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+
 #ifndef ATT_PRIO
 #define ATT_PRIO 0  // experiment switch: 1 = s_setprio(1) around the two MFMA clusters, 2 = static priority 1 for waves 4..7
 #endif
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
         for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb)
-            st[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[k4][mb], qf[kh * 4 + k4], st[mb], 0, 0, 0);
+            st[mb] = ATTN_MFMA(kf[k4][mb], qf[kh * 4 + k4], st[mb], 0, 0, 0);
         if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       }
       // ---- mask, online softmax (this lane: query ql, keys of its half).  Scores stay RAW (unscaled): the
@@ -292,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
             const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
             const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
             u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
-            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, acc[dt], 0, 0, 0);
+            acc[dt] = ATTN_MFMA(__builtin_bit_cast(bf16x8, vw), pf, acc[dt], 0, 0, 0);
           }
         }
       if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);

@@ -28,6 +28,47 @@
 #include "common.cuh"
 #include "kernels.h"
 
+// A second compile of this file with -DG256_F16=1 (build_native.py: gemm256_f16.o) is the SAME kernel for fp16 storage - the
+// data movement of two 16-bit types is identical; what changes is the MFMA opcode (v_mfma_f32_16x16x32_f16) and the half
+// conversions / rounding points of the epilogues - under the entry points launch_gemm256_f16 & co., used by the generic
+// storage path (generic.hip) for prefills of fp16 models.  The default compile is untouched by this block (its ISA hash is
+// checked like the decode engine's).
+#ifndef G256_F16
+#define G256_F16 0
+#endif
+#if G256_F16
+typedef _Float16 g256_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float g256_h_to_f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t g256_h_from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float g256_h_round(float f) { return (float)(_Float16)f; }
+__device__ __forceinline__ uint32_t g256_h_pack2(float lo, float hi) {
+  return (uint32_t)g256_h_from_f(lo) | ((uint32_t)g256_h_from_f(hi) << 16);
+}
+__device__ __forceinline__ float g256_h_lo(uint32_t u) { return g256_h_to_f((uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float g256_h_hi(uint32_t u) { return g256_h_to_f((uint16_t)(u >> 16)); }
+__device__ __forceinline__ float g256_h_swiglu(float acc1, float acc3) {  // swiglu_bf_fast with fp16 rounding points
+  const float a = g256_h_round(acc1), b = g256_h_round(acc3);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a);
+  const float s = g256_h_round(a * __builtin_amdgcn_rcpf(1.0f + e));
+  return s * b;
+}
+#define bf_round g256_h_round
+#define pack_bf2 g256_h_pack2
+#define f_to_bf g256_h_from_f
+#define bf_to_f g256_h_to_f
+#define bf_lo g256_h_lo
+#define bf_hi g256_h_hi
+#define swiglu_bf_fast g256_h_swiglu
+#define bf16x8 g256_f16x8
+#define G256_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define gemm256_applicable gemm256_applicable_f16
+#define gemm256_half_applicable gemm256_half_applicable_f16
+#define launch_gemm256_half launch_gemm256_half_f16
+#define launch_gemm256 launch_gemm256_f16
+#else
+#define G256_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+
 // Build-time experiment switches (all off in the shipped build; the experimental main loops live OUTSIDE the product tree, in scripts/probes/gemm256_experiments.inc):
 #ifndef G256_PRIO
 #define G256_PRIO 0
@@ -218,8 +259,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmArgs g) {
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-    acc[HA][HB][i][j] = kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ks][j], af[ks][i], acc[HA][HB][i][j], 0, 0, 0) \
-                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], BF[ks][j], acc[HA][HB][i][j], 0, 0, 0);
+    acc[HA][HB][i][j] = kSwap ? G256_MFMA(BF[ks][j], af[ks][i], acc[HA][HB][i][j], 0, 0, 0) \
+                              : G256_MFMA(af[ks][i], BF[ks][j], acc[HA][HB][i][j], 0, 0, 0);
 
   const int nk = g.K / BK;
   if constexpr (MH == 1) {

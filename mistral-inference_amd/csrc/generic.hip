@@ -21,6 +21,7 @@
 //     position % W, newer ones from the post-RoPE activation rows (same visibility rule as attn_prefill.hip), so the one
 //     kernel serves first prefills, later chunks, decode steps and the cache=None call.
 #include <cstdlib>
+#include <cstring>
 
 #include "common.cuh"
 #include "kernels.h"
@@ -912,8 +913,54 @@ hipError_t launch_g_rmsnorm(int dt, void* out, const void* x, const void* w, int
   G_DISPATCH(dt, hipLaunchKernelGGL((g_rmsnorm_kernel<T>), dim3(T_rows), dim3(256), 0, s, (T*)out, (const T*)x, (const T*)w, D, eps))
 }
 
+// fp16 prefills of at least 256 rows: the tuned 256 x 256 8-phase MFMA kernel, compiled a second time for fp16 payloads
+// (gemm256.hip, -DG256_F16=1: same DMA / LDS / barrier schedule, v_mfma_f32_16x16x32_f16, half rounding points).  It also
+// takes the multi-matrix (q | k | v) and the fused SwiGLU forms.  MI_GENERIC_G256=0 keeps everything on the kernels above.
+static bool g256_f16_args(const GLinearArgs& g, GemmArgs& a) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MI_GENERIC_G256");
+    on = e ? atoi(e) : 1;
+  }
+  if (!on || g.active || g.norm_w || g.M < 256) return false;
+  if (g.ldx % 8 || (reinterpret_cast<size_t>(g.x) & 15) || (reinterpret_cast<size_t>(g.w) & 15)) return false;
+  memset(&a, 0, sizeof(a));
+  a.M = g.M; a.N = g.N; a.K = g.K; a.a = reinterpret_cast<const bf16_t*>(g.x); a.lda = g.ldx;
+  a.out = g.out; a.ldo = g.ldo;
+  a.w0 = reinterpret_cast<const bf16_t*>(g.w);
+  switch (g.epi) {
+    case G_EPI_STORE: a.epi = GEMM_STORE; break;
+    case G_EPI_RESIDUAL:
+      if (g.ldr != g.ldo) return false;
+      a.epi = GEMM_RESIDUAL; a.residual = reinterpret_cast<const bf16_t*>(g.residual); break;
+    case G_EPI_LOGITS: a.epi = GEMM_LOGITS; break;
+    case G_EPI_SWIGLU: a.epi = GEMM_SWIGLU; break;
+    default: return false;
+  }
+  if (g.epi == G_EPI_SWIGLU) {
+    if (!g.w1) return false;
+    a.w1 = reinterpret_cast<const bf16_t*>(g.w1); a.n0 = a.n1 = g.N;
+  } else if (g.w1) {
+    a.w1 = reinterpret_cast<const bf16_t*>(g.w1); a.w2 = reinterpret_cast<const bf16_t*>(g.w2);
+    a.n0 = g.n0; a.n1 = g.w2 ? g.n1 : g.N;
+  } else {
+    a.n0 = a.n1 = g.N;
+  }
+  return gemm256_applicable_f16(a);
+}
+
+bool g_linear_fused_ok(int dt, const GLinearArgs& g) {
+  if (g_gemv_takes(g.M, g.K, g.ldx)) return true;
+  GemmArgs a;
+  return dt == G_DT_FP16 && g256_f16_args(g, a);
+}
+
 hipError_t launch_g_linear(int dt, const GLinearArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
+  if (dt == G_DT_FP16) {
+    GemmArgs a;
+    if (g256_f16_args(g, a)) return launch_gemm256_f16(a, s);
+  }
   switch (dt) {
     case G_DT_BF16: return linear_e<sbf16>(g, s);
     case G_DT_FP16: return linear_e<_Float16>(g, s);
@@ -936,6 +983,24 @@ hipError_t launch_g_kv_write(int dt, void* ck, void* cv, int W, const void* k, c
 
 hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s) {
   if (a.Dh > 256 || a.H % a.Hkv) return hipErrorInvalidValue;
+  // fp16 prefills with 128-wide heads: the tuned MFMA flash kernel compiled for fp16 payloads (attn_prefill.hip, -DATTN_F16=1;
+  // P is rounded to fp16 for P.V as fp16 flash kernels do).  MI_GENERIC_ATTN_MFMA=0 keeps the fp32-P kernel below.
+  static int mfma_on = -1;
+  if (mfma_on < 0) {
+    const char* e = getenv("MI_GENERIC_ATTN_MFMA");
+    mfma_on = e ? atoi(e) : 1;
+  }
+  if (mfma_on && dt == G_DT_FP16 && a.Dh == 128 && a.T >= 128 && a.B > 0 && a.max_q_len > 0 && a.ld % 8 == 0 &&
+      ((reinterpret_cast<size_t>(a.qkv) | reinterpret_cast<size_t>(a.cache_k) | reinterpret_cast<size_t>(a.cache_v) |
+        reinterpret_cast<size_t>(a.out)) & 15) == 0 &&
+      (size_t)a.W * a.Hkv * a.Dh < (1ull << 31) && (size_t)a.T * (size_t)a.ld < (1ull << 31)) {
+    AttnPrefillArgs p;
+    p.out = a.out; p.qkv = reinterpret_cast<const bf16_t*>(a.qkv); p.ld = a.ld;
+    p.cache_k = reinterpret_cast<const bf16_t*>(a.cache_k); p.cache_v = reinterpret_cast<const bf16_t*>(a.cache_v);
+    p.W = a.W; p.B = a.B; p.max_q_len = a.max_q_len; p.H = a.H; p.Hkv = a.Hkv; p.Dh = a.Dh;
+    p.q_start = a.q_start; p.kv_before = a.kv_before; p.causal = a.causal; p.scale = a.scale;
+    return launch_attn_prefill_f16(p, s);
+  }
   G_DISPATCH(dt, attention_t<T>(a, s))
 }
 

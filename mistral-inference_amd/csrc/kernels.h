@@ -100,6 +100,9 @@ hipError_t launch_gemm256(const GemmArgs& g, hipStream_t s);
 bool gemm256_half_applicable(const GemmArgs& g);  // 128x256 tiles of the same kernel: the columns of a half-filled last round
 hipError_t launch_gemm256_half(const GemmArgs& g, hipStream_t s);
 void gemm_set_tail_mode(int mode);  // mi_debug_set_prefill_kernels
+// gemm256.hip compiled with -DG256_F16=1: the same kernel on fp16 payloads (generic.hip: prefills of fp16 models)
+bool gemm256_applicable_f16(const GemmArgs& g);
+hipError_t launch_gemm256_f16(const GemmArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- attention
 struct AttnDecodeArgs {
@@ -134,6 +137,7 @@ struct AttnPrefillArgs {
 };
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s);
 void attn_prefill_set_mode(int waves);  // mi_debug_set_prefill_kernels (negative: keep)
+hipError_t launch_attn_prefill_f16(const AttnPrefillArgs& a, hipStream_t s);  // attn_prefill.hip compiled with -DATTN_F16=1
 
 // Compute units of the current device (256 on a full MI355X; fewer in partitioned modes).  Grid-shaping heuristics
 // (rounds of blocks, tail splitting) use it; results never depend on it.
@@ -337,10 +341,12 @@ struct GAttnArgs {
   int causal;            // 0: the cache=None call (every token sees every token, transformer_layers.py:165)
   float scale;
   float* partial;        // scratch of g_attn_partial_floats(T, H, Dh) floats: launches with few (token, head) pairs split the keys
+  int B, max_q_len;      // sequences / longest new-token run of the forward (0: unknown - the MFMA prefill route is not taken)
 };
 size_t g_elem_bytes(int dt);
 size_t g_attn_partial_floats(int T, int H, int Dh);
 bool g_gemv_takes(int M, int K, int ldx);  // the M <= 8 kernel (fused norm / multi-matrix / SwiGLU forms) applies
+bool g_linear_fused_ok(int dt, const GLinearArgs& g);  // a multi-matrix / SwiGLU request has a kernel (M <= 8 rows, or fp16 with >= 256 rows)
 hipError_t launch_g_embedding(int dt, void* out, const void* table, const int64_t* ids, int T, int D, int vocab, uint32_t* bad_id,
                               hipStream_t s);
 hipError_t launch_g_rmsnorm(int dt, void* out, const void* x, const void* w, int T, int D, float eps, hipStream_t s);
