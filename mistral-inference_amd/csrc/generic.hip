@@ -14,12 +14,16 @@
 // configurations are all bf16 and run on the tuned kernels (gemv_core.cuh, gemm256.hip, decode_engine.hip, ...).
 //   * linear, more than 8 rows: 128 x 128 tiles on the matrix cores (v_mfma_f32_32x32x16 f16 / bf16, v_mfma_f32_32x32x2 f32),
 //     operands staged through LDS in the storage type; rows that are not 16-byte aligned: a 64 x 64 fp32-FMA tile kernel;
-//   * linear, up to 8 rows (decode): one wave per two output columns, 16-byte weight loads (four in flight per lane), lanes
-//     stride K, wave reduction;
-//   * attention: one block per (query token, head); four waves split the visible keys, 64 lanes span the head dimension
-//     (coalesced K / V rows, score by wave reduction), per-wave online softmax merged at the end.  Keys older than this forward come from the ring at slot
-//     position % W, newer ones from the post-RoPE activation rows (same visibility rule as attn_prefill.hip), so the one
-//     kernel serves first prefills, later chunks, decode steps and the cache=None call.
+//     fp16 with at least 256 rows: the tuned 256 x 256 8-phase kernel itself, compiled for fp16 payloads (gemm256.hip);
+//   * linear, up to 8 rows (decode): one wave per two weight rows, templated on the row count, eight 16-byte weight loads per
+//     lane issued before anything waits, lanes stride K, wave reduction; fused forms: RMSNorm prologue, q | k | v from three
+//     matrices, gate | up | SiLU | product;
+//   * attention: one block per (query token, head); 4 or 16 waves split the visible keys, 64 lanes span the head dimension
+//     (one coalesced load per K / V row, score by wave reduction), per-wave online softmax merged at the end; launches with
+//     few (token, head) pairs also split the keys over blocks and merge in a second launch.  Keys older than this forward
+//     come from the ring at slot position % W, newer ones from the post-RoPE activation rows (same visibility rule as
+//     attn_prefill.hip), so the one kernel serves first prefills, later chunks, decode steps and the cache=None call; fp16
+//     prefills with 128-wide heads: the MFMA flash kernel itself, compiled for fp16 payloads (attn_prefill.hip).
 #include <cstdlib>
 #include <cstring>
 
