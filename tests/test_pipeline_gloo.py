@@ -185,7 +185,7 @@ def _interleaved_case(world):
     return params, w, prompts
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_interleaved_decoder_one_sequence_per_stage(world):
     """pipeline_decode.InterleavedDecoder over gloo: `world` sequences through `world` stages, every stage busy on a different
     sequence each tick.  Tokens and log-probabilities of EVERY sequence equal decoding it alone in one process (the oracle's
