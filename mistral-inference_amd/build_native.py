@@ -29,7 +29,8 @@ PER_FILE_FLAGS = {"decode_engine.hip": os.environ.get("MI_ENGINE_FLAGS", "-mllvm
 VARIANT_OBJECTS = {"decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
                    "decode_engine_moe.o": ("decode_engine.hip", ["-DENG_WIDE=2"]),    # 8-fill ring, MoE GQA 4 (Mixtral-8x7B)
                    "gemm256_f16.o": ("gemm256.hip", ["-DG256_F16=1"]),                # the 256-tile GEMM on fp16 payloads (generic path)
-                   "attn_prefill_f16.o": ("attn_prefill.hip", ["-DATTN_F16=1"])}      # the MFMA prefill attention on fp16 payloads
+                   "attn_prefill_f16.o": ("attn_prefill.hip", ["-DATTN_F16=1"]),      # the MFMA prefill attention on fp16 payloads
+                   "gemv_f16.o": ("gemv.hip", ["-DGEMV_F16=1"])}                      # the weight-streaming GEMV kernels on fp16 payloads
 
 
 def _hipcc() -> str:

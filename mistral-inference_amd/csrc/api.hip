@@ -987,6 +987,30 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
   // T <= 8 (decode steps, tiny prompts): the row kernel's fused forms - RMSNorm in the prologue, q | k | v in one launch,
   // gate / up / SiLU / product in one launch: 8 launches per dense layer instead of 13
   const bool rows = g_gemv_takes(T, D, D);
+  // ... and for fp16 those launches are the TUNED weight-streaming kernels themselves (gemv.hip compiled for fp16 payloads,
+  // launch_gemv_f16): RMSNorm + q | k | v + RoPE in one launch, Wo / W2 with the residual, RMSNorm + gate | up + SiLU, the LM
+  // head - the launch path of mi_forward minus its bf16 attention kernels.  MI_GENERIC_GEMV_TUNED=0: the generic row kernel.
+  static int tuned_rows = -1;
+  if (tuned_rows < 0) {
+    const char* e = getenv("MI_GENERIC_GEMV_TUNED");
+    tuned_rows = e ? atoi(e) : 1;
+  }
+  const bool rows16 = rows && dt == G_DT_FP16 && tuned_rows != 0 && Dh % 2 == 0;
+  auto gemv16 = [&](GemvArgs a, const char* what) -> int {  // gemv_passes for the fp16 compile
+    const int cap = gemv_max_tokens_f16(a.K);
+    const size_t out_elt = (a.mode == GEMV_LOGITS) ? 4 : 2;
+    for (int t0 = 0; t0 < T; t0 += cap) {
+      GemvArgs p = a;
+      p.T = (T - t0 < cap) ? T - t0 : cap;
+      p.x = a.x + (size_t)t0 * a.ldx;
+      p.out = (char*)a.out + (size_t)t0 * a.ldo * out_elt;
+      if (a.residual) p.residual = a.residual + (size_t)t0 * a.ldo;
+      if (a.tok_pos) p.tok_pos = a.tok_pos + t0;
+      if (a.tok_seq) p.tok_seq = a.tok_seq + t0;
+      MI_TRY(hip_rc(launch_gemv_f16(p, s), what));
+    }
+    return MI_OK;
+  };
 
   if (branch == MI_BRANCH_DECODE)
     MI_TRY(hip_rc(launch_decode_prep(bt->kv_seqlens, bt->q_start, bt->kv_before, bt->tok_seq, bt->tok_pos, B, ws.ctrl, s), "decode_prep"));
@@ -999,7 +1023,17 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     void* ck = has_cache ? bt->cache_k[l] : nullptr;
     void* cv = has_cache ? bt->cache_v[l] : nullptr;
     // ---- attention_norm, q | k | v, RoPE (transformer_layers.py:66-70)
-    if (rows) {
+    if (rows16) {
+      GemvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.mode = GEMV_QKV_ROPE; a.K = D; a.N = qkv_cols; a.x = (const bf16_t*)h; a.ldx = D;
+      a.norm_w = (const bf16_t*)L.attention_norm; a.eps = m->norm_eps;
+      a.w0 = (const bf16_t*)L.wq; a.w1 = (const bf16_t*)L.wk; a.w2 = (const bf16_t*)L.wv; a.n0 = nq; a.n1 = nq + nkv;
+      a.out = ws.qkv; a.ldo = qkv_cols;
+      a.rope_cs = m->rope_cs; a.tok_pos = bt->tok_pos; a.tok_seq = bt->tok_seq; a.head_dim = Dh;
+      a.write_kv = 0;  // (the ring write follows the attention here: g_kv_write below)
+      MI_TRY(gemv16(a, "norm + q|k|v + rope (fp16 gemv)"));
+    } else if (rows) {
       GLinearArgs g;
       memset(&g, 0, sizeof(g));
       g.x = h; g.ldx = D; g.w = L.wq; g.w1 = L.wk; g.w2 = L.wv; g.n0 = nq; g.n1 = nq + nkv; g.norm_w = L.attention_norm; g.eps = m->norm_eps;
@@ -1019,7 +1053,7 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
         MI_TRY(linear(ws.xn, D, L.wv, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, nkv, D, G_EPI_STORE, nullptr, nullptr, "wv"));
       }
     }
-    MI_TRY(hip_rc(launch_g_rope(dt, ws.qkv, qkv_cols, T, nq + nkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
+    if (!rows16) MI_TRY(hip_rc(launch_g_rope(dt, ws.qkv, qkv_cols, T, nq + nkv, Dh, m->rope_cs, bt->tok_pos, s), "rope"));
     // ---- attention over [surviving ring entries ++ this forward's keys], then the ring write (cache.py:83-117)
     GAttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -1035,11 +1069,30 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
       MI_TRY(hip_rc(launch_g_kv_write(dt, ck, cv, W, ws.qkv + (size_t)nq * es, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, T, nkv,
                                       bt->tok_seq, bt->tok_pos, bt->q_start, s), "kv_write"));
     // ---- h = h + wo(attn)
-    MI_TRY(linear(ws.attn, nq, L.wo, h, D, D, nq, G_EPI_RESIDUAL, h, nullptr, "wo"));
+    if (rows16) {
+      GemvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.mode = GEMV_RESIDUAL; a.K = nq; a.N = D; a.x = (const bf16_t*)ws.attn; a.ldx = nq;
+      a.w0 = (const bf16_t*)L.wo; a.n0 = a.n1 = D; a.out = h; a.ldo = D; a.residual = (const bf16_t*)h;
+      MI_TRY(gemv16(a, "wo (fp16 gemv)"));
+    } else {
+      MI_TRY(linear(ws.attn, nq, L.wo, h, D, D, nq, G_EPI_RESIDUAL, h, nullptr, "wo"));
+    }
     // ---- h = h + FFN(ffn_norm(h))
     if (m->num_experts == 0) {
       if (!L.w1 || !L.w2 || !L.w3) return fail(MI_ERR_ARG, "mi_forward_generic: dense layer without w1/w2/w3");
-      if (rows) {
+      if (rows16) {
+        GemvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_SWIGLU; a.K = D; a.N = F; a.x = (const bf16_t*)h; a.ldx = D;
+        a.norm_w = (const bf16_t*)L.ffn_norm; a.eps = m->norm_eps;
+        a.w0 = (const bf16_t*)L.w1; a.w1 = (const bf16_t*)L.w3; a.n0 = a.n1 = F; a.out = ws.a; a.ldo = F;
+        MI_TRY(gemv16(a, "norm + w1|w3 + swiglu (fp16 gemv)"));
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_RESIDUAL; a.K = F; a.N = D; a.x = (const bf16_t*)ws.a; a.ldx = F;
+        a.w0 = (const bf16_t*)L.w2; a.n0 = a.n1 = D; a.out = h; a.ldo = D; a.residual = (const bf16_t*)h;
+        MI_TRY(gemv16(a, "w2 (fp16 gemv)"));
+      } else if (rows) {
         GLinearArgs g;
         memset(&g, 0, sizeof(g));
         g.x = h; g.ldx = D; g.w = L.w1; g.w1 = L.w3; g.norm_w = L.ffn_norm; g.eps = m->norm_eps;
@@ -1058,7 +1111,7 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
           MI_TRY(hip_rc(launch_g_swiglu(dt, ws.a, ws.b, T, F, nullptr, s), "swiglu"));
         }
       }
-      MI_TRY(linear(ws.a, F, L.w2, h, D, D, F, G_EPI_RESIDUAL, h, nullptr, "w2"));
+      if (!rows16) MI_TRY(linear(ws.a, F, L.w2, h, D, D, F, G_EPI_RESIDUAL, h, nullptr, "w2"));
     } else {
       MI_TRY(hip_rc(launch_g_rmsnorm(dt, ws.xn, h, L.ffn_norm, T, D, m->norm_eps, s), "ffn_norm"));
       // moe.py:24-32: experts in ascending id, each adding round(weight * expert(x)) for the rows that picked it
@@ -1084,7 +1137,14 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
 
   if (m->final_norm) {
     if (bt->logits) {
-      if (rows) {
+      if (rows16) {
+        GemvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = GEMV_LOGITS; a.K = D; a.N = m->vocab_size; a.x = (const bf16_t*)h; a.ldx = D;
+        a.norm_w = (const bf16_t*)m->final_norm; a.eps = m->norm_eps;
+        a.w0 = (const bf16_t*)m->output; a.n0 = a.n1 = m->vocab_size; a.out = bt->logits; a.ldo = m->vocab_size;
+        MI_TRY(gemv16(a, "final norm + lm head (fp16 gemv)"));
+      } else if (rows) {
         GLinearArgs g;
         memset(&g, 0, sizeof(g));
         g.x = h; g.ldx = D; g.w = m->output; g.norm_w = m->final_norm; g.eps = m->norm_eps;

@@ -13,6 +13,47 @@
 // strided over the whole grid, so at any instant the chip streams one contiguous weight region.
 #include <cstdlib>
 
+#include "common.cuh"
+
+// A second compile with -DGEMV_F16=1 (build_native.py: gemv_f16.o) is the same weight-streaming kernel for fp16 storage:
+// v_dot2_f32_f16 for v_dot2c_f32_bf16 and half conversions / rounding points, under launch_gemv_f16 (api.hip: decode steps of
+// fp16 models in mi_forward_generic).  Every 16-bit access of gemv_core.cuh goes through the helpers renamed here; the default
+// compile is untouched by this block (ISA hash checked) and gemv_core.cuh itself - shared with the frozen decode engine - is
+// not edited.
+#ifndef GEMV_F16
+#define GEMV_F16 0
+#endif
+#if GEMV_F16
+typedef _Float16 gemv_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float gemv_h_to_f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t gemv_h_from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float gemv_h_round(float f) { return (float)(_Float16)f; }
+__device__ __forceinline__ uint32_t gemv_h_pack2(float lo, float hi) {
+  return (uint32_t)gemv_h_from_f(lo) | ((uint32_t)gemv_h_from_f(hi) << 16);
+}
+__device__ __forceinline__ float gemv_h_lo(uint32_t u) { return gemv_h_to_f((uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float gemv_h_hi(uint32_t u) { return gemv_h_to_f((uint16_t)(u >> 16)); }
+__device__ __forceinline__ float gemv_h_dot2(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(gemv_half2, a), __builtin_bit_cast(gemv_half2, b), acc, false);
+}
+__device__ __forceinline__ float gemv_h_swiglu(float acc1, float acc3) {  // swiglu_bf with fp16 rounding points
+  const float a = gemv_h_round(acc1), b = gemv_h_round(acc3);
+  const float s = gemv_h_round(a / (1.0f + expf(-a)));
+  return s * b;
+}
+#define dot2_bf16 gemv_h_dot2
+#define bf_lo gemv_h_lo
+#define bf_hi gemv_h_hi
+#define pack_bf2 gemv_h_pack2
+#define bf_round gemv_h_round
+#define f_to_bf gemv_h_from_f
+#define bf_to_f gemv_h_to_f
+#define swiglu_bf gemv_h_swiglu
+#define gemv_core gemv_core_f16
+#define gemv_max_tokens gemv_max_tokens_f16
+#define launch_gemv launch_gemv_f16
+#endif
+
 #include "gemv_core.cuh"
 
 namespace {

@@ -56,6 +56,9 @@ struct GemvArgs {
 
 int gemv_max_tokens(int K);
 hipError_t launch_gemv(const GemvArgs& a, hipStream_t s);
+// gemv.hip compiled with -DGEMV_F16=1: the same kernels on fp16 payloads (mi_forward_generic: decode steps of fp16 models)
+int gemv_max_tokens_f16(int K);
+hipError_t launch_gemv_f16(const GemvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------- GEMM
 enum GemmEpi { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SWIGLU = 2, GEMM_LOGITS = 3, GEMM_LOGPROB = 4 };
