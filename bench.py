@@ -10,10 +10,13 @@ with the ring full (4096 keys per layer).  Inputs (weights, K/V rings, token ids
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # pipeline stages over RCCL
 
-N > 1 (one rank per GPU, layer ranges as pipeline stages): the headline `value` is the pipeline's THROUGHPUT - N independent
-sequences in flight, one per stage at any time, every call still batch 1 / seq 1 on that sequence's own K/V rings ("scaling":
-"weak": a step = one new token for every sequence; mistral_inference/pipeline_decode.py).  The relay of ONE sequence through the
-same stages - what the reference's pipeline does, N GPUs at the speed of one - is reported beside it as `single_stream`.
+N > 1 (one rank per GPU, layer ranges as pipeline stages): the headline `value` stays the BASELINE metric - ONE sequence relayed
+through the N stages, what the reference's pipeline does (transformer.py:195-237; "scaling": "strong": the same work on more
+GPUs, and by construction no faster than on one).  The pipeline's THROUGHPUT mode - N independent sequences in flight, one per
+stage at any time (mistral_inference/pipeline_decode.py) - is reported beside it under `pipeline_throughput`.
+
+N = 1 additionally carries, as sub-objects of the same line: `nemo` and `mixtral` (BASELINE configs[2] and [3] measured by this
+same script in a subprocess each), `parity` (the configs[0] model against the CPU oracle in this run) and `cpu_baseline`.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md section 6 for the roofline / cpu_baseline definitions).
 """
@@ -80,13 +83,13 @@ def build_model(params: dict, rank: int, world: int, device: str):
     return model.eval()
 
 
-def decode_bytes_per_token(p: dict, ctx: int) -> int:
-    """weights read once + K/V window read once (bf16)."""
+def decode_bytes_per_token(p: dict, ctx: int, head: bool = True) -> int:
+    """weights read once + K/V window read once (bf16).  head=False: a pipeline stage without the LM head."""
     D, L, H, Hkv, Dh, F, V = p["dim"], p["n_layers"], p["n_heads"], p["n_kv_heads"], p["head_dim"], p["hidden_dim"], p["vocab_size"]
     moe = p.get("moe")
     ffn = (moe["num_experts_per_tok"] * 3 * D * F + moe["num_experts"] * D) if moe else 3 * D * F
     per_layer = D * H * Dh + 2 * D * Hkv * Dh + H * Dh * D + 2 * D + ffn
-    w = 2 * (L * per_layer + V * D + D)
+    w = 2 * (L * per_layer + (V * D + D if head else 0))
     W = p.get("sliding_window") or ctx
     kv = L * 2 * min(ctx, W) * Hkv * Dh * 2
     return w + kv
@@ -181,11 +184,47 @@ def dominant_kernel_roofline(model, iters: int) -> dict:
             "launches_timed": n}
 
 
+def stage_roofline(model, cache, params: dict, rank: int, world: int, iters: int) -> dict:
+    """N > 1: this rank's stage alone - `iters` back-to-back decode calls of its layer range without the hops (what
+    pipeline_decode.InterleavedDecoder issues per tick), HIP events on the launch stream, against the stage's own bytes."""
+    dev = model.device
+    be = model._backend
+    last = rank == world - 1
+    h = torch.zeros((1, model.args.dim), dtype=model.dtype, device=dev)
+    ids = torch.ones(1, dtype=torch.long, device=dev) if rank == 0 else None
+    logits = torch.empty((1, model.vocab_size), dtype=torch.float32, device=dev) if last else None
+    stream = torch.cuda.current_stream(dev)
+
+    def one():
+        meta = cache.batch_metadata([1])
+        be.run_stack(model, h, ids, meta, cache, logits)
+        cache.advance_host([1])
+
+    for _ in range(3):
+        one()
+    ctx0 = cache._seen[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        one()
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    nbytes = decode_bytes_per_token(dict(params, n_layers=model.n_local_layers), ctx0 + iters // 2, head=last)
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"rank": rank, "layers": model.n_local_layers, "lm_head": last, "bytes_per_call": nbytes, "avg_call_us": round(us, 2),
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def reference_baseline(params: dict, ctx: int, steps: int = 6):
     """The UNMODIFIED reference timed on this box's host cores (oracle/time_reference.py in a subprocess: the reference
     shares the product's package name).  None where the reference source is absent (the GPU box)."""
     import subprocess
+    # the source tree where it exists (the build container), else its byte-compiled form oracle/build_ref.py put under
+    # oracle/_ref/ (git-ignored, travels with the working tree to the GPU box like the built .so does)
     ref = os.environ.get("MISTRAL_REFERENCE_SRC", "/root/reference/src")
+    if not os.path.isdir(os.path.join(ref, "mistral_inference")):
+        ref = os.path.join(ROOT, "oracle", "_ref")
     if not os.path.isdir(os.path.join(ref, "mistral_inference")):
         return None
     p = {k: v for k, v in params.items()}
@@ -193,7 +232,11 @@ def reference_baseline(params: dict, ctx: int, steps: int = 6):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--params", json.dumps(p),
                             "--ctx", str(ctx), "--steps", str(steps)], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, MISTRAL_REFERENCE_SRC=ref))
-        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+        if r.returncode != 0:
+            return None
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["reference_form"] = "source tree" if ref.endswith("/src") else "oracle/_ref (byte-compiled from the unmodified source by oracle/build_ref.py)"
+        return out
     except Exception:  # noqa: BLE001  (a baseline that cannot be taken is reported as absent, never as a number)
         return None
 
@@ -273,6 +316,39 @@ def port_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
             "sample": f"oracle decode step at ctx {ctx} (W={W}) with {nl} of {params['n_layers']} layers + LM head, "
                       f"{steps} steps, bf16, {cores} threads; per-layer time x{params['n_layers']} + head "
                       f"({per_layer * 1e3:.1f} ms/layer, {t_head * 1e3:.1f} ms head)"}
+
+
+def sub_measurement(model_key: str, prefill: int, steps: int, warmup: int, timeout_s: int = 900) -> dict:
+    """Another BASELINE config measured by THIS script in a subprocess of its own (its own weights, its own timing bracket;
+    a crash or a time-out there costs the sub-object, never the headline line).  Returns the fields a reader needs."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--model", model_key, "--prefill", str(prefill), "--steps", str(steps),
+           "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001  (reported, never hidden)
+        return {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+    rf = d.get("roofline", {})
+    return {"workload": d["config"]["workload"], "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            "warmup": d["warmup"], "context_at_timing": d["config"]["context_at_timing"],
+            "bytes_per_token": d["hbm_roofline_step"]["bytes_per_token"], "hbm_roofline_frac": d["hbm_roofline_step"]["frac"],
+            "decode_launch": d["config"]["decode_launch"],
+            "dominant_kernel": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")},
+            "prefill_tokens": d["prefill"]["tokens"], "prefill_tokens_per_s": d["prefill"]["tokens_per_s"],
+            "prefill_mfma_frac": d["prefill"]["mfma_frac"], "wall_s": round(time.perf_counter() - t0, 1)}
+
+
+def parity_in_this_run() -> dict:
+    """SURVEY.md 8(d) "parity in the same run": BASELINE configs[0] (Mistral-7B dims, 2 layers, 32-token prompt + 16 greedy
+    tokens) on the HIP path against the CPU oracle on identical weights and prompt.  The comparison itself lives in
+    __graft_entry__.parity_numbers (next to smoke(), which holds the oracle as its checker)."""
+    try:
+        import __graft_entry__ as ge
+        return ge.parity_numbers()
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
 
 def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: int, Wm: int, sync):
@@ -378,10 +454,11 @@ def interleaved_run(opt, model, rank: int, world: int, dev: str, T0: int, K: int
         dec.run(K)
         sync()
         dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt, dec.tick_host_us], device=dev, dtype=torch.float64)
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     del dec, caches
-    return float(tmax.item())
+    interleaved_run.tick_host_us = float(tmax[1].item())
+    return float(tmax[0].item())
 
 
 def respawn_under_torchrun(n: int) -> int:
@@ -409,6 +486,8 @@ def main() -> None:
     ap.add_argument("--loop", default="greedy", choices=["greedy", "forward"],
                     help="greedy: generate()'s temperature-0 loop (sample fused into the step); forward: forward() + torch.argmax per token")
     ap.add_argument("--no-mixtral", action="store_true", help="N > 1: skip the Mixtral sub-measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the `nemo` / `mixtral` / `parity` sub-objects (the headline fields are the same either way)")
     ap.add_argument("--mixtral-layers", type=int, default=None, help="debug only: layers of the N > 1 Mixtral sub-measurement")
     opt = ap.parse_args()
 
@@ -447,12 +526,18 @@ def main() -> None:
     interleave = world > 1 and opt.loop == "greedy" and os.environ.get("MI_BENCH_INTERLEAVE", "1") != "0"
     dt_il = None
     if interleave:
+        ok = 1
         try:
             dt_il = interleaved_run(opt, model, rank, world, dev, T0, K, Wm, sync)
-        except Exception as e:  # an error every rank raises alike (API / shape): keep the single-stream line instead of no line
-            print(f"[bench] rank {rank}: interleaved measurement failed ({type(e).__name__}: {e}); reporting the single-stream relay",
+        except Exception as e:  # keep the single-stream line instead of no line
+            print(f"[bench] rank {rank}: interleaved measurement failed ({type(e).__name__}: {e}); reporting the single-stream relay only",
                   file=sys.stderr, flush=True)
-            interleave = False
+            ok = 0
+        # every rank learns whether ALL ranks finished: a rank that raised alone must not leave the others with a number
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            interleave, dt_il = False, None
 
     from mistral_inference import _hip
     engine = _hip.decode_engine_status(model._backend._workspace)
@@ -495,20 +580,27 @@ def main() -> None:
         if opt.loop == "greedy":
             # not inside the K-step bracket: the once-per-chunk read-back of the samples (status copy + host sync + gather)
             out["collect_ms_per_chunk"] = round(getattr(timed_run, "collect_s", 0.0) * 1e3, 3)
+        if world > 1:
+            # the record shows what the collective layer saw: process-group backend and size, and - with the C-ABI transport -
+            # the communicator's own rank count
+            out["distributed"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                                  "transport": type(model.pp_comm).__name__,
+                                  "rccl_comm_ranks": getattr(model.pp_comm, "world_size", None) if type(model.pp_comm).__name__ == "RcclComm" else None}
+            out["hbm_roofline_step"]["note"] = (f"ONE sequence relayed through {world} stages: the stages run one after the other, so the "
+                                                f"roofline time is the one-GPU sum (SURVEY.md 8e) and frac is priced against ONE GPU's peak")
         if dt_il is not None:
-            # N > 1 headline = the pipeline's throughput: `world` sequences in flight, one per stage (each call still batch 1,
-            # seq 1 on that sequence's own rings); a step = one round = one new token for EVERY sequence.  The relay figure of
-            # ONE sequence through the same stages (what the reference's pipeline does: N GPUs, the speed of one) stays beside it.
+            # N > 1: the headline above is the BASELINE metric (one sequence through the stages).  The throughput mode - `world`
+            # sequences in flight, one per stage, each call still batch 1 / seq 1 on that sequence's own rings; a round = one
+            # new token for EVERY sequence - is an extra of this implementation and lives in its own object.
             rate = K * world / dt_il
-            out["single_stream"] = {"tokens_per_s": out["value"], "ms_per_step": out["ms_per_step"],
-                                    "hbm_roofline_frac_of_one_gpu": out["hbm_roofline_step"]["frac"],
-                                    "note": "one sequence relayed through the stages (reference transformer.py:195-237)"}
-            out["value"], out["ms_per_step"], out["scaling"] = round(rate, 2), round(dt_il / K * 1e3, 4), "weak"
             agg = step_bytes * rate / 1e9
-            out["hbm_roofline_step"] = {"bytes_per_token": step_bytes, "achieved_GBs": round(agg, 1), "peak_GBs": HBM_PEAK_GBS * world,
-                                        "frac": round(agg / (HBM_PEAK_GBS * world), 4), "note": f"aggregate over {world} GPUs"}
-            out["config"]["sequences_in_flight"] = world
-            out["config"]["parallelism"] += f"; decode throughput: {world} sequences in flight, one per stage, ring of grouped send+recv per tick"
+            out["pipeline_throughput"] = {
+                "tokens_per_s": round(rate, 2), "tokens_per_s_per_gpu": round(rate / world, 2), "ms_per_round": round(dt_il / K * 1e3, 4),
+                "sequences_in_flight": world, "scaling": "weak",
+                "hbm_roofline_frac": round(agg / (HBM_PEAK_GBS * world), 4), "hbm_peak_GBs": HBM_PEAK_GBS * world,
+                "tick_host_us": round(getattr(interleaved_run, "tick_host_us", float("nan")), 2),
+                "note": "one sequence per stage in flight, ring of grouped send+recv per tick (mistral_inference/pipeline_decode.py); "
+                        "tick_host_us = host time per tick of the loop (max over ranks)"}
         # the dominant kernel is timed on this rank's own layers (any N)
         if engine["engine_launches"] > 0 and world == 1:
             with torch.inference_mode():
@@ -528,6 +620,22 @@ def main() -> None:
     out = report() if rank == 0 else None
     if world > 1:  # the other ranks wait here while rank 0 times its dominant kernel
         torch.distributed.barrier()
+        # every stage's own decode call (no hop: Backend.run_stack directly, as the throughput mode issues it) against the
+        # bytes of its own layers (+ the LM head on the last stage)
+        with torch.inference_mode():
+            mine = stage_roofline(model, cache, params, rank, world, iters=16)
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
+        if out is not None:
+            out["roofline_per_rank"] = per_rank
+    if world == 1 and opt.model == "mistral-7b" and not opt.layers and not opt.no_extras:
+        # the other BASELINE configs and parity, in the one line the driver records (the headline fields above are final)
+        del model, cache, nxt
+        torch.cuda.empty_cache()
+        out["parity"] = parity_in_this_run()
+        torch.cuda.empty_cache()
+        out["nemo"] = sub_measurement("nemo-12b", 8192, K, Wm)
+        out["mixtral"] = sub_measurement("mixtral-8x7b", T0, K, Wm)
     if world > 1 and not opt.no_mixtral and opt.model == "mistral-7b" and (not opt.layers or opt.mixtral_layers):
         # north_star: "Mixtral-8x7B pipeline-parallel tokens/sec reported at 1/2/4/8 GPUs" (BASELINE configs[3], and
         # configs[4] - Mixtral-8x22B over 8 stages - where 8 GPUs are present).  The N = 1 headline line is untouched; a

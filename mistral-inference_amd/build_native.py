@@ -26,7 +26,11 @@ PER_FILE_FLAGS = {"decode_engine.hip": os.environ.get("MI_ENGINE_FLAGS", "-mllvm
 
 # Second compile of the engine source under other entry-point names (csrc/decode_engine.hip, ENG_WIDE): the shapes the shipped
 # instantiations decline, without touching one instruction of the shipped kernels.
-VARIANT_OBJECTS = {"decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
+# round 5: the headline shape's engine (dense GQA-4, rows of 4-piece groups) - the winner of the same-box A/B of
+# scripts/build_variants.py engine_slots / scripts/engine_ab.py (profiles/EXPERIMENTS.md round 5)
+ENGINE_NEXT_FLAGS = ["-DENG_SUFFIX=_next", "-DENG_HEADLINE_ONLY=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"]
+VARIANT_OBJECTS = {"decode_engine_next.o": ("decode_engine.hip", ENGINE_NEXT_FLAGS),
+                   "decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
                    "decode_engine_moe.o": ("decode_engine.hip", ["-DENG_WIDE=2"]),    # 8-fill ring, MoE GQA 4 (Mixtral-8x7B)
                    "gemm256_f16.o": ("gemm256.hip", ["-DG256_F16=1"]),                # the 256-tile GEMM on fp16 payloads (generic path)
                    "attn_prefill_f16.o": ("attn_prefill.hip", ["-DATTN_F16=1"]),      # the MFMA prefill attention on fp16 payloads
@@ -44,7 +48,10 @@ def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    missing = [d for d in deps if not os.path.exists(d)]
+    if missing:  # a header that was moved or renamed must not silently stop triggering rebuilds
+        raise RuntimeError(f"build_native: dependency listed but not found: {missing}")
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(verbose: bool = True, extra_flags=(), obj_dir: str = OBJ, lib: str = LIB) -> str:

@@ -18,6 +18,17 @@
 #include "../../include/mistral_hip_debug.h"
 #include "kernels.h"
 
+#ifdef MI_SLOT_LIST  // experiment libraries: see g_slots below
+#define X(n)                                                                         \
+  bool decode_engine_applicable_x##n(const EngProblem&, char*, size_t);             \
+  hipError_t launch_decode_engine_x##n(const EngProblem&, hipStream_t, bool*);      \
+  void decode_engine_set_trace_x##n(void*);                                          \
+  void decode_engine_set_knobs_x##n(int, int);                                       \
+  void decode_engine_set_holders_x##n(int);
+MI_SLOT_LIST
+#undef X
+#endif
+
 namespace {
 
 thread_local char g_detail[512] = "";
@@ -57,6 +68,23 @@ int engine_variant() {
   }
   return g_engine_variant;
 }
+// Experiment libraries only (scripts/build_variants.py engine_slots -> -DMI_SLOT_LIST="X(0) X(1) ..."): further compiles of the
+// engine source under the names *_x<N>, selected at run time by mi_debug_set_engine_slot (scripts/engine_ab.py: one process,
+// one set of weights, every variant timed in turn on the same box).  Not compiled into the shipped library.
+#ifdef MI_SLOT_LIST
+struct EngSlot {
+  bool (*applicable)(const EngProblem&, char*, size_t);
+  hipError_t (*launch)(const EngProblem&, hipStream_t, bool*);
+  void (*set_trace)(void*);
+  void (*set_knobs)(int, int);
+  void (*set_holders)(int);
+};
+#define X(n) {decode_engine_applicable_x##n, launch_decode_engine_x##n, decode_engine_set_trace_x##n, decode_engine_set_knobs_x##n, decode_engine_set_holders_x##n},
+const EngSlot g_slots[] = {MI_SLOT_LIST};
+#undef X
+constexpr int N_SLOTS = (int)(sizeof(g_slots) / sizeof(g_slots[0]));
+int g_slot = -1;
+#endif
 int engine_mode() {
   if (g_engine_mode < 0) {
     const char* e = getenv("MI_DECODE_ENGINE");
@@ -482,6 +510,7 @@ int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream) 
 }
 
 int mi_decode_engine_census(int forget) {
+  if (forget) decode_engine_forget_census_next();
   if (forget) decode_engine_forget_census_wide();
   if (forget) decode_engine_forget_census_moe();
   if (forget) decode_engine_forget_census();
@@ -497,12 +526,20 @@ int mi_decode_engine_status(const void* workspace, mi_stream_t stream, uint32_t 
 size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(device_cus()); }
 int mi_debug_set_engine_knobs(int thin, int depth) {
   decode_engine_set_knobs(thin, depth);
+  decode_engine_set_knobs_next(thin, depth);
+#ifdef MI_SLOT_LIST
+  for (const EngSlot& sl : g_slots) sl.set_knobs(thin, depth);
+#endif
   decode_engine_set_knobs_wide(thin, depth);
   decode_engine_set_knobs_moe(thin, depth);
   return MI_OK;
 }
 int mi_debug_set_engine_holders(int on) {
   decode_engine_set_holders(on);
+  decode_engine_set_holders_next(on);
+#ifdef MI_SLOT_LIST
+  for (const EngSlot& sl : g_slots) sl.set_holders(on);
+#endif
   decode_engine_set_holders_wide(on);
   decode_engine_set_holders_moe(on);
   return MI_OK;
@@ -512,6 +549,12 @@ int mi_debug_set_engine_variant(int variant) {
   g_engine_variant = variant < 0 || variant > 2 ? 0 : variant;
   return prev;
 }
+#ifdef MI_SLOT_LIST
+extern "C" int mi_debug_set_engine_slot(int slot) {  // -1: the library's own routing; returns the number of slots
+  g_slot = slot < 0 || slot >= N_SLOTS ? -1 : slot;
+  return N_SLOTS;
+}
+#endif
 int mi_debug_set_prefill_kernels(int attn_waves, int gemm_tail) {
   attn_prefill_set_mode(attn_waves);
   if (gemm_tail >= 0) gemm_set_tail_mode(gemm_tail);
@@ -519,6 +562,10 @@ int mi_debug_set_prefill_kernels(int attn_waves, int gemm_tail) {
 }
 int mi_debug_set_engine_trace(void* dev_buffer) {
   decode_engine_set_trace(dev_buffer);
+  decode_engine_set_trace_next(dev_buffer);
+#ifdef MI_SLOT_LIST
+  for (const EngSlot& sl : g_slots) sl.set_trace(dev_buffer);
+#endif
   decode_engine_set_trace_wide(dev_buffer);
   decode_engine_set_trace_moe(dev_buffer);
   return MI_OK;
@@ -604,6 +651,29 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     // -8..-11 us per layer), which the shipped object - frozen, see decode_engine.hip - does not.  Variant 2 = shipped build
     // first for every model (the A/B of that choice).
     // (MoE: the 8-fill MoE build where the model fits it - Mixtral-8x7B -, else the 7-fill wide build - Mixtral-8x22B.)
+#ifdef MI_SLOT_LIST
+    if (g_slot >= 0 && dense_ok && g_slots[g_slot].applicable(pr, nullptr, 0)) {
+      bool declined = false;
+      MI_TRY(hip_rc(g_slots[g_slot].launch(pr, s, &declined), "decode engine (experiment slot)"));
+      if (!declined) {
+        if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        if (want_topp) MI_TRY(sample_step());
+        return MI_OK;
+      }
+    }
+#endif
+    // round 5: the dense GQA-4 headline shapes take the `next` compile (sentinel-first sweeps, see decode_engine.hip ENG_SENT)
+    const bool next_ok = dense_ok && m->num_experts == 0 && engine_variant() == 0 && decode_engine_applicable_next(pr, nullptr, 0);
+    if (next_ok) {
+      bool declined = false;
+      MI_TRY(hip_rc(launch_decode_engine_next(pr, s, &declined), "decode engine"));
+      if (!declined) {
+        if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        if (want_topp) MI_TRY(sample_step());
+        return MI_OK;
+      }
+      snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail_next());  // informational
+    }
     const bool moe_ok = dense_ok && m->num_experts > 0 && engine_variant() == 0 && decode_engine_applicable_moe(pr, nullptr, 0);
     const bool wide_ok = !moe_ok && dense_ok && decode_engine_applicable_wide(pr, nullptr, 0);
     const bool wide_first = engine_variant() == 1 || (engine_variant() == 0 && m->num_experts > 0);

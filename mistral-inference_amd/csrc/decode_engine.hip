@@ -48,12 +48,23 @@
 // ENG_WIDE = 2: the same additions with the shipped 8-fill ring, MoE models only (decode_engine_moe.o): at dim 4096 the four
 // consumer waves' W1|W3 units span exactly 8 fills, and the 7-fill ring of ENG_WIDE = 1 costs Mixtral-8x7B 6 % of its W1|W3
 // streaming rate (25.6 vs 27.2 GB/s per CU, profiles/r04_engine_trace_8x7b_*) - as much as the batched router saves.
-#if ENG_WIDE == 1
+// ENG_SUFFIX (round 5): further compiles of this source under their own entry-point names - `_next` (decode_engine_next.o: the
+// dense GQA-4 headline shape with the round-5 switches below: ENG_ABORT_RARE, ENG_DONE_*, ENG_SLP_*) and the `_x<N>` slots
+// of an experiment library (scripts/build_variants.py engine_slots, scripts/engine_ab.py).  ENG_HEADLINE_ONLY = 1 instantiates
+// only decode_engine_kernel<4, dense, all rows multiples of 4 pieces>.
+#ifndef ENG_HEADLINE_ONLY
+#define ENG_HEADLINE_ONLY 0
+#endif
+#define ENG_CAT_(a, b) a##b
+#define ENG_CAT(a, b) ENG_CAT_(a, b)
+#if defined(ENG_SUFFIX)
+#define ENG_NAME(x) ENG_CAT(x, ENG_SUFFIX)
+#elif ENG_WIDE == 1
 #define ENG_NAME(x) x##_wide
 #elif ENG_WIDE == 2
 #define ENG_NAME(x) x##_moe
 #endif
-#if ENG_WIDE
+#if ENG_WIDE || defined(ENG_SUFFIX)
 #define launch_decode_engine ENG_NAME(launch_decode_engine)
 #define decode_engine_applicable ENG_NAME(decode_engine_applicable)
 #define decode_engine_granule_bytes ENG_NAME(decode_engine_granule_bytes)
@@ -100,15 +111,50 @@ constexpr int NCONS = 4;
 #ifndef ENG_CBAR_FLAGS
 #define ENG_CBAR_FLAGS 0  // 1: consumer barrier on per-wave flag words polled without sleeping (+10..20 us per step)
 #endif
+// ---- round 5 (all off in the default compile, whose ISA stays what it was: scripts/engine_isa_hash.sh) ----------------------
+// s_sleep arguments of the bounded spins, per kind of wait (each unit is 64 clocks)
+#ifndef ENG_SLP_RING
+#define ENG_SLP_RING 1   // loader: ring full
+#endif
+#ifndef ENG_SLP_STOP
+#define ENG_SLP_STOP 1   // loader: stopped while this CU's consumers sweep
+#endif
+#ifndef ENG_SLP_FILL
+#define ENG_SLP_FILL 1   // consumers: waiting for a fill to land
+#endif
+#ifndef ENG_SLP_CBAR
+#define ENG_SLP_CBAR 1   // consumers: barrier among the four waves / holders done
+#endif
+#ifndef ENG_SLP_SWEEP
+#define ENG_SLP_SWEEP 1  // consumers: between two passes of a hand-off sweep
+#endif
+#ifndef ENG_SLP_HOLD
+#define ENG_SLP_HOLD 1   // holder waves (waits of tens of microseconds)
+#endif
+#ifndef ENG_ABORT_RARE
+#define ENG_ABORT_RARE 0  // 1: the abort word is read on every 1024th iteration of a spin only (one LDS read less per poll)
+#endif
+#ifndef ENG_DONE_B128
+#define ENG_DONE_B128 0   // 1: the four consumer marks in one 16-byte aligned LDS line: the loader reads them with ONE ds_read_b128
+#endif
+#ifndef ENG_DONE_CACHE
+#define ENG_DONE_CACHE 0  // 1: the loader re-reads the consumer marks only when the minimum it last saw no longer frees the slot
+#endif
+#ifndef ENG_CONS_PRIO
+#define ENG_CONS_PRIO 0   // s_setprio of the consumer waves (the loader runs at 3, holders at 0)
+#endif
 constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
 constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
-constexpr int FILL = 16;             // pieces per fill
+#ifndef ENG_FILL
+#define ENG_FILL 16  // (8: finer publication of landed data, twice the loader's per-fill bookkeeping - round-5 experiment)
+#endif
+constexpr int FILL = ENG_FILL;       // pieces per fill
 #if ENG_WIDE == 1
 constexpr int RING_FILLS = 7;        // 112 KiB ring: 47 KiB left for the activation region (a 32 KiB hid vector fits)
 #define RING_IDX(sh, x) ((uint32_t)(x) % (uint32_t)(RING_FILLS * FILL))  // not a power of two: a constant modulo (scalar ALU)
 #else
-constexpr int RING_FILLS = 8;        // 128 KiB ring
+constexpr int RING_FILLS = 128 / FILL;  // 128 KiB ring
 #define RING_IDX(sh, x) ((x) & (sh).ring_mask)
 #endif
 constexpr int LDS_TOTAL = 160 * 1024;
@@ -133,7 +179,7 @@ typedef LDS_AS bf16_t lbf16;
 // control words at the start of the LDS
 enum : int {
   C_LANDED = 0,     // fills completely in LDS (loader -> consumers)
-  C_DONE = 1,       // [NCONS] first piece index each consumer wave may still read (consumers -> loader)
+  C_DONE = ENG_DONE_B128 ? 40 : 1,  // [NCONS] first piece index each consumer wave may still read (consumers -> loader)
   C_CBAR = 5,       // consumer-wave barrier counter
   C_GATHERING = 6,  // consumers are sweeping granules: the loader keeps one fill outstanding
   C_ABORT = 7,
@@ -192,11 +238,13 @@ __device__ __forceinline__ void raise_abort(const Shared& sh, uint32_t code) {
 }
 
 // One iteration of a bounded spin.  Returns false when the wait must be abandoned.
+template <int SLP = 1>
 __device__ __forceinline__ bool spin_ok(const Shared& sh, uint32_t& spins, uint32_t code) {
-  __builtin_amdgcn_s_sleep(1);
-  if (sh.ctl[C_ABORT]) return false;
+  __builtin_amdgcn_s_sleep(SLP);
+  if (!ENG_ABORT_RARE && sh.ctl[C_ABORT]) return false;
   ++spins;
   if ((spins & 1023u) == 0) {
+    if (ENG_ABORT_RARE && sh.ctl[C_ABORT]) return false;
     if (__hip_atomic_load(sh.ctrl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
       sh.ctl[C_ABORT] = 1;
       return false;
@@ -266,9 +314,17 @@ struct Loader {
   uint32_t g = 0;    // pieces issued
   uint32_t pub = 0;  // fills published
   uint32_t stalls = 0;  // fills that had to wait for a free ring slot (trace only)
+#if ENG_DONE_CACHE
+  uint32_t done_seen = 0;  // minimum of the consumer marks at the last look
+#endif
 
   __device__ __forceinline__ uint32_t min_done() const {
+#if ENG_DONE_B128
+    const u32x4 d = *reinterpret_cast<const LDS_AS volatile u32x4*>(sh.ctl + C_DONE);
+    return min(min(d[0], d[1]), min(d[2], d[3]));
+#else
     return min(min(sh.ctl[C_DONE + 0], sh.ctl[C_DONE + 1]), min(sh.ctl[C_DONE + 2], sh.ctl[C_DONE + 3]));
+#endif
   }
   __device__ __forceinline__ void publish(uint32_t fills) {
     if (fills > pub) {
@@ -281,13 +337,19 @@ struct Loader {
     const uint32_t f = g / FILL;
     if (f >= (uint32_t)ring_fills) {
       const uint32_t need = (f - ring_fills + 1) * FILL;
+#if ENG_DONE_CACHE
+      if (done_seen >= need) return;  // (marks only grow: what was seen once stays true)
+      done_seen = min_done();
+      if (done_seen < need) {
+#else
       if (min_done() < need) {
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         publish(f);  // everything issued has landed: consumers must not starve while we wait for them
         ++stalls;
         uint32_t spins = 0;
         while (min_done() < need)
-          if (!spin_ok(sh, spins, 0x100)) break;
+          if (!spin_ok<ENG_SLP_RING>(sh, spins, 0x100)) break;
       }
     }
   }
@@ -302,16 +364,16 @@ struct Loader {
       publish(f);
       uint32_t spins = 0;
       while (sh.ctl[C_GATHERING])
-        if (!spin_ok(sh, spins, 0x100)) break;
+        if (!spin_ok<ENG_SLP_STOP>(sh, spins, 0x100)) break;
     } else if (thin && sh.ctl[C_GATHERING]) {  // thin == 1: keep one fill in flight during sweeps (A/B)
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      publish(f - 1);
+      publish(f - 16 / FILL);
     } else if (depth >= 3) {
       asm volatile("s_waitcnt vmcnt(47)" ::: "memory");  // <= 3 fills in flight (the counter saturates at 63)
-      if (f >= 3) publish(f - 3);
+      if (f >= 48 / FILL) publish(f - 48 / FILL);
     } else {
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      if (f >= 2) publish(f - 2);
+      if (f >= 32 / FILL) publish(f - 32 / FILL);
     }
   }
   // The DMA itself.  ENG_ASM_DMA = 1 (experiment, off): issued from inline asm (cdna_hip_programming.md section 5.7 recipe: M0
@@ -517,7 +579,7 @@ struct Cons {
     for (;;) {
       landed = sh.ctl[C_LANDED];
       if (landed >= need) return;
-      if (!spin_ok(sh, spins, 0x200)) return;
+      if (!spin_ok<ENG_SLP_FILL>(sh, spins, 0x200)) return;
     }
   }
   __device__ __forceinline__ void set_done(uint32_t piece_idx) { sh.ctl[C_DONE + w] = piece_idx; }
@@ -530,7 +592,7 @@ struct Cons {
     if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_CBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t spins = 0;
     while (sh.ctl[C_CBAR] < cbar_target)
-      if (!spin_ok(sh, spins, 0x300)) break;
+      if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x300)) break;
     asm volatile("" ::: "memory");
   }
 #else
@@ -676,7 +738,7 @@ struct Cons {
           ok &= have[k];
         }
         if (__all(ok)) break;
-        if (!spin_ok(sh, spins, 0x400)) break;
+        if (!spin_ok<ENG_SLP_SWEEP>(sh, spins, 0x400)) break;
       }
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
@@ -717,7 +779,7 @@ struct Cons {
           ok &= have[k];
         }
         if (__all(ok)) break;
-        if (!spin_ok(sh, spins, 0x400)) break;
+        if (!spin_ok<ENG_SLP_SWEEP>(sh, spins, 0x400)) break;
       }
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
@@ -781,7 +843,7 @@ struct Cons {
         ok &= have[i];
       }
       if (__all(ok)) break;
-      if (!spin_ok(sh, spins, 0x400)) break;
+      if (!spin_ok<ENG_SLP_SWEEP>(sh, spins, 0x400)) break;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) xr[i] = u32x4{lo[i][0], lo[i][2], hi[i][0], hi[i][2]};
@@ -1101,6 +1163,7 @@ template <int R, bool MOE, bool ALL4>
 __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh, int c, int w, int lane, int pos, int seq, uint32_t epoch,
                                              uint32_t arrive_target) {
   Cons cs{sh, w, lane};
+  if (ENG_CONS_PRIO) __builtin_amdgcn_s_setprio(ENG_CONS_PRIO);
   lbf16* xs = reinterpret_cast<lbf16*>(sh.xs);
   lu32* xs32 = reinterpret_cast<lu32*>(sh.xs);
   gu64* G = (gu64*)a.gran;
@@ -1447,7 +1510,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         hold_target += (uint32_t)n_hold;
         uint32_t spins = 0;
         while (sh.ctl[C_HDONE] < hold_target)
-          if (!spin_ok(sh, spins, 0x500)) break;
+          if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
       }
       sh.ctl[C_GATHERING] = 1;
       cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
@@ -1631,7 +1694,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     const int j = p.f1 - n_hold + hi;
     uint32_t spins = 0;
     while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
-      if (!spin_ok(sh, spins, 0x600)) return;
+      if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
     const size_t r0 = (size_t)(2 * j) * a.D + lane * 8;
     const bf16_t* rows[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r0 + a.D, L.w3 + r0 + a.D};
     u32x4 hw[HOLD_GROUPS][4][4];  // [group][row][piece in group]: constant indices only -> registers
@@ -1641,7 +1704,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       for (int half = 0; half < 2; ++half) {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
         spins = 0;
         while (sh.ctl[C_GATHERING])
-          if (!spin_ok(sh, spins, 0x600)) return;
+          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
 #pragma unroll
         for (int r = 2 * half; r < 2 * half + 2; ++r)
 #pragma unroll
@@ -1653,7 +1716,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     }
     spins = 0;
     while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
-      if (!spin_ok(sh, spins, 0x600)) return;
+      if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int grp = 0; grp < HOLD_GROUPS; ++grp)
@@ -1782,6 +1845,10 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   if (((pr.D >> 9) & 1) && pr.D > 3072) return no("odd number of 512-element pieces per row at a large dim");
 #endif
   if (pr.V % 2) return no("odd vocab");
+#if ENG_HEADLINE_ONLY
+  if (pr.E || pr.H != 4 * pr.Hkv || pr.D % 2048 || (pr.H * DH) % 2048 || pr.F % 2048)
+    return no("this build instantiates the dense GQA-4 kernel for rows of 4-piece groups only");
+#endif
 #if ENG_WIDE == 2
   if (!pr.E) return no("the 8-fill MoE build takes MoE models only");
 #endif
@@ -1978,7 +2045,9 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   (moe ? (all4 ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
        : (all4 ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
     switch (a.R) {
-#if ENG_WIDE == 2
+#if ENG_HEADLINE_ONLY
+      case 4: fn = (!moe && all4) ? (const void*)decode_engine_kernel<4, false, true> : nullptr; break;
+#elif ENG_WIDE == 2
       case 4: fn = !moe ? nullptr : (all4 ? (const void*)decode_engine_kernel<4, true, true> : (const void*)decode_engine_kernel<4, true, false>); break;
 #elif ENG_WIDE
       case 4: fn = ENG_PICK(4); break;

@@ -305,6 +305,16 @@ void decode_engine_forget_census_moe();
 void decode_engine_set_trace_moe(void* dev_buffer);
 void decode_engine_set_knobs_moe(int thin, int depth);
 void decode_engine_set_holders_moe(int on);
+// ... and a fourth time (round 5, decode_engine_next.o: -DENG_SUFFIX=_next -DENG_HEADLINE_ONLY=1 + the ENG_SENT / ENG_KV_PROG /
+// ENG_SLP_* switches build_native.py lists): the dense GQA-4 shapes with rows of 4-piece groups, i.e. the headline model.  The
+// frozen default object stays in the library (every other dense shape; MI_ENGINE_VARIANT=2 routes the headline to it for A/B).
+bool decode_engine_applicable_next(const EngProblem& pr, char* why, size_t why_len);
+hipError_t launch_decode_engine_next(const EngProblem& pr, hipStream_t s, bool* declined);
+const char* decode_engine_census_detail_next();
+void decode_engine_forget_census_next();
+void decode_engine_set_trace_next(void* dev_buffer);
+void decode_engine_set_knobs_next(int thin, int depth);
+void decode_engine_set_holders_next(int on);
 
 // ---------------------------------------------------------------------------------------------- generic storage dtype
 // generic.hip: the operator sequence of the hot path for fp32 / fp16 storage (and for bf16 shapes the tuned kernels

@@ -16,6 +16,7 @@ N / (T_step + N x hop) against 1 / (T_step + N x hop) for the relay.
 """
 from __future__ import annotations
 
+import time
 from typing import List, Tuple
 
 import torch
@@ -49,6 +50,7 @@ class InterleavedDecoder:
         self.logits = torch.empty((1, model.vocab_size), dtype=torch.float32, device=dev) if self.is_last else None
         self.h = [torch.empty((1, model.args.dim), dtype=model.dtype, device=dev) for _ in range(2)]  # in flight / being filled
         self.steps_done = 0
+        self.tick_host_us = 0.0  # host time per tick of the last run() (enqueue cost of one stage call + one grouped exchange)
 
     def run(self, n: int) -> Tuple[torch.Tensor, torch.Tensor]:
         m, N, r = self.model, self.world, self.rank
@@ -59,6 +61,7 @@ class InterleavedDecoder:
         total = n * N
         nxt, prv = (r + 1) % N, (r - 1) % N
         cur = 0  # index of the activation buffer this stage computes in
+        t_host = time.perf_counter()
         for t in range(total + N - 1):
             idx = t - r
             active = 0 <= idx < total
@@ -87,6 +90,7 @@ class InterleavedDecoder:
                 m.pp_comm.exchange(send_t, nxt, recv_t, prv)
                 if not self.is_first and recv_t is not None:
                     cur = 1 - cur
+        self.tick_host_us = (time.perf_counter() - t_host) / max(1, total + N - 1) * 1e6
         if N > 1:
             m.pp_comm.broadcast(out_tok, src=N - 1)
             m.pp_comm.broadcast(out_lp, src=N - 1)

@@ -96,6 +96,69 @@ FILE_VARIANTS = {
 }
 
 
+# Engine experiment SLOTS: many compiles of decode_engine.hip (headline instantiation only, ~8 s each) linked into ONE library
+# under the names *_x<N>; scripts/engine_ab.py times them all in one process on one set of weights (mi_debug_set_engine_slot).
+#     python scripts/build_variants.py engine_slots [names...]   ->  lib/variants/libmistral_hip_slots.so + slots.json
+ENGINE_SLOTS = {
+    "copy": (),                                                     # control: the shipped source, this one instantiation
+    "ar": ("-DENG_ABORT_RARE=1",),                                  # round-5 call 1: -0.8 %
+    "ar_b128": ("-DENG_ABORT_RARE=1", "-DENG_DONE_B128=1"),
+    "ar_cache": ("-DENG_ABORT_RARE=1", "-DENG_DONE_CACHE=1"),
+    "ar_b128_cache": ("-DENG_ABORT_RARE=1", "-DENG_DONE_B128=1", "-DENG_DONE_CACHE=1"),
+    "ar_fill8": ("-DENG_ABORT_RARE=1", "-DENG_FILL=8"),
+    "ar_slpfill0": ("-DENG_ABORT_RARE=1", "-DENG_SLP_FILL=0"),
+    "ar_slpfill2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_FILL=2"),
+    "ar_slpfill4": ("-DENG_ABORT_RARE=1", "-DENG_SLP_FILL=4"),
+    "ar_cbar0": ("-DENG_ABORT_RARE=1", "-DENG_SLP_CBAR=0"),
+    "ar_cbar2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_CBAR=2"),
+    "ar_sweep0": ("-DENG_ABORT_RARE=1", "-DENG_SLP_SWEEP=0"),
+    "ar_sweep2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_SWEEP=2"),
+    "ar_sweep4": ("-DENG_ABORT_RARE=1", "-DENG_SLP_SWEEP=4"),
+    "ar_ring2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_RING=2"),
+    "ar_ring8": ("-DENG_ABORT_RARE=1", "-DENG_SLP_RING=8"),
+    "ar_stop2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_STOP=2"),
+    "ar_stop8": ("-DENG_ABORT_RARE=1", "-DENG_SLP_STOP=8"),
+    "ar_hold4": ("-DENG_ABORT_RARE=1", "-DENG_SLP_HOLD=4"),
+    "ar_hold32": ("-DENG_ABORT_RARE=1", "-DENG_SLP_HOLD=32"),
+    "ar_prio1": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"),
+    "ar_prio2": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=2"),
+    "ar_trace0": ("-DENG_ABORT_RARE=1", "-DENG_TRACE=0"),
+    "ar_trace2": ("-DENG_ABORT_RARE=1", "-DENG_TRACE=2"),
+}
+
+
+def build_engine_slots(names):
+    import json
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    names = [n for n in (names or ENGINE_SLOTS)]
+    obj_dir = "/tmp/obj_slots"
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = b._hipcc()
+    src = os.path.join(b.CSRC, "decode_engine.hip")
+    jobs, objs = [], []
+    for i, n in enumerate(names):
+        flags = ENGINE_SLOTS[n] if n in ENGINE_SLOTS else tuple(n.split(","))  # (an ad-hoc slot: comma-separated flags)
+        o = os.path.join(obj_dir, f"de_x{i}.o")
+        objs.append(o)
+        jobs.append([hipcc, *b.FLAGS, *b.PER_FILE_FLAGS.get("decode_engine.hip", []), f"-DENG_SUFFIX=_x{i}", "-DENG_HEADLINE_ONLY=1",
+                     *flags, "-c", src, "-o", o])
+    api_o = os.path.join(obj_dir, "api.o")
+    slot_list = " ".join(f"X({i})" for i in range(len(names)))
+    jobs.append([hipcc, *b.FLAGS, f"-DMI_SLOT_LIST={slot_list}", "-c", os.path.join(b.CSRC, "api.hip"), "-o", api_o])
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-3000:])
+    main = [api_o if s_ == "api.hip" else os.path.join(b.OBJ, s_.replace(".hip", ".o")) for s_ in b.SOURCES]
+    main += [os.path.join(b.OBJ, v) for v in b.VARIANT_OBJECTS]
+    lib = os.path.join(ROOT, "lib", "variants", "libmistral_hip_slots.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *main, *objs, "-ldl", "-o", lib], check=True)
+    with open(os.path.join(ROOT, "lib", "variants", "slots.json"), "w") as f:
+        json.dump({"slots": [{"index": i, "name": n, "flags": list(ENGINE_SLOTS.get(n, n.split(",")))} for i, n in enumerate(names)]}, f, indent=1)
+    return lib
+
+
 def build_file_variant(name, src, flags):
     import subprocess
     obj_dir = f"/tmp/obj_{name}"
@@ -113,6 +176,9 @@ def build_file_variant(name, src, flags):
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "lib", "variants"), exist_ok=True)
     b.build(verbose=False)
+    if "engine_slots" in sys.argv[1:]:
+        print(build_engine_slots(sys.argv[sys.argv.index("engine_slots") + 1:]), flush=True)
+        sys.exit(0)
     for name, (src, flags) in FILE_VARIANTS.items():
         if name in sys.argv[1:] or "gemm" in sys.argv[1:] and name.startswith("g_") or "attn" in sys.argv[1:] and name.startswith("a_") or "engine_flags" in sys.argv[1:] and name.startswith("e_") and not name.startswith("e_mask") or "engine_masks" in sys.argv[1:] and name.startswith("e_mask") or "launch_flags" in sys.argv[1:] and name.startswith("l_"):
             print(name, build_file_variant(name, src, flags), flush=True)

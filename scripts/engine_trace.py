@@ -56,10 +56,14 @@ def main():
         L.mi_debug_set_engine_trace(None)
     print("status", _hip.decode_engine_status(model._backend._workspace), "step ms (traced)", e0.elapsed_time(e1))
     t = buf.cpu().numpy().reshape(-1, 32, 26).astype(np.float64)
-    nb = t.shape[0]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "engine_trace.npy"), t)
-    nl = opt.layers
+    report(t, opt.layers)
+
+
+def report(t, nl):
+    """Print the phase timeline of one traced launch: t[cu][layer][event] in 100 MHz ticks (scripts/engine_ab.py calls this too)."""
+    nb = t.shape[0]
     us = 0.01  # 100 MHz ticks -> us
     t0 = t[:, 0, 0].min()
     print(f"CUs {nb}, layers {nl}; whole launch span (first start -> last end): "
@@ -100,7 +104,8 @@ def handoffs(t, nl):
     stamps of consumer wave 0 of every CU.  Usable offline: `engine_trace.py --analyze gpurun_out/engine_trace.npy`."""
     us = 0.01
     mid = range(2, max(3, nl - 2))
-    edges = [("W2 rows (prev) -> h", 16, 1, True), ("q|k|v rows -> q", 3, 5, False), ("partials -> merge", 7, 8, False),
+    edges = [("W2 rows (prev) -> h", 17, 1, True),  # (event 17: all four waves are through their W2 units; 16 is wave 0 alone)
+             ("q|k|v rows -> q", 3, 5, False), ("partials -> merge", 7, 8, False),
              ("merged -> attn", 9, 10, False), ("Wo rows -> h1", 11, 12, False), ("W1|W3 rows -> hid", 14, 15, False)]
     print("\nhand-offs (us, middle layers): producers' skew max-median | first sweep done - last producer done | "
           "median consumer's wait (median gathered - median producer end)")

@@ -268,6 +268,50 @@ def test_wide_engine_build_bit_equal_launch_path(name):
         assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
 
 
+# The NEXT build (round 5: decode_engine_next.o = the same source with sentinel-first sweeps on the W2 -> h and W1|W3 -> hid
+# edges, the loader streaming through the sentinel wait, fill-by-fill K/V waits): the dense GQA-4 shapes whose rows are all
+# multiples of 4 pieces - the headline model - are routed to it.  None of SHAPES qualifies, so its code runs here at sizes the
+# suite can afford, against the launch path AND against the frozen default object (mi_debug_set_engine_variant(2)).
+NEXT_SHAPES = {
+    # holder waves on (12 W1|W3 units per CU), ring wraps
+    "holders_window_wraps": dict(dim=2048, n_layers=3, head_dim=128, hidden_dim=6144, n_heads=16, n_kv_heads=4, norm_eps=1e-5,
+                                 vocab_size=1000, sliding_window=48),
+    # no holder waves (4 units per CU), 1200-slot ring with empty later splits, some CUs without a W2 / Wo unit pair
+    "no_holders_long_ring": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=16, n_kv_heads=4, norm_eps=1e-6,
+                                 vocab_size=514, sliding_window=1200),
+    # the headline's widths at 2 layers: dim 4096, 32 / 8 heads, hidden 14336
+    "headline_widths": dict(dim=4096, n_layers=2, head_dim=128, hidden_dim=14336, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                            vocab_size=2048, sliding_window=64),
+}
+
+
+@pytest.mark.parametrize("name", sorted(NEXT_SHAPES))
+def test_next_engine_build_bit_equal_launch_path_and_frozen_build(name):
+    from mistral_inference import _hip
+    p = NEXT_SHAPES[name]
+    m, _ = _model(mo.OracleArgs(**p), seed=19)
+    prompt_len, steps = (40, 14) if p["sliding_window"] < 100 else (300, 8)
+    ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(3)).cuda()
+    ref, ref_rings, st0 = _run(m, ids, prompt_len, steps, engine=False)
+    got, got_rings, st1 = _run(m, ids, prompt_len, steps, engine=True)
+    graph, _, st2 = _run(m, ids, prompt_len, steps, engine=True, graph=True)
+    prev = _hip.lib().mi_debug_set_engine_variant(2)
+    try:
+        frozen, frozen_rings, st3 = _run(m, ids, prompt_len, steps, engine=True)
+    finally:
+        _hip.lib().mi_debug_set_engine_variant(prev)
+    assert st1["status"] == 0 and st1["abort"] == 0 and st2["status"] == 0 and st3["status"] == 0, (st1, st2, st3)
+    assert st1["engine_launches"] - st0["engine_launches"] >= steps and st3["engine_launches"] - st2["engine_launches"] >= steps
+    for i, (a, b, c, d) in enumerate(zip(ref, got, graph, frozen)):
+        assert torch.isfinite(b).all(), i
+        assert torch.equal(a, b), (name, i, float((a - b).abs().max()))
+        assert torch.equal(a, c), (name, "graph", i)
+        assert torch.equal(a, d), (name, "frozen", i)
+    for l, ((k0, v0), (k1, v1), (k2, v2)) in enumerate(zip(ref_rings, got_rings, frozen_rings)):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
+        assert torch.equal(k0, k2) and torch.equal(v0, v2), (name, "frozen", l)
+
+
 def test_engine_right_after_a_one_token_prompt():
     """kv_len = 2, 3, ...: every split but the first is empty, the current slot is the only other key."""
     p = SHAPES["gqa4_window_wraps"]
