@@ -657,11 +657,12 @@ def main() -> None:
                               "prefill_tokens_per_s": round(T0 / pre2, 1),
                               "prefill_mfma_frac": round(prefill_flops(mx_params, T0) / pre2 / 2.5e15 / world, 4),
                               "transport": type(m2.pp_comm).__name__}
-            if dt2_il is not None:  # the pipeline's throughput (one sequence per stage in flight) next to the single-sequence relay
+            if dt2_il is not None:  # the pipeline's throughput (one sequence per stage in flight) beside the single-sequence relay
                 r2 = K * world / dt2_il
-                out["mixtral"].update({"single_stream_tokens_per_s": out["mixtral"]["tokens_per_s"], "tokens_per_s": round(r2, 2),
-                                       "ms_per_step": round(dt2_il / K * 1e3, 4), "sequences_in_flight": world,
-                                       "hbm_roofline_frac": round(b2 * r2 / 1e9 / (HBM_PEAK_GBS * world), 4)})
+                out["mixtral"]["pipeline_throughput"] = {
+                    "tokens_per_s": round(r2, 2), "tokens_per_s_per_gpu": round(r2 / world, 2), "ms_per_round": round(dt2_il / K * 1e3, 4),
+                    "sequences_in_flight": world, "hbm_roofline_frac": round(b2 * r2 / 1e9 / (HBM_PEAK_GBS * world), 4),
+                    "tick_host_us": round(getattr(interleaved_run, "tick_host_us", float("nan")), 2)}
         del m2, c2
     if world > 1:
         torch.distributed.barrier()

@@ -228,6 +228,11 @@ __global__ __launch_bounds__(ST) void sample_top_p_kernel(const float* logits, i
                                                          const float* uniforms, int64_t* tok, float* lp, int64_t* hist_tok,
                                                          float* hist_lp, int hist_len, const uint32_t* ctrl) {
   __shared__ Scratch sc;
+  // Behind the persistent decode engine: a launch that failed its residency gate (status 0x700) wrote nothing - no logits, no
+  // step count - and poisons the workspace until the host has re-run the step on the launch path (GreedySession._recover).
+  // Drawing from whatever the logits buffer holds would overwrite `tok`, which is the NEXT step's input id and the id the
+  // recovery re-runs from.  (The stand-alone mi_sample_top_p passes no control block.)
+  if (ctrl && ctrl[1] != 0) return;
   const int b = blockIdx.x;
   Row r;
   r.x = logits + (size_t)b * ld;

@@ -216,7 +216,17 @@ def sample(logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tens
     native launch (mi_sample_top_p: no sort of the vocabulary, no host sync), seeded from torch's default generator."""
     if temperature > 0 and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2:
         from . import _hip
-        tok, _ = _hip.sample_top_p(logits.contiguous(), temperature, top_p, seed=int(torch.randint(0, 2 ** 62, (1,)).item()))
+        # Seeding contract: one 62-bit seed per call from torch's DEFAULT (CPU) generator, i.e. `torch.manual_seed` makes a
+        # generation reproducible; a seeded CUDA generator (what the reference's torch.multinomial consumes) does not enter.
+        seed = torch.randint(0, 2 ** 62, (1,))
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # pipeline ranks sample the same broadcast logits: they must draw the same variate whatever state their own CPU
+            # generators are in - rank 0's seed for everybody (the fused session does the same once per generation)
+            box = seed.to(logits.device) if dist.get_backend() == "nccl" else seed
+            dist.broadcast(box, src=0)
+            seed = box.cpu()
+        tok, _ = _hip.sample_top_p(logits.contiguous(), temperature, top_p, seed=int(seed.item()))
         return tok.reshape(-1)
     if temperature > 0:
         probs = torch.softmax(logits / temperature, dim=-1)

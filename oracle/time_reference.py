@@ -3,7 +3,7 @@
 given context, on a bounded sample (a few of the model's layers + the LM head), scaled linearly in the layer count.
 
 Test/bench infrastructure (bench.py's `cpu_baseline` leg runs it in a subprocess when the reference source is present -
-the build container; the GPU box has no /root/reference and falls back to the oracle port).  Prints one JSON line.
+the build container - or, on the GPU box, its byte-compiled form under oracle/_ref, see oracle/build_ref.py).  Prints one JSON line.
 """
 import argparse
 import json
@@ -13,6 +13,8 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("MISTRAL_REFERENCE_SRC", "/root/reference/src")
+if not os.path.isdir(os.path.join(REF, "mistral_inference")):
+    REF = os.path.join(HERE, "_ref")  # the same package byte-compiled from the unmodified source (oracle/build_ref.py)
 sys.path[:0] = [os.path.join(HERE, "shim"), REF]
 
 import torch  # noqa: E402

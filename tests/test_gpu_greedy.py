@@ -179,6 +179,38 @@ def test_generate_fused_equals_unfused_with_and_without_eos():
         assert a[0] == b[0], eos
 
 
+def test_residency_gate_failure_on_the_first_sampled_step_keeps_the_input_token():
+    """temperature > 0: the nucleus draw is its own small kernel behind the engine launch.  When the FIRST step of a session
+    fails its residency gate the logits buffer has never been written: the draw must not run (it would replace the input id
+    the recovery re-runs from by a sample of garbage).  Same seed, same tokens as an undisturbed session."""
+    from mistral_inference import _hip
+    m = _model(DENSE, seed=8)
+    prompts = _prompts(1, DENSE["vocab_size"], 4)
+    kw = dict(graph=True, temperature=0.7, top_p=0.8, seed=1234)
+    try:
+        c, last = _prefill(m, prompts, 60)
+        first = torch.argmax(last, dim=-1)
+        sess = m.greedy_session(c, first, **kw)
+        sess.run(6)
+        ref_t, ref_lp = sess.collect()
+        assert _hip.decode_engine_status(m._backend._workspace)["engine_launches"] >= 6
+        c2, last2 = _prefill(m, prompts, 60)
+        sess2 = m.greedy_session(c2, torch.argmax(last2, dim=-1), **kw)
+        sess2.logits.fill_(float("nan"))               # what a draw from the never-written buffer would see
+        _hip.debug_engine_sabotage(m._backend._workspace, 1)
+        sess2.run(6)                                   # step 0 fails its gate, the rest find the workspace poisoned
+        torch.cuda.synchronize()
+        assert _hip.decode_engine_status(m._backend._workspace)["status"] == 0x700
+        assert torch.equal(sess2.buf.tok, first), (sess2.buf.tok.tolist(), first.tolist())   # the input id survived
+        got_t, got_lp = sess2.collect()                # re-runs the six steps on the launch path
+        assert torch.equal(got_t, ref_t), (got_t[:, 0].tolist(), ref_t[:, 0].tolist())
+        assert float((got_lp - ref_lp).abs().max()) < 2e-5
+    finally:
+        if m._backend._workspace is not None:
+            _hip.debug_engine_sabotage(m._backend._workspace, 0)
+        _hip.set_decode_engine(True)
+
+
 def test_residency_gate_failure_writes_nothing_and_steps_are_rerun():
     """An engine launch whose residency census fails (here: sabotaged to wait for one workgroup too many) must leave
     position, rings and samples untouched, poison the workspace (later launches leave at once) and report 0x700;

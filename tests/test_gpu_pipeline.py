@@ -116,14 +116,22 @@ def test_bench_two_ranks_prints_one_json_line():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    # N > 1 headline: the pipeline's throughput, one sequence per stage in flight (weak scaling); the single-sequence relay beside it
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["sequences_in_flight"] == 2 and d["single_stream"]["tokens_per_s"] > 0
+    # N > 1 headline = the BASELINE metric: ONE sequence relayed through the stages (strong scaling, the reference's pipeline);
+    # the throughput mode (one sequence per stage in flight) in its own object, with the host cost per tick of its loop
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["metric"].startswith("decode tokens/sec/GPU (batch=1")
+    pt = d["pipeline_throughput"]
+    assert pt["sequences_in_flight"] == 2 and pt["scaling"] == "weak" and pt["tokens_per_s"] > 0 and pt["tick_host_us"] > 0
+    assert abs(pt["tokens_per_s_per_gpu"] * 2 - pt["tokens_per_s"]) < 0.02
+    assert d["distributed"] == {"backend": "gloo", "world_size": 2, "transport": "TorchDistComm", "rccl_comm_ranks": None}
     assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
+    per_rank = d["roofline_per_rank"]
+    assert [r["rank"] for r in per_rank] == [0, 1] and [r["lm_head"] for r in per_rank] == [False, True]
+    assert all(0 < r["frac"] < 1 and r["layers"] == 2 for r in per_rank)
     # north_star's multi-GPU model: a Mixtral sub-measurement over the same stages (8x7B dims for N < 8, layer-truncated here)
     mx = d["mixtral"]
     assert "Mixtral-8x7B" in mx["model"] and mx["tokens_per_s"] > 0 and 0 < mx["hbm_roofline_frac"] < 1 and mx["prefill_tokens_per_s"] > 0
-    assert mx["sequences_in_flight"] == 2 and mx["single_stream_tokens_per_s"] > 0
+    assert mx["pipeline_throughput"]["sequences_in_flight"] == 2 and mx["pipeline_throughput"]["tokens_per_s"] > 0
 
 
 def test_plain_bench_invocation_spawns_its_own_ranks():
