@@ -99,31 +99,13 @@ FILE_VARIANTS = {
 # Engine experiment SLOTS: many compiles of decode_engine.hip (headline instantiation only, ~8 s each) linked into ONE library
 # under the names *_x<N>; scripts/engine_ab.py times them all in one process on one set of weights (mi_debug_set_engine_slot).
 #     python scripts/build_variants.py engine_slots [names...]   ->  lib/variants/libmistral_hip_slots.so + slots.json
+_AP = ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1")   # round-5 calls 1-2: abort word read rarely (-0.8 %), consumers at priority 1 (-0.25 %)
 ENGINE_SLOTS = {
-    "copy": (),                                                     # control: the shipped source, this one instantiation
-    "ar": ("-DENG_ABORT_RARE=1",),                                  # round-5 call 1: -0.8 %
-    "ar_b128": ("-DENG_ABORT_RARE=1", "-DENG_DONE_B128=1"),
-    "ar_cache": ("-DENG_ABORT_RARE=1", "-DENG_DONE_CACHE=1"),
-    "ar_b128_cache": ("-DENG_ABORT_RARE=1", "-DENG_DONE_B128=1", "-DENG_DONE_CACHE=1"),
-    "ar_fill8": ("-DENG_ABORT_RARE=1", "-DENG_FILL=8"),
-    "ar_slpfill0": ("-DENG_ABORT_RARE=1", "-DENG_SLP_FILL=0"),
-    "ar_slpfill2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_FILL=2"),
-    "ar_slpfill4": ("-DENG_ABORT_RARE=1", "-DENG_SLP_FILL=4"),
-    "ar_cbar0": ("-DENG_ABORT_RARE=1", "-DENG_SLP_CBAR=0"),
-    "ar_cbar2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_CBAR=2"),
-    "ar_sweep0": ("-DENG_ABORT_RARE=1", "-DENG_SLP_SWEEP=0"),
-    "ar_sweep2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_SWEEP=2"),
-    "ar_sweep4": ("-DENG_ABORT_RARE=1", "-DENG_SLP_SWEEP=4"),
-    "ar_ring2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_RING=2"),
-    "ar_ring8": ("-DENG_ABORT_RARE=1", "-DENG_SLP_RING=8"),
-    "ar_stop2": ("-DENG_ABORT_RARE=1", "-DENG_SLP_STOP=2"),
-    "ar_stop8": ("-DENG_ABORT_RARE=1", "-DENG_SLP_STOP=8"),
-    "ar_hold4": ("-DENG_ABORT_RARE=1", "-DENG_SLP_HOLD=4"),
-    "ar_hold32": ("-DENG_ABORT_RARE=1", "-DENG_SLP_HOLD=32"),
-    "ar_prio1": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"),
-    "ar_prio2": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=2"),
-    "ar_trace0": ("-DENG_ABORT_RARE=1", "-DENG_TRACE=0"),
-    "ar_trace2": ("-DENG_ABORT_RARE=1", "-DENG_TRACE=2"),
+    "ap": _AP,
+    "ap_dyn3": _AP + ("-DENG_DYN=3",),
+    "ap_dyn3_self": _AP + ("-DENG_DYN=3", "-DENG_DYN_SELF=1"),
+    "ap_dyn6_self": _AP + ("-DENG_DYN=6", "-DENG_DYN_SELF=1"),
+    "ap_dyn3_self_lead4": _AP + ("-DENG_DYN=3", "-DENG_DYN_SELF=1", "-DENG_DYN_LEAD=4"),
 }
 
 
