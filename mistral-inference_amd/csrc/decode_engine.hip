@@ -143,25 +143,13 @@ constexpr int NCONS = 4;
 #ifndef ENG_CONS_PRIO
 #define ENG_CONS_PRIO 0   // s_setprio of the consumer waves (the loader runs at 3, holders at 0)
 #endif
-// ENG_DYN = n > 0: DYNAMIC TAIL of the W1|W3 phase.  The phase is ~28 us of streaming per workgroup and ends with the one
-// all-to-all whose wait is dominated by stragglers: per layer the slowest workgroup finishes ~3.3 us after the average one
-// (in-kernel timelines: a per-XCD part that differs from box to box plus ~1.3 us of per-layer jitter, maximum over 256) and
-// every workgroup waits for it.  With ENG_DYN the last n ring units of every workgroup's slab are not its own: they form
-// pools (8 shards of NB / 8 workgroups, each shard mixing all XCDs) that workgroups draw from as they get there - one
-// device-scope fetch-add per unit, issued by the idle holder wave 0 one unit ahead of the loader, which passes the unit id on
-// to the consumers through LDS.  A unit's arithmetic does not depend on who computes it (the hid granule is addressed by
-// the GLOBAL unit id), so results stay bit-identical; the pool counters only ever grow (base read at kernel entry).
-#ifndef ENG_DYN
-#define ENG_DYN 0
-#endif
-#ifndef ENG_DYN_SELF
-#define ENG_DYN_SELF 0
-#endif
-#ifndef ENG_DYN_LEAD
-#define ENG_DYN_LEAD 2    // the loader asks for its first pool unit when it starts its (LEAD)th-last static unit
-#endif
-#ifndef ENG_DYN_AHEAD
-#define ENG_DYN_AHEAD 1   // pool units the dispatcher keeps drawn ahead of the loader
+// ENG_HOLD_SPLIT = 1: a FOURTH held W1|W3 unit per workgroup.  A holder wave uses 128 of its 256 VGPRs for its unit; holders
+// 0 and 1 additionally keep one (w1, w3) row PAIR each of a fourth unit (64 VGPRs more) - holder 0 the pair that gives the
+// low half of that unit's hid granule, holder 1 the high half; holder 0 passes its 16 bits through LDS (C_HHALF) and holder
+// 1 publishes the granule.  32 KiB more per workgroup and layer that is fetched while the attention block's hand-offs keep
+// the ring full, instead of through the HBM-bound W1|W3 phase (1.16 us of stream per layer).
+#ifndef ENG_HOLD_SPLIT
+#define ENG_HOLD_SPLIT 0
 #endif
 constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
@@ -209,13 +197,7 @@ enum : int {
   C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
   C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
-  C_PQ = 44,        // [4] ENG_DYN: pool entries drawn by the dispatcher (global unit id + 1; P_END: the pool is empty)
-  C_PGRAB = 48,     // ENG_DYN: entries written so far (dispatcher -> loader), cumulative over the launch
-  C_PTAKEN = 49,    // ENG_DYN: entries taken so far (loader -> dispatcher)
-  C_PWANT = 50,     // ENG_DYN: (layer + 1) once the loader is about to run out of static units
-  C_UID = 52,       // [8] ENG_DYN: global ids of the dynamic units in stream order (loader -> consumers)
-  C_NDYN = 60,      // ENG_DYN: dynamic units announced so far, cumulative
-  C_DEND = 61,      // ENG_DYN: (layer + 1) once the layer's last dynamic unit has been announced
+  C_HHALF = 44,     // ENG_HOLD_SPLIT: ((layer + 1) << 16) | bf16 bits of the split unit's low half (holder 0 -> holder 1)
   C_EXPERT = 20,    // MoE: ((layer + 1) << 16) | expert A | expert B << 8 (ascending ids) once the router has decided (consumers -> loader)
   C_RLOGIT = 24     // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
 };
@@ -223,10 +205,6 @@ enum : int {
 // launches completed, [5] decode steps committed (index into the greedy history ring), [6] workgroup arrivals
 // [7] test hook: engine launches that shall fail their residency gate (mi_debug_engine_sabotage)
 enum : int { G_EPOCH = 0, G_STATUS = 1, G_ABORT = 2, G_BADID = 3, G_LAUNCHES = 4, G_STEPS = 5, G_ARRIVE = 6, G_SABOTAGE = 7 };
-#if ENG_DYN
-constexpr int G_POOL = 64;  // [ENG_MAXL][8] pool counters (words 64 .. 319 of the 1024-word control block)
-constexpr uint32_t P_END = 0xffffffffu;
-#endif
 constexpr uint32_t ARRIVE_POLLS = 1u << 16;  // ~50 ms: far beyond the ~1 us over which a resident grid starts
 
 // Optional timeline (mi_debug_set_engine_trace): trace[c][layer][event] = 100 MHz wall clock.  Consumer wave 0 writes
@@ -335,17 +313,11 @@ __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P
 constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
 __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
   const int P = a.D >> 9;
-  return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
-}
-
-// ENG_DYN: units of every workgroup's W1|W3 slab that go into the shared pools (0: the static split).  Needs equal slabs
-// (every workgroup contributes the same number), shards of equal size, holder waves (holder 0 is the dispatcher) and a few
-// static units per consumer wave in front of the tail.
-__device__ __forceinline__ int dyn_units(const EngArgs& a, int n_f) {
-#if ENG_DYN
-  return (holder_units(a, n_f) > 0 && (a.F / 2) % a.NB == 0 && a.NB % 64 == 0 && n_f - NHOLD - ENG_DYN >= NCONS) ? ENG_DYN : 0;
+#if ENG_HOLD_SPLIT
+  static_assert(NHOLD >= 2, "the split unit needs holders 0 and 1");
+  return (a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD + 1) ? NHOLD + 1 : 0;
 #else
-  return 0;
+  return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
 #endif
 }
 
@@ -533,9 +505,6 @@ struct Loader {
 template <bool MOE>
 __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
   Loader ld{sh, lane, a.ring_fills, a.thin, a.depth};
-#if ENG_DYN
-  uint32_t dyn_taken = 0, dyn_seen = 0;  // pool entries taken / dynamic units announced since the launch began
-#endif
   __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
   const int PD = a.D >> 9;
   for (int l = 0; l < a.n_layers; ++l) {
@@ -564,42 +533,12 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     trace_ev(sh, c, l, TR_CONS + 3, tr);
     if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
     if constexpr (!MOE) {
-#if ENG_DYN
-      const int n_dyn = dyn_units(a, p.f1 - p.f0);
-      const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0) - n_dyn;
-#else
       const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
-#endif
       for (int j = p.f0; j < f_ring; ++j) {
-#if ENG_DYN
-        if (n_dyn && j == max(f_ring - ENG_DYN_LEAD, p.f0)) sh.ctl[C_PWANT] = (uint32_t)(l + 1);
-#endif
         const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
         const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
         ld.template unit<4>(rp, a.D >> 9);
       }
-#if ENG_DYN
-      if (n_dyn) {  // the tail: units drawn from the shard's pool until it is empty (the dispatcher is one unit ahead)
-        for (;;) {
-          uint32_t spins = 0;
-          while (sh.ctl[C_PGRAB] == dyn_taken)
-            if (!spin_ok<ENG_SLP_RING>(sh, spins, 0x100)) break;
-          if (sh.ctl[C_PGRAB] == dyn_taken) break;  // (abandoned wait: the launch is draining)
-          const uint32_t e = sh.ctl[C_PQ + (dyn_taken & 3u)];
-          ++dyn_taken;
-          sh.ctl[C_PTAKEN] = dyn_taken;
-          if (e == P_END) break;
-          const int j = __builtin_amdgcn_readfirstlane((int)(e - 1u));
-          sh.ctl[C_UID + (dyn_seen & 7u)] = (uint32_t)j;
-          ++dyn_seen;
-          sh.ctl[C_NDYN] = dyn_seen;  // (LDS operations of one wave complete in order: the id is there before the count)
-          const size_t r0 = (size_t)(2 * j) * a.D, r1 = r0 + a.D;
-          const bf16_t* const rp[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r1, L.w3 + r1};
-          ld.template unit<4>(rp, a.D >> 9);
-        }
-        sh.ctl[C_DEND] = (uint32_t)(l + 1);
-      }
-#endif
       trace_ev(sh, c, l, TR_CONS + 4, tr);
       ld.pairs(L.w2, p.o0, p.o1, a.F);
     } else {
@@ -1246,9 +1185,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   const int nq = a.H * DH, nkv = a.Hkv * DH;
   uint32_t g = 0;  // first piece of the current segment
   uint32_t hold_target = 0;  // W1|W3 units the holder waves must have finished (cumulative)
-#if ENG_DYN
-  uint32_t dyn_base = 0;     // dynamic W1|W3 units announced in the layers before this one (cumulative, as C_NDYN)
-#endif
   long greedy_token = 0;     // the fused greedy sample (workgroup 0, wave 0, lane 0)
   float greedy_logprob = 0.f;
   bool greedy_valid = false;
@@ -1564,47 +1500,6 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     if constexpr (!MOE) {
       const int n_hold = holder_units(a, p.f1 - p.f0);
       if (n_hold && w == 0) sh.ctl[C_XREADY] = (uint32_t)(l + 1);  // (rmsnorm_store ends with a barrier of the consumer waves)
-#if ENG_DYN
-      if (const int n_dyn = dyn_units(a, p.f1 - p.f0)) {
-        // static units first, then whatever this workgroup's loader draws from the pool: stream unit k >= n_st is the
-        // (k - n_st)th dynamic unit of the layer, announced by the loader (C_UID / C_NDYN) when it starts to stream it
-        const int n_st = p.f1 - p.f0 - n_hold - n_dyn;
-        for (int k = w;; k += NCONS) {
-          const uint32_t ga = g + (uint32_t)(4 * k) * PD;
-          cs.set_done(ga);  // (this wave is done with everything in front of its next unit, whether that unit comes or not)
-          int u = p.f0 + k;
-          if (k >= n_st) {
-            const uint32_t j = (uint32_t)(k - n_st);
-            bool have = false;
-            uint32_t spins = 0;
-            for (;;) {
-              const bool ended = sh.ctl[C_DEND] == (uint32_t)(l + 1);  // read BEFORE the count: then the count is final
-              have = (uint32_t)(sh.ctl[C_NDYN] - dyn_base) > j;
-              if (have || ended) break;
-              if (!spin_ok<ENG_SLP_FILL>(sh, spins, 0x200)) break;
-            }
-            if (!have) break;
-            u = (int)sh.ctl[C_UID + ((dyn_base + j) & 7u)];
-          }
-          float vv[4];
-          cs.template unit_dot<4, ALL4>(ga, PD, xs, vv);
-          const float a0 = vv[0], b0 = vv[1], a1 = vv[2], b1 = vv[3];
-          if (lane == 0) {
-            const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(a0, b0)) | ((uint32_t)f_to_bf(swiglu_bf(a1, b1)) << 16);
-            cs.publish(G + a.g_hid + u, tag_of(l, 5), packed);
-          }
-        }
-        {  // every wave leaves with the layer's final count (the wave that saw the end first may be ahead of the others)
-          uint32_t spins = 0;
-          while (sh.ctl[C_DEND] != (uint32_t)(l + 1))
-            if (!spin_ok<ENG_SLP_FILL>(sh, spins, 0x200)) break;
-          const uint32_t n_dynamic = sh.ctl[C_NDYN] - dyn_base;
-          dyn_base += n_dynamic;
-          g += (uint32_t)(4 * (n_st + (int)n_dynamic)) * PD;
-          cs.set_done(g);
-        }
-      } else
-#endif
       {
         const int n_u = p.f1 - p.f0 - n_hold;  // the slab's last n_hold units belong to the holder waves
         for (int k = w; k < n_u; k += NCONS) {
@@ -1626,7 +1521,11 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       // ================================================================ h = h1 + hid @ W2^T
       cs.cbar();
       if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
+#if ENG_HOLD_SPLIT
+        hold_target += (uint32_t)NHOLD;  // (holder WAVES report, n_hold counts held units)
+#else
         hold_target += (uint32_t)n_hold;
+#endif
         uint32_t spins = 0;
         while (sh.ctl[C_HDONE] < hold_target)
           if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
@@ -1804,23 +1703,19 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
   gu64* G = (gu64*)a.gran;
   const int PD = a.D >> 9;
   const lchar* xl = sh.xs + lane * 16;
-#if ENG_DYN
-  // pool counters only grow: their values at kernel entry (lane l: layer l) are this launch's zero.  No workgroup can draw
-  // from a pool before every workgroup has passed the residency gate, tens of microseconds from here.
-  const int shard = (c >> 3) & 7;
-  uint32_t pool_base = 0, dyn_grabbed = 0;
-#if ENG_DYN_SELF
-  uint32_t dyn_self = 0;
-#endif
-  if (hi == 0 && lane < a.n_layers) pool_base = __hip_atomic_load(sh.ctrl + G_POOL + lane * 8 + shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
   for (int l = 0; l < a.n_layers; ++l) {
     const EngLayer& L = a.L[l];
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
     const int n_hold = holder_units(a, p.f1 - p.f0);
+#if ENG_HOLD_SPLIT
+    if (!n_hold) continue;
+    const int j = p.f1 - n_hold + hi;  // holders 0 .. 2: units f1 - 4 .. f1 - 2; unit f1 - 1 is shared by holders 0 and 1
+    const bool extra = hi < 2;
+#else
     if (hi >= n_hold) continue;
     const int j = p.f1 - n_hold + hi;
+#endif
     uint32_t spins = 0;
     while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
       if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
@@ -1843,6 +1738,23 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
           }
       }
     }
+#if ENG_HOLD_SPLIT
+    u32x4 hx[HOLD_GROUPS][2][4];  // rows (2 jx + hi) of W1 and W3, jx = f1 - 1
+    if (extra) {
+      const size_t rx = (size_t)(2 * (p.f1 - 1) + hi) * a.D + lane * 8;
+      const bf16_t* xrows[2] = {L.w1 + rx, L.w3 + rx};
+#pragma unroll
+      for (int grp = 0; grp < HOLD_GROUPS; ++grp) {
+        spins = 0;
+        while (sh.ctl[C_GATHERING])
+          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hx[grp][r][q] = ld16_nt(xrows[r] + (size_t)min(grp * 4 + q, PD - 1) * 512);
+      }
+    }
+#endif
     spins = 0;
     while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
       if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
@@ -1866,45 +1778,44 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 5 + 1);
       const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(v[0], v[1])) | ((uint32_t)f_to_bf(swiglu_bf(v[2], v[3])) << 16);
       __hip_atomic_store(G + a.g_hid + j, ((unsigned long long)tag << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if !ENG_HOLD_SPLIT
       // the LDS reads of x above were consumed by the dots: the region may be overwritten once every holder says so
       __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#if ENG_DYN
-    // DISPATCHER (holder wave 0, idle from here to the next layer's Wo stream): draws this workgroup's pool units, one
-    // device-scope fetch-add each, ENG_DYN_AHEAD ahead of the loader, and hands the global unit ids over through C_PQ.
-    if (const int n_dyn = (hi == 0) ? dyn_units(a, p.f1 - p.f0) : 0) {
-      const int n_f = p.f1 - p.f0, n_st = n_f - n_hold - n_dyn;
-      const int members = a.NB >> 3;                    // workgroups per shard
-      const uint32_t pool_n = (uint32_t)(members * n_dyn);
-      const uint32_t base = (uint32_t)__shfl((int)pool_base, l, 64);
-      spins = 0;
-      while (sh.ctl[C_PWANT] < (uint32_t)(l + 1))
-        if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
-      for (;;) {
-        spins = 0;
-        while ((uint32_t)(dyn_grabbed - sh.ctl[C_PTAKEN]) >= (uint32_t)ENG_DYN_AHEAD)
-          if (!spin_ok<ENG_SLP_FILL>(sh, spins, 0x600)) return;
-        uint32_t t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(sh.ctrl + G_POOL + l * 8 + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) - base;
-        uint32_t e = P_END;
-#if ENG_DYN_SELF  // diagnostic: the whole machinery, but every workgroup draws exactly its own tail units in order
-        (void)q; (void)pool_n;
-        if (dyn_self < (uint32_t)n_dyn) e = (uint32_t)(p.f0 + n_st + (int)dyn_self) + 1u;
-        dyn_self = e == P_END ? 0u : dyn_self + 1u;
-#else
-        if (q < pool_n) {  // pool entry q: unit (q % n_dyn) of the tail of member (q / n_dyn) of this shard
-          const int i = (int)(q / (uint32_t)n_dyn), r = (int)(q % (uint32_t)n_dyn);
-          const int ci = (i >> 3) * 64 + shard * 8 + (i & 7);
-          e = (uint32_t)(n_f * ci + n_st + r) + 1u;
-        }
 #endif
-        sh.ctl[C_PQ + (dyn_grabbed & 3u)] = e;
-        ++dyn_grabbed;
-        sh.ctl[C_PGRAB] = dyn_grabbed;  // (in order behind the entry)
-        if (e == P_END) break;
+    }
+#if ENG_HOLD_SPLIT
+    if (extra) {  // this wave's half of the shared unit: the same per-row chains as Cons::unit_dot<4>
+      float ax[2] = {0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < HOLD_GROUPS; ++grp)
+        if (grp * 4 < PD) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 xv = lds16(xl + (grp * 4 + q) * PIECE);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ax[r] = dot2_bf16(hx[grp][r][q][i], xv[i], ax[r]);
+          }
+        }
+      const float g1 = wave_sum(ax[0]), g3 = wave_sum(ax[1]);
+      const uint32_t half = (uint32_t)f_to_bf(swiglu_bf(g1, g3));
+      if (hi == 0) {
+        if (lane == 0) sh.ctl[C_HHALF] = ((uint32_t)(l + 1) << 16) | half;
+      } else {
+        uint32_t lo = 0;
+        spins = 0;
+        while (((lo = sh.ctl[C_HHALF]) >> 16) != (uint32_t)(l + 1))
+          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+        if (lane == 0) {
+          const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 5 + 1);
+          __hip_atomic_store(G + a.g_hid + (p.f1 - 1), ((unsigned long long)tag << 32) | (lo & 0xffffu) | (half << 16), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
+    // the LDS reads of x above were consumed by the dots: the region may be overwritten once every holder wave says so
+    if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
   }
 }

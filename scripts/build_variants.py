@@ -101,11 +101,11 @@ FILE_VARIANTS = {
 #     python scripts/build_variants.py engine_slots [names...]   ->  lib/variants/libmistral_hip_slots.so + slots.json
 _AP = ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1")   # round-5 calls 1-2: abort word read rarely (-0.8 %), consumers at priority 1 (-0.25 %)
 ENGINE_SLOTS = {
+    "copy": (),
     "ap": _AP,
-    "ap_dyn3": _AP + ("-DENG_DYN=3",),
-    "ap_dyn3_self": _AP + ("-DENG_DYN=3", "-DENG_DYN_SELF=1"),
-    "ap_dyn6_self": _AP + ("-DENG_DYN=6", "-DENG_DYN_SELF=1"),
-    "ap_dyn3_self_lead4": _AP + ("-DENG_DYN=3", "-DENG_DYN_SELF=1", "-DENG_DYN_LEAD=4"),
+    "ap_split": _AP + ("-DENG_HOLD_SPLIT=1",),                      # a fourth held W1|W3 unit, shared by holders 0 and 1
+    "ap_split_hold4": _AP + ("-DENG_HOLD_SPLIT=1", "-DENG_SLP_HOLD=4"),
+    "split": ("-DENG_HOLD_SPLIT=1",),
 }
 
 
