@@ -28,9 +28,11 @@ PER_FILE_FLAGS = {"decode_engine.hip": os.environ.get("MI_ENGINE_FLAGS", "-mllvm
 # instantiations decline, without touching one instruction of the shipped kernels.
 # round 5: the headline shape's engine (dense GQA-4, rows of 4-piece groups) - the winner of the same-box A/B of
 # scripts/build_variants.py engine_slots / scripts/engine_ab.py (profiles/EXPERIMENTS.md round 5)
-ENGINE_NEXT_FLAGS = ["-DENG_SUFFIX=_next", "-DENG_HEADLINE_ONLY=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"]
+ENGINE_NEXT_FLAGS = ["-DENG_SUFFIX=_next", "-DENG_HEADLINE_ONLY=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1", "-DENG_HOLD_STAGE=2"]
 VARIANT_OBJECTS = {"decode_engine_next.o": ("decode_engine.hip", ENGINE_NEXT_FLAGS),
-                   "decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
+                   # (the wide build also takes the two round-5 switches: +0.7 % on the 8x22B stage; the 8-fill MoE build does NOT -
+                   #  the same two switches make Mixtral-8x7B 4.5 % slower, profiles/EXPERIMENTS.md round 5)
+                   "decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
                    "decode_engine_moe.o": ("decode_engine.hip", ["-DENG_WIDE=2"]),    # 8-fill ring, MoE GQA 4 (Mixtral-8x7B)
                    "gemm256_f16.o": ("gemm256.hip", ["-DG256_F16=1"]),                # the 256-tile GEMM on fp16 payloads (generic path)
                    "attn_prefill_f16.o": ("attn_prefill.hip", ["-DATTN_F16=1"]),      # the MFMA prefill attention on fp16 payloads

@@ -143,13 +143,11 @@ constexpr int NCONS = 4;
 #ifndef ENG_CONS_PRIO
 #define ENG_CONS_PRIO 0   // s_setprio of the consumer waves (the loader runs at 3, holders at 0)
 #endif
-// ENG_HOLD_SPLIT = 1: a FOURTH held W1|W3 unit per workgroup.  A holder wave uses 128 of its 256 VGPRs for its unit; holders
-// 0 and 1 additionally keep one (w1, w3) row PAIR each of a fourth unit (64 VGPRs more) - holder 0 the pair that gives the
-// low half of that unit's hid granule, holder 1 the high half; holder 0 passes its 16 bits through LDS (C_HHALF) and holder
-// 1 publishes the granule.  32 KiB more per workgroup and layer that is fetched while the attention block's hand-offs keep
-// the ring full, instead of through the HBM-bound W1|W3 phase (1.16 us of stream per layer).
-#ifndef ENG_HOLD_SPLIT
-#define ENG_HOLD_SPLIT 0
+#ifndef ENG_HOLD_STAGE
+#define ENG_HOLD_STAGE 3  // the holders' fetch of a layer's units may begin when the loader has issued: 0 nothing yet, 1 q|k|v, 2 + K/V, 3 + Wo
+#endif
+#ifndef ENG_HOLD_CHECK
+#define ENG_HOLD_CHECK 8  // holder loads between two looks at the sweep flag (8: two rows of a 4-piece group; 4: one row)
 #endif
 constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
@@ -197,7 +195,6 @@ enum : int {
   C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
   C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
-  C_HHALF = 44,     // ENG_HOLD_SPLIT: ((layer + 1) << 16) | bf16 bits of the split unit's low half (holder 0 -> holder 1)
   C_EXPERT = 20,    // MoE: ((layer + 1) << 16) | expert A | expert B << 8 (ascending ids) once the router has decided (consumers -> loader)
   C_RLOGIT = 24     // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
 };
@@ -313,12 +310,7 @@ __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P
 constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <= 4096
 __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
   const int P = a.D >> 9;
-#if ENG_HOLD_SPLIT
-  static_assert(NHOLD >= 2, "the split unit needs holders 0 and 1");
-  return (a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD + 1) ? NHOLD + 1 : 0;
-#else
   return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ loader wave
@@ -514,10 +506,12 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     plan_layer(a, L, c, pos, p);
     const bool tr = lane == 0;
     trace_ev(sh, c, l, TR_CONS + 0, tr);
+    if (NHOLD && ENG_HOLD_STAGE == 0) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);
     ld.pairs(L.wq, p.q0, p.q1, a.D);
     ld.pairs(L.wk, p.k0, p.k1, a.D);
     ld.pairs(L.wv, p.v0, p.v1, a.D);
     trace_ev(sh, c, l, TR_CONS + 1, tr);
+    if (NHOLD && ENG_HOLD_STAGE == 1) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);
     if (p.n_att) {  // K piece j, V piece j: 4 ring slots x 256 B each (slots past the ring end are clamped; masked later)
       const int kv_real = p.kvh / a.kv_groups;
       const size_t row_stride = (size_t)a.Hkv * DH;
@@ -529,9 +523,10 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
       }
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
+    if (NHOLD && ENG_HOLD_STAGE == 2) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);
     ld.pairs(L.wo, p.o0, p.o1, a.H * DH);
     trace_ev(sh, c, l, TR_CONS + 3, tr);
-    if (NHOLD) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
+    if (NHOLD && ENG_HOLD_STAGE == 3) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);  // the latency-critical small phases are issued: holders may fetch
     if constexpr (!MOE) {
       const int f_ring = p.f1 - holder_units(a, p.f1 - p.f0);
       for (int j = p.f0; j < f_ring; ++j) {
@@ -1521,11 +1516,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       // ================================================================ h = h1 + hid @ W2^T
       cs.cbar();
       if (n_hold) {  // the holder waves read the activation region too: it is overwritten only when they are done with it
-#if ENG_HOLD_SPLIT
-        hold_target += (uint32_t)NHOLD;  // (holder WAVES report, n_hold counts held units)
-#else
         hold_target += (uint32_t)n_hold;
-#endif
         uint32_t spins = 0;
         while (sh.ctl[C_HDONE] < hold_target)
           if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
@@ -1708,14 +1699,8 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     LayerPlan p;
     plan_layer(a, L, c, pos, p);
     const int n_hold = holder_units(a, p.f1 - p.f0);
-#if ENG_HOLD_SPLIT
-    if (!n_hold) continue;
-    const int j = p.f1 - n_hold + hi;  // holders 0 .. 2: units f1 - 4 .. f1 - 2; unit f1 - 1 is shared by holders 0 and 1
-    const bool extra = hi < 2;
-#else
     if (hi >= n_hold) continue;
     const int j = p.f1 - n_hold + hi;
-#endif
     uint32_t spins = 0;
     while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
       if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
@@ -1730,31 +1715,20 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
         while (sh.ctl[C_GATHERING])
           if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
 #pragma unroll
-        for (int r = 2 * half; r < 2 * half + 2; ++r)
+        for (int r = 2 * half; r < 2 * half + 2; ++r) {
+          if (ENG_HOLD_CHECK == 4 && r == 2 * half + 1) {
+            spins = 0;
+            while (sh.ctl[C_GATHERING])
+              if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int piece = min(grp * 4 + q, PD - 1);  // groups beyond the row are never used (holder_units: PD <= 8)
             hw[grp][r][q] = ld16_nt(rows[r] + (size_t)piece * 512);
           }
+        }
       }
     }
-#if ENG_HOLD_SPLIT
-    u32x4 hx[HOLD_GROUPS][2][4];  // rows (2 jx + hi) of W1 and W3, jx = f1 - 1
-    if (extra) {
-      const size_t rx = (size_t)(2 * (p.f1 - 1) + hi) * a.D + lane * 8;
-      const bf16_t* xrows[2] = {L.w1 + rx, L.w3 + rx};
-#pragma unroll
-      for (int grp = 0; grp < HOLD_GROUPS; ++grp) {
-        spins = 0;
-        while (sh.ctl[C_GATHERING])
-          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hx[grp][r][q] = ld16_nt(xrows[r] + (size_t)min(grp * 4 + q, PD - 1) * 512);
-      }
-    }
-#endif
     spins = 0;
     while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
       if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
@@ -1778,45 +1752,9 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 5 + 1);
       const uint32_t packed = (uint32_t)f_to_bf(swiglu_bf(v[0], v[1])) | ((uint32_t)f_to_bf(swiglu_bf(v[2], v[3])) << 16);
       __hip_atomic_store(G + a.g_hid + j, ((unsigned long long)tag << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if !ENG_HOLD_SPLIT
       // the LDS reads of x above were consumed by the dots: the region may be overwritten once every holder says so
       __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
     }
-#if ENG_HOLD_SPLIT
-    if (extra) {  // this wave's half of the shared unit: the same per-row chains as Cons::unit_dot<4>
-      float ax[2] = {0.f, 0.f};
-#pragma unroll
-      for (int grp = 0; grp < HOLD_GROUPS; ++grp)
-        if (grp * 4 < PD) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const u32x4 xv = lds16(xl + (grp * 4 + q) * PIECE);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) ax[r] = dot2_bf16(hx[grp][r][q][i], xv[i], ax[r]);
-          }
-        }
-      const float g1 = wave_sum(ax[0]), g3 = wave_sum(ax[1]);
-      const uint32_t half = (uint32_t)f_to_bf(swiglu_bf(g1, g3));
-      if (hi == 0) {
-        if (lane == 0) sh.ctl[C_HHALF] = ((uint32_t)(l + 1) << 16) | half;
-      } else {
-        uint32_t lo = 0;
-        spins = 0;
-        while (((lo = sh.ctl[C_HHALF]) >> 16) != (uint32_t)(l + 1))
-          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
-        if (lane == 0) {
-          const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 5 + 1);
-          __hip_atomic_store(G + a.g_hid + (p.f1 - 1), ((unsigned long long)tag << 32) | (lo & 0xffffu) | (half << 16), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    // the LDS reads of x above were consumed by the dots: the region may be overwritten once every holder wave says so
-    if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
   }
 }
 

@@ -103,9 +103,13 @@ _AP = ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1")   # round-5 calls 1-2: abort w
 ENGINE_SLOTS = {
     "copy": (),
     "ap": _AP,
-    "ap_split": _AP + ("-DENG_HOLD_SPLIT=1",),                      # a fourth held W1|W3 unit, shared by holders 0 and 1
-    "ap_split_hold4": _AP + ("-DENG_HOLD_SPLIT=1", "-DENG_SLP_HOLD=4"),
-    "split": ("-DENG_HOLD_SPLIT=1",),
+    "ap_h2": _AP + ("-DENG_HOLDERS=2",),
+    "ap_h1": _AP + ("-DENG_HOLDERS=1",),
+    "ap_stage2": _AP + ("-DENG_HOLD_STAGE=2",),
+    "ap_stage1": _AP + ("-DENG_HOLD_STAGE=1",),
+    "ap_stage0": _AP + ("-DENG_HOLD_STAGE=0",),
+    "ap_check4": _AP + ("-DENG_HOLD_CHECK=4",),
+    "ap_stage2_check4": _AP + ("-DENG_HOLD_STAGE=2", "-DENG_HOLD_CHECK=4"),
 }
 
 
