@@ -33,7 +33,9 @@ VARIANT_OBJECTS = {"decode_engine_next.o": ("decode_engine.hip", ENGINE_NEXT_FLA
                    # (the wide build also takes the two round-5 switches: +0.7 % on the 8x22B stage; the 8-fill MoE build does NOT -
                    #  the same two switches make Mixtral-8x7B 4.5 % slower, profiles/EXPERIMENTS.md round 5)
                    "decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
-                   "decode_engine_moe.o": ("decode_engine.hip", ["-DENG_WIDE=2"]),    # 8-fill ring, MoE GQA 4 (Mixtral-8x7B)
+                   # 8-fill ring, MoE GQA 4 (Mixtral-8x7B); round 5: its idle holder waves keep six q|k|v units of the NEXT layer,
+                   # fetched during the router bubble (ENG_QKV_HOLD = 2: +1.9 % on one box, +-0 on another)
+                   "decode_engine_moe.o": ("decode_engine.hip", ["-DENG_WIDE=2", "-DENG_QKV_HOLD=2"]),
                    "gemm256_f16.o": ("gemm256.hip", ["-DG256_F16=1"]),                # the 256-tile GEMM on fp16 payloads (generic path)
                    "attn_prefill_f16.o": ("attn_prefill.hip", ["-DATTN_F16=1"]),      # the MFMA prefill attention on fp16 payloads
                    "gemv_f16.o": ("gemv.hip", ["-DGEMV_F16=1"])}                      # the weight-streaming GEMV kernels on fp16 payloads

@@ -143,6 +143,16 @@ constexpr int NCONS = 4;
 #ifndef ENG_CONS_PRIO
 #define ENG_CONS_PRIO 0   // s_setprio of the consumer waves (the loader runs at 3, holders at 0)
 #endif
+// ENG_QKV_HOLD = 1 (MoE models; their holder waves have no W1|W3 unit to keep - which experts stream is decided late): the
+// three holder waves keep the LAST SIX q|k|v row-pair units of the NEXT layer in registers (two units = 4 rows = 128 VGPRs
+// each), fetched in the one window of a MoE layer in which HBM idles - the router bubble: the loader has flushed behind
+// the Wo rows and waits for the expert decision (~6 us, profiles/r04_engine_trace_8x7b_*).  When attention_norm(h) of that
+// layer stands in LDS they reduce their rows from registers (the arithmetic of Cons::unit_dot<2>: bit-identical) and run
+// the consumers' epilogue (RoPE, ring write, granule).  96 KiB per workgroup and layer that no longer pass through the ring
+// in the loader-bound q|k|v phase.
+#ifndef ENG_QKV_HOLD
+#define ENG_QKV_HOLD 0
+#endif
 #ifndef ENG_HOLD_STAGE
 #define ENG_HOLD_STAGE 3  // the holders' fetch of a layer's units may begin when the loader has issued: 0 nothing yet, 1 q|k|v, 2 + K/V, 3 + Wo
 #endif
@@ -195,6 +205,9 @@ enum : int {
   C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
   C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
+  C_XA = 21,        // ENG_QKV_HOLD: (layer + 1) once attention_norm(h) of that layer stands in the activation region (-> holders)
+  C_HGO = 23,       // ENG_QKV_HOLD = 2: (layer + 1) once this workgroup has h1 of that layer (the router runs next: no sweep for a while)
+  C_HQDONE = 22,    // ENG_QKV_HOLD: holder waves done with their q|k|v units since the launch began (-> consumers)
   C_EXPERT = 20,    // MoE: ((layer + 1) << 16) | expert A | expert B << 8 (ascending ids) once the router has decided (consumers -> loader)
   C_RLOGIT = 24     // [16] MoE: bf16-rounded router logits of the layer (fp32 words)
 };
@@ -311,6 +324,21 @@ constexpr int HOLD_GROUPS = 2;  // 4-piece groups per row a holder can keep: D <
 __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
   const int P = a.D >> 9;
   return (NHOLD > 0 && a.holders && a.E == 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_f >= 2 * NCONS + NHOLD) ? NHOLD : 0;
+}
+
+#if ENG_QKV_HOLD
+// q|k|v units (row pairs) of a workgroup that the holder waves keep in registers: the last 2 * NHOLD of the list q.., k.., v..
+__device__ __forceinline__ int qkv_held(const EngArgs& a, int n_u) {
+  const int P = a.D >> 9;
+  return (NHOLD > 0 && a.holders && a.E > 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_u >= NCONS + 2 * NHOLD) ? 2 * NHOLD : 0;
+}
+#endif
+// list index k of a workgroup's q|k|v units -> kind (0 q, 1 k, 2 v) and global row pair inside that matrix
+__device__ __forceinline__ void qkv_unit(const LayerPlan& p, int k, int& kind, int& u) {
+  const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0;
+  if (k < nq_u) { kind = 0; u = p.q0 + k; }
+  else if (k < nq_u + nk_u) { kind = 1; u = p.k0 + (k - nq_u); }
+  else { kind = 2; u = p.v0 + (k - nq_u - nk_u); }
 }
 
 // ------------------------------------------------------------------------------------------------ loader wave
@@ -507,9 +535,22 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     const bool tr = lane == 0;
     trace_ev(sh, c, l, TR_CONS + 0, tr);
     if (NHOLD && ENG_HOLD_STAGE == 0) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);
-    ld.pairs(L.wq, p.q0, p.q1, a.D);
-    ld.pairs(L.wk, p.k0, p.k1, a.D);
-    ld.pairs(L.wv, p.v0, p.v1, a.D);
+#if ENG_QKV_HOLD
+    if (const int n_held = qkv_held(a, (p.q1 - p.q0) + 2 * (p.k1 - p.k0))) {  // the list without its last n_held units
+      const int n_s = (p.q1 - p.q0) + 2 * (p.k1 - p.k0) - n_held;
+      for (int k = 0; k < n_s; ++k) {
+        int kind, u;
+        qkv_unit(p, k, kind, u);
+        const bf16_t* base = kind == 0 ? L.wq : (kind == 1 ? L.wk : L.wv);
+        ld.pairs(base, u, u + 1, a.D);
+      }
+    } else
+#endif
+    {
+      ld.pairs(L.wq, p.q0, p.q1, a.D);
+      ld.pairs(L.wk, p.k0, p.k1, a.D);
+      ld.pairs(L.wv, p.v0, p.v1, a.D);
+    }
     trace_ev(sh, c, l, TR_CONS + 1, tr);
     if (NHOLD && ENG_HOLD_STAGE == 1) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);
     if (p.n_att) {  // K piece j, V piece j: 4 ring slots x 256 B each (slots past the ring end are clamped; masked later)
@@ -1180,6 +1221,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
   const int nq = a.H * DH, nkv = a.Hkv * DH;
   uint32_t g = 0;  // first piece of the current segment
   uint32_t hold_target = 0;  // W1|W3 units the holder waves must have finished (cumulative)
+#if ENG_QKV_HOLD
+  uint32_t hq_target = 0;    // holder waves that must have finished their q|k|v units (cumulative)
+#endif
   long greedy_token = 0;     // the fused greedy sample (workgroup 0, wave 0, lane 0)
   float greedy_logprob = 0.f;
   bool greedy_valid = false;
@@ -1256,7 +1300,16 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       }
     }
     {
-      const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0, n_u = nq_u + 2 * nk_u;
+      const int nq_u = p.q1 - p.q0, nk_u = p.k1 - p.k0;
+#if ENG_QKV_HOLD
+      const int n_held = qkv_held(a, nq_u + 2 * nk_u);
+      const int n_u = nq_u + 2 * nk_u - n_held;  // the holder waves reduce the last n_held units from their registers
+      // (rmsnorm_store ended with a barrier of the consumer waves; layer 0: the residency gate has been passed, so the
+      // holders' side effects - granules, ring rows - come after it as well)
+      if (n_held && w == 0) sh.ctl[C_XA] = (uint32_t)(l + 1);
+#else
+      const int n_u = nq_u + 2 * nk_u;
+#endif
       for (int k = w; k < n_u; k += NCONS) {
         const uint32_t ga = g + (uint32_t)(2 * k) * PD;
         cs.set_done(ga);
@@ -1294,6 +1347,14 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
     // ================================================================ attention: this CU's (kv head, split)
     cs.cbar();  // every wave is done with the normalised activations: the region becomes attention scratch
+#if ENG_QKV_HOLD
+    if (qkv_held(a, (p.q1 - p.q0) + 2 * (p.k1 - p.k0))) {  // ... and so are the holder waves (they finished long ago: 4 rows each)
+      hq_target += (uint32_t)NHOLD;
+      uint32_t spins = 0;
+      while (sh.ctl[C_HQDONE] < hq_target)
+        if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
+    }
+#endif
     trace_ev(sh, c, l, 4, trc);
     if (p.att) {
       const int kv_real = p.kvh / a.kv_groups;
@@ -1489,6 +1550,9 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     sh.ctl[C_GATHERING] = 1;
     cs.norm_load_granules(xr, G + a.g_h1, a.D, tag_of(l, 4));
     sh.ctl[C_GATHERING] = 0;
+#if ENG_QKV_HOLD == 2
+    if (MOE && w == 0) sh.ctl[C_HGO] = (uint32_t)(l + 1);
+#endif
     trace_ev(sh, c, l, 12, trc);
     cs.rmsnorm_store(xr, xs, a.D, nw, a.eps);
     trace_ev(sh, c, l, 13, trc);
@@ -1690,6 +1754,111 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 // ------------------------------------------------------------------------------------------------ holder waves
 // Holder hi owns W1|W3 unit f1 - n_hold + hi of every layer (rows w1[2j], w3[2j], w1[2j+1], w3[2j+1]).  Same arithmetic
 // as Cons::unit_dot<4>: per row, pieces in ascending order, four dot2_bf16 per piece, then wave_sum - bit-identical.
+#if ENG_QKV_HOLD
+// MoE models: holder hi keeps q|k|v units n_u - 6 + 2 hi and + 1 of the list (q.., k.., v..) of every layer, fetched during the
+// PREVIOUS layer's router bubble (layer 0: at once).  Rows reduce as in Cons::unit_dot<2>; epilogue as in run_consumer.
+__device__ __forceinline__ void run_qkv_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, int seq, uint32_t epoch) {
+  gu64* G = (gu64*)a.gran;
+  const int PD = a.D >> 9;
+  const lchar* xl = sh.xs + lane * 16;
+  const int nq = a.H * DH, nkv = a.Hkv * DH;
+  {
+    LayerPlan p0;
+    plan_layer(a, a.L[0], c, pos, p0);
+    if (!qkv_held(a, (p0.q1 - p0.q0) + 2 * (p0.k1 - p0.k0))) return;  // (the same answer for every layer: shapes do not change)
+  }
+  u32x4 hw[HOLD_GROUPS][4][4];  // [group][row: unit 0 rows 0-1, unit 1 rows 0-1][piece in group]: constant indices only
+  // iteration l: reduce and publish the units of layer l (held since iteration l - 1), then fetch those of layer l + 1
+  for (int l = -1; l < a.n_layers; ++l) {
+    uint32_t spins = 0;
+    if (l >= 0) {
+      const EngLayer& L = a.L[l];
+      LayerPlan p;
+      plan_layer(a, L, c, pos, p);
+      const int n_u = (p.q1 - p.q0) + 2 * (p.k1 - p.k0);
+      int kind0, u0, kind1, u1;
+      qkv_unit(p, n_u - 2 * NHOLD + 2 * hi, kind0, u0);
+      qkv_unit(p, n_u - 2 * NHOLD + 2 * hi + 1, kind1, u1);
+      const float2 cs0 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + (((2 * u0) % DH) >> 1)) * 2);
+      const float2 cs1 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + (((2 * u1) % DH) >> 1)) * 2);
+      while (sh.ctl[C_XA] < (uint32_t)(l + 1))
+        if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < HOLD_GROUPS; ++grp)
+        if (grp * 4 < PD) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 xv = lds16(xl + (grp * 4 + q) * PIECE);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(hw[grp][r][q][i], xv[i], acc[r]);
+          }
+        }
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = wave_sum(acc[r]);
+      if (lane == 0) {
+        const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 1 + 1);
+        auto finish = [&](int kind, int u, float2 cs2, float d0, float d1) {
+          float y0 = bf_round(d0), y1 = bf_round(d1);
+          if (kind < 2) {  // rope.py:13-23 on the adjacent pair
+            float re, im;
+            rope_pair(y0, y1, cs2.x, cs2.y, re, im);
+            y0 = re;
+            y1 = im;
+          }
+          const uint32_t packed = pack_bf2(y0, y1);
+          if (kind > 0) {  // cache.py:83-92
+            const size_t slot = (size_t)seq * L.W + p.cur_slot;
+            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + 2 * u;
+            *reinterpret_cast<uint32_t*>(ring) = packed;
+          }
+          const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
+          __hip_atomic_store(G + a.g_qkv + gi, ((unsigned long long)tag << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        finish(kind0, u0, cs0, v[0], v[1]);
+        finish(kind1, u1, cs1, v[2], v[3]);
+        __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HQDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    if (l + 1 < a.n_layers) {
+      if (l >= 0) {
+        spins = 0;
+        // ENG_QKV_HOLD = 1: the loader has issued layer l's Wo rows (it flushes and waits for the router next); 2: this workgroup
+        // has gathered h1 - the attention block's sweeps are over, the router's arithmetic begins
+        while (sh.ctl[ENG_QKV_HOLD == 2 ? C_HGO : C_LSTAGE] < (uint32_t)(l + 1))
+          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+      }
+      const EngLayer& L = a.L[l + 1];
+      LayerPlan p;
+      plan_layer(a, L, c, pos, p);
+      const int n_u = (p.q1 - p.q0) + 2 * (p.k1 - p.k0);
+      int kind0, u0, kind1, u1;
+      qkv_unit(p, n_u - 2 * NHOLD + 2 * hi, kind0, u0);
+      qkv_unit(p, n_u - 2 * NHOLD + 2 * hi + 1, kind1, u1);
+      const bf16_t* b0 = (kind0 == 0 ? L.wq : (kind0 == 1 ? L.wk : L.wv)) + (size_t)(2 * u0) * a.D + lane * 8;
+      const bf16_t* b1 = (kind1 == 0 ? L.wq : (kind1 == 1 ? L.wk : L.wv)) + (size_t)(2 * u1) * a.D + lane * 8;
+      const bf16_t* rows[4] = {b0, b0 + a.D, b1, b1 + a.D};
+#pragma unroll
+      for (int grp = 0; grp < HOLD_GROUPS; ++grp) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
+          spins = 0;
+          while (sh.ctl[C_GATHERING])
+            if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+#pragma unroll
+          for (int r = 2 * half; r < 2 * half + 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hw[grp][r][q] = ld16_nt(rows[r] + (size_t)min(grp * 4 + q, PD - 1) * 512);
+        }
+      }
+    }
+  }
+}
+#endif
+
 __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, uint32_t epoch) {
   gu64* G = (gu64*)a.gran;
   const int PD = a.D >> 9;
@@ -1788,6 +1957,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const int seq = 0;
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
   if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
+#if ENG_QKV_HOLD
+  else if (w > NCONS && MOE) run_qkv_holder(a, sh, c, w - NCONS - 1, lane, pos, seq, epoch);
+#endif
   else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);
   else {
     // residency census: every workgroup counts itself in; consumers check the total before their first side effect

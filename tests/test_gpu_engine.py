@@ -98,6 +98,10 @@ SHAPES = {
                                vocab_size=1000, sliding_window=48, num_experts=8, num_experts_per_tok=2),
     "moe_4_experts_mha": dict(dim=1024, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=8, n_kv_heads=8, norm_eps=1e-5,
                               vocab_size=514, sliding_window=None, num_experts=4, num_experts_per_tok=2),
+    # MoE with 12 q|k|v units per workgroup (32 + 2 x 8 heads) and rows of 4 pieces: the holder waves of the MoE engine build
+    # keep the last six units of every layer in registers, fetched during the previous layer's router bubble (ENG_QKV_HOLD)
+    "moe_qkv_holders": dict(dim=2048, n_layers=3, head_dim=128, hidden_dim=2048, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                            vocab_size=1000, sliding_window=48, num_experts=4, num_experts_per_tok=2),
     # rows whose piece count is not a multiple of 4: dim 3072 = 6 pieces (streamed in 2-piece groups), hidden 1536 = 3 (single
     # pieces) - the Mistral-Nemo case (dim 5120 = 10 pieces) in small; 6 kv heads x 32 splits leave a quarter of the CUs without
     # attention work
