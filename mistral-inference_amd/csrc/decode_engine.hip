@@ -153,6 +153,14 @@ constexpr int NCONS = 4;
 #ifndef ENG_QKV_HOLD
 #define ENG_QKV_HOLD 0
 #endif
+// ENG_SADDR = 1: the loader's weight DMAs in the SGPR-base form (`global_load_lds_dwordx4 v_lane_offset, s[base:base+1]`): the
+// per-unit / per-group address arithmetic becomes scalar and no VGPR that an in-flight DMA names is ever rewritten.  (With
+// 64-bit VGPR addresses hipcc guards every rewrite of the address pair with `s_waitcnt vmcnt(0)` - it treats the pair as
+// the destination of a load - which drains the DMA queue once per unit in some builds and not in others: one of the
+// mechanisms behind this kernel's "regimes", profiles/EXPERIMENTS.md round 5.)
+#ifndef ENG_SADDR
+#define ENG_SADDR 0
+#endif
 #ifndef ENG_HOLD_STAGE
 #define ENG_HOLD_STAGE 3  // the holders' fetch of a layer's units may begin when the loader has issued: 0 nothing yet, 1 q|k|v, 2 + K/V, 3 + Wo
 #endif
@@ -348,6 +356,9 @@ struct Loader {
   uint32_t g = 0;    // pieces issued
   uint32_t pub = 0;  // fills published
   uint32_t stalls = 0;  // fills that had to wait for a free ring slot (trace only)
+#if ENG_SADDR
+  uint32_t lane16 = 0;  // this lane's byte offset inside a piece (set by run_loader)
+#endif
 #if ENG_DONE_CACHE
   uint32_t done_seen = 0;  // minimum of the consumer marks at the last look
 #endif
@@ -416,7 +427,7 @@ struct Loader {
   // (checked in the ISA) and is nevertheless 20-30 us per step slower than the builtin form (profiles/EXPERIMENTS.md).
   template <int N>
   __device__ __forceinline__ void dma_n(const void* src_lane, lchar* dst) {
-#if ENG_ASM_DMA
+#if ENG_ASM_DMA || ENG_SADDR == 3  // (SADDR = 3, experiment: the K/V pieces - per-lane row addresses - from inline asm as well; +0.7 %)
     unsigned keep;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<size_t>(dst);
     if constexpr (N == 1)
@@ -443,6 +454,51 @@ struct Loader {
   __device__ __forceinline__ void dma(const void* src_lane, lchar* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (LDS_AS void*)dst, 16, OFF, 2 /* nt */);
   }
+#if ENG_SADDR
+  // wave-uniform base (SGPR pair) + this lane's 32-bit byte offset (one VGPR, written once per launch)
+  template <int OFF>
+  __device__ __forceinline__ void dma_s(const char* sbase, lchar* dst) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(sbase);  // (readfirstlane: an opaque, provably uniform pair)
+    const unsigned long long bu = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const __attribute__((address_space(1))) char* gp = (const __attribute__((address_space(1))) char*)bu + (uint32_t)(lane * 16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (LDS_AS void*)dst, 16, OFF, 2 /* nt */);
+  }
+  __device__ __forceinline__ void piece_s(const char* sbase) {
+    if ((g & (FILL - 1)) == 0) fill_begin();
+    dma_s<0>(sbase, slot_of(g));
+    ++g;
+    if ((g & (FILL - 1)) == 0) fill_end();
+  }
+  __device__ __forceinline__ void piece4_s(const char* sbase) {
+    if ((g & (FILL - 1)) == 0) fill_begin();
+    lchar* dst = slot_of(g);
+#if ENG_SADDR == 2
+    // (hipcc's lowering of the builtin keeps the 64-bit VGPR address even for an SGPR base + zext(VGPR) sum: the SGPR-base
+    // form is written out.  M0 carries the LDS address; it is written in the statement that reads it and restored
+    // (cdna_hip_programming.md section 5.7).  hipcc does not count these loads: every wait for them is the explicit
+    // vmcnt(N) of fill_begin / fill_end / flush, which assume nothing else.)
+    unsigned keep;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<size_t>(dst);
+    const unsigned long long b = reinterpret_cast<unsigned long long>(sbase);
+    const unsigned long long bu = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane16), "s"(bu), "s"(lds_addr) : "memory");
+#else
+    dma_s<0>(sbase, dst);
+    dma_s<PIECE>(sbase, dst);
+    dma_s<2 * PIECE>(sbase, dst);
+    dma_s<3 * PIECE>(sbase, dst);
+#endif
+    g += 4;
+    if ((g & (FILL - 1)) == 0) fill_end();
+  }
+#endif
   __device__ __forceinline__ lchar* slot_of(uint32_t piece_idx) {  // wave-uniform (becomes M0)
     return sh.ring + (uint32_t)__builtin_amdgcn_readfirstlane((int)RING_IDX(sh, piece_idx)) * PIECE;
   }
@@ -500,12 +556,21 @@ struct Loader {
     for (int p0 = 0; p0 < P; p0 += G) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+#if ENG_SADDR
+        const char* sb = reinterpret_cast<const char*>(rp[r]) + (size_t)p0 * PIECE;
+        if (G == 4 && (g & 3) == 0) {
+          piece4_s(sb);
+        } else {
+          for (int i = 0; i < G; ++i) piece_s(sb + (size_t)i * PIECE);
+        }
+#else
         const char* src = reinterpret_cast<const char*>(rp[r]) + (size_t)p0 * PIECE + lane * 16;
         if (G == 4 && (g & 3) == 0) {
           piece4(src);
         } else {
           for (int i = 0; i < G; ++i) piece(src + (size_t)i * PIECE);
         }
+#endif
       }
     }
   }
@@ -525,6 +590,9 @@ struct Loader {
 template <bool MOE>
 __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, int c, int lane, int pos, int seq) {
   Loader ld{sh, lane, a.ring_fills, a.thin, a.depth};
+#if ENG_SADDR
+  ld.lane16 = (uint32_t)lane * 16u;
+#endif
   __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
   const int PD = a.D >> 9;
   for (int l = 0; l < a.n_layers; ++l) {

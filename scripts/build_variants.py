@@ -100,16 +100,18 @@ FILE_VARIANTS = {
 # under the names *_x<N>; scripts/engine_ab.py times them all in one process on one set of weights (mi_debug_set_engine_slot).
 #     python scripts/build_variants.py engine_slots [names...]   ->  lib/variants/libmistral_hip_slots.so + slots.json
 _AP = ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1")   # round-5 calls 1-2: abort word read rarely (-0.8 %), consumers at priority 1 (-0.25 %)
+_NS = _AP + ("-DENG_HOLD_STAGE=2", "-DENG_SADDR=2")
 ENGINE_SLOTS = {
     "copy": (),
-    "ap": _AP,
-    "ap_h2": _AP + ("-DENG_HOLDERS=2",),
-    "ap_h1": _AP + ("-DENG_HOLDERS=1",),
-    "ap_stage2": _AP + ("-DENG_HOLD_STAGE=2",),
-    "ap_stage1": _AP + ("-DENG_HOLD_STAGE=1",),
-    "ap_stage0": _AP + ("-DENG_HOLD_STAGE=0",),
-    "ap_check4": _AP + ("-DENG_HOLD_CHECK=4",),
-    "ap_stage2_check4": _AP + ("-DENG_HOLD_STAGE=2", "-DENG_HOLD_CHECK=4"),
+    "nx": _AP + ("-DENG_HOLD_STAGE=2",),
+    "ns": _NS,                                                      # weight DMAs from inline asm in the SGPR-base form (K/V pieces: the builtin)
+    "ns_trace0": _NS + ("-DENG_TRACE=0",),
+    "ns_cache": _NS + ("-DENG_DONE_CACHE=1",),
+    "ns_b128": _NS + ("-DENG_DONE_B128=1",),
+    "ns_hold4": _NS + ("-DENG_SLP_HOLD=4",),
+    "ns_ring4": _NS + ("-DENG_SLP_RING=4",),
+    "ns_cbar2": _NS + ("-DENG_SLP_CBAR=2",),
+    "ns_prio2": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=2", "-DENG_HOLD_STAGE=2", "-DENG_SADDR=2"),
 }
 
 

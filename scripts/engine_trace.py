@@ -40,6 +40,10 @@ def main():
     cache.reset()
     ids = torch.randint(0, a.vocab_size, (opt.prefill,), generator=torch.Generator().manual_seed(0)).cuda()
     L = _hip.lib()
+    # the stamp sites live in the frozen default build, the wide and the MoE build; the headline shape's `next` build is compiled
+    # without them (ENG_TRACE=0) - route dense models to the frozen build for the trace (variant 2)
+    if not params.get("moe"):
+        L.mi_debug_set_engine_variant(2)
     with torch.inference_mode():
         nxt = torch.argmax(model.forward(ids, [opt.prefill], cache)[-1:], dim=-1)
         for _ in range(4):
