@@ -31,11 +31,11 @@ V=$REPO/mistral-inference_amd/lib/variants/libmistral_hip_e_trace0.so
 for name in shipped e_trace0; do
   if [ $name == e_trace0 ]; then export MISTRAL_HIP_LIB=$V; else unset MISTRAL_HIP_LIB; fi
   # un-profiled timing of the same command first (a profiled pass clocks differently: never compare across)
-  python bench.py --steps 12 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'ms_per_step', d['ms_per_step'], 'kernel_us', d['roofline']['avg_launch_us'])" | tee -a $OUT/table.txt
+  python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'ms_per_step', d['ms_per_step'], 'kernel_us', d['roofline']['avg_launch_us'])" | tee -a $OUT/table.txt
   i=0
   while read -r set; do
     i=$((i+1))
-    (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/raw_${name}_$i -o pmc -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $OUT/log_${name}_$i.txt 2>&1) || echo "set $i failed for $name" | tee -a $OUT/table.txt
+    (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/raw_${name}_$i -o pmc -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $OUT/log_${name}_$i.txt 2>&1) || echo "set $i failed for $name" | tee -a $OUT/table.txt
   done < $OUT/sets.txt
 done
 unset MISTRAL_HIP_LIB

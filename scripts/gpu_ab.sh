@@ -10,7 +10,7 @@ LOG=gpurun_out/ab.log
 : > $LOG
 run() {  # label, env...
   local label=$1; shift
-  env "$@" timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline $EXTRA > gpurun_out/v.out 2>&1
+  env "$@" timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-extras $EXTRA > gpurun_out/v.out 2>&1
   python - "$label" <<'PY' | tee -a gpurun_out/ab.log
 import json, sys
 try:

@@ -10,7 +10,7 @@ run() {  # label, then env assignments, then -- bench args
   local label=$1; shift
   local envs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   local defaults="--steps 64 --warmup 8"; case " $* " in *" --steps "*) defaults="";; esac
-  env "${envs[@]}" timeout 600 python bench.py $defaults --no-cpu-baseline "$@" > gpurun_out/v.out 2>&1
+  env "${envs[@]}" timeout 600 python bench.py $defaults --no-cpu-baseline --no-extras "$@" > gpurun_out/v.out 2>&1
   python - "$label" <<'PY' | tee -a gpurun_out/ab_env.log
 import json, sys
 try:

@@ -10,7 +10,12 @@ LOG=gpurun_out/final.log
 timeout 1000 python -m pytest tests -m gpu -q -x -s > gpurun_out/pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -5 | tee -a $LOG
 grep -E "layer parity|8 layers, 4096|Mixtral-8x7B dims x 4|Mixtral-8x22B dims x 3|Nemo-12B dims x 4|max\|HIP|bit-exact" gpurun_out/pytest_gpu.log | cut -c1-400 >> $LOG
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | cut -c1-500 | tee -a $LOG
-timeout 300 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 | tee gpurun_out/bench_steps20.json.log | cut -c1-600 | tee -a $LOG
-timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_steps64.json.log | cut -c1-300 | tee -a $LOG
-timeout 400 bash scripts/profile_round.sh > gpurun_out/profile_round.log 2>&1; tail -3 gpurun_out/profile_round.log | cut -c1-200
+timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 | tee gpurun_out/bench_steps20.json.log | cut -c1-600 | tee -a $LOG
+timeout 300 python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_steps64.json.log | cut -c1-300 | tee -a $LOG
+timeout 900 bash scripts/profile_round.sh pmc > gpurun_out/profile_round.log 2>&1; tail -3 gpurun_out/profile_round.log | cut -c1-200
 timeout 200 python scripts/generic_probe.py 4 2048 > gpurun_out/generic_probe.log 2>&1; tail -1 gpurun_out/generic_probe.log | cut -c1-700 | tee -a $LOG
+# the engine builds side by side on THIS box (frozen default object, the routed `next` build, its twin with stamp sites for the
+# timeline) - needs lib/variants/libmistral_hip_slots.so (python scripts/build_variants.py engine_slots)
+[ -f mistral-inference_amd/lib/variants/libmistral_hip_slots.so ] && MISTRAL_HIP_LIB=$PWD/mistral-inference_amd/lib/variants/libmistral_hip_slots.so \
+  timeout 400 python scripts/engine_ab.py --steps 200 --reps 3 --only nx,ns,ns_trace0,copy --trace-names ns > gpurun_out/engine_ab.stdout 2>&1
+grep -A8 "^entry" gpurun_out/engine_ab.stdout | cut -c1-120 | tee -a $LOG

@@ -9,14 +9,14 @@ timeout 3000 python -m pytest tests -m gpu -q -x -s > gpurun_out/pytest_gpu.log 
 grep -E "layer parity|8 layers, 4096|Mixtral-8x7B dims x 4|Mixtral-8x22B dims x 3|Nemo-12B dims x 4|max\|HIP|bit-exact" gpurun_out/pytest_gpu.log | cut -c1-500 | tee -a $LOG
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | cut -c1-500 | tee -a $LOG
 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 | tee gpurun_out/bench_steps20.json.log | cut -c1-400 | tee -a $LOG
-python bench.py --steps 64 --warmup 8 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_steps64.json.log | cut -c1-300 | tee -a $LOG
+python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_steps64.json.log | cut -c1-300 | tee -a $LOG
 bash scripts/profile_round.sh pmc > gpurun_out/profile_round.log 2>&1; tail -5 gpurun_out/profile_round.log | cut -c1-200
-python bench.py --model nemo-12b --prefill 8192 --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_nemo12b.json.log | cut -c1-300 | tee -a $LOG
+python bench.py --model nemo-12b --prefill 8192 --steps 32 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_nemo12b.json.log | cut -c1-300 | tee -a $LOG
 python bench.py --model mixtral-8x7b --steps 32 --warmup 4 2>&1 | tail -1 | tee gpurun_out/bench_mixtral8x7b.json.log | cut -c1-300 | tee -a $LOG
-MI_ENGINE_VARIANT=2 python bench.py --model mixtral-8x7b --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_mixtral8x7b_shipped_engine_build.json.log | cut -c1-300 | tee -a $LOG
-python bench.py --model mixtral-8x22b --layers 7 --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_8x22b_stage7.json.log | cut -c1-300 | tee -a $LOG
-MI_DECODE_ENGINE=0 python bench.py --model mixtral-8x22b --layers 7 --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_8x22b_stage7_launch_path.json.log | cut -c1-300 | tee -a $LOG
-MI_DECODE_ENGINE=0 python bench.py --steps 32 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_launch_path.json.log | cut -c1-300 | tee -a $LOG
+MI_ENGINE_VARIANT=2 python bench.py --model mixtral-8x7b --steps 32 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_mixtral8x7b_shipped_engine_build.json.log | cut -c1-300 | tee -a $LOG
+python bench.py --model mixtral-8x22b --layers 7 --steps 32 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_8x22b_stage7.json.log | cut -c1-300 | tee -a $LOG
+MI_DECODE_ENGINE=0 python bench.py --model mixtral-8x22b --layers 7 --steps 32 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_8x22b_stage7_launch_path.json.log | cut -c1-300 | tee -a $LOG
+MI_DECODE_ENGINE=0 python bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_launch_path.json.log | cut -c1-300 | tee -a $LOG
 timeout 300 python scripts/engine_trace.py > gpurun_out/engine_trace.log 2>&1; tail -48 gpurun_out/engine_trace.log | tee -a $LOG
 timeout 300 python scripts/engine_trace.py --model mixtral-8x7b --layers 8 > gpurun_out/engine_trace_8x7b.log 2>&1
 timeout 300 python scripts/engine_trace.py --model mixtral-8x22b --layers 7 > gpurun_out/engine_trace_8x22b_stage7.log 2>&1

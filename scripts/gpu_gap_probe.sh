@@ -9,7 +9,7 @@ probe() {  # label, env..., -- bench args
   local label=$1; shift
   local envs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   rm -rf gpurun_out/gap_$label
-  (cd /tmp && env "${envs[@]}" timeout 600 rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/gap_$label -o t -- python $REPO/bench.py --steps 24 --warmup 4 --no-cpu-baseline "$@" > $REPO/gpurun_out/gap_$label.log 2>&1)
+  (cd /tmp && env "${envs[@]}" timeout 600 rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/gap_$label -o t -- python $REPO/bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extras "$@" > $REPO/gpurun_out/gap_$label.log 2>&1)
   python - "$label" <<'PY'
 import csv, glob, sys, json
 label = sys.argv[1]

@@ -4,7 +4,7 @@
 # Round 3: 1166-1179 W at sclk 2.39 GHz, mclk 2.0 GHz - the decode engine is NOT at the 1400 W limit (the prefill GEMMs are:
 # scripts/prefill_probe.py --power).  The 4000-step run itself: 2.6276 ms per step = 380.6 tokens/s = 70.2 % of 8 TB/s.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 100 python bench.py --steps 4000 --warmup 8 --no-cpu-baseline > /tmp/b.log 2>&1 &
+timeout 100 python bench.py --steps 4000 --warmup 8 --no-cpu-baseline --no-extras > /tmp/b.log 2>&1 &
 BP=$!
 for i in $(seq 1 40); do
   timeout 5 rocm-smi --showpower --showclocks --json 2>/dev/null | python -c "

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$PWD
 rm -rf gpurun_out/prof gpurun_out/pmc
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o decode -- python $REPO/bench.py --steps 16 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/prof_bench.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o decode -- python $REPO/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/prof_bench.log 2>&1)
 python - <<'PY'
 import csv, glob, os
 f = glob.glob("gpurun_out/prof/**/*kernel_trace.csv", recursive=True)
@@ -28,11 +28,11 @@ PY
 find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
 if [ "$1" == "pmc" ]; then
 # the FULL headline configuration (32 layers, 4096-token prefill, decode at context 4096+): counters in their own passes
-(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o fetch -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_fetch.log 2>&1)
-(cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o write -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_write.log 2>&1)
-(cd /tmp && timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o mfma -- python $REPO/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph > $REPO/gpurun_out/pmc_mfma.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o fetch -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $REPO/gpurun_out/pmc_fetch.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o write -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $REPO/gpurun_out/pmc_write.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --pmc MfmaUtil VALUBusy LdsUtil LdsBankConflict --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc -o mfma -- python $REPO/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $REPO/gpurun_out/pmc_mfma.log 2>&1)
 # the launch path (6 kernels per layer) for the per-kernel decode table
-(cd /tmp && MI_DECODE_ENGINE=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_launch -o decode -- python $REPO/bench.py --steps 16 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/prof_launch.log 2>&1)
+(cd /tmp && MI_DECODE_ENGINE=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_launch -o decode -- python $REPO/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/prof_launch.log 2>&1)
 find gpurun_out/prof_launch -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats_launch_path.csv
 find gpurun_out/prof_launch -name "*kernel_trace.csv" -size +20M -delete
 find gpurun_out/pmc -name "*.csv" -size +20M -delete

@@ -63,3 +63,45 @@ def test_plain_multi_gpu_invocation_re_executes_under_torchrun(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_stage_bytes_without_lm_head():
+    """A pipeline stage that does not own the LM head reads (vocab x dim + dim) bf16 less per token (bench.stage_roofline)."""
+    p = dict(bench.MISTRAL_7B)
+    full, stage = bench.decode_bytes_per_token(p, 4096), bench.decode_bytes_per_token(p, 4096, head=False)
+    assert full - stage == 2 * (p["vocab_size"] * p["dim"] + p["dim"])
+
+
+def test_sub_measurement_reports_an_error_instead_of_raising(monkeypatch):
+    """The nemo / mixtral sub-objects of the N = 1 line come from subprocesses of this script: a crash or a time-out there must
+    cost the sub-object, never the headline line."""
+    import subprocess
+
+    class R:
+        stdout, returncode = "not json\n", 1
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    out = bench.sub_measurement("nemo-12b", 8192, 4, 2)
+    assert set(out) == {"error"}
+
+    def boom(*a, **k):
+        raise subprocess.TimeoutExpired("bench.py", 1)
+    monkeypatch.setattr(subprocess, "run", boom)
+    assert "TimeoutExpired" in bench.sub_measurement("mixtral-8x7b", 4096, 4, 2)["error"]
+
+
+def test_reference_bytecode_recipe():
+    """oracle/build_ref.py: the unmodified reference byte-compiled into oracle/_ref/ (what lets bench.py's cpu_baseline time the
+    reference itself on the GPU box).  Where /root/reference exists: rebuild, then import the SOURCELESS package through the shim."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference/src/mistral_inference"):
+        import pytest
+        pytest.skip("no reference source on this machine (the GPU box uses the prebuilt oracle/_ref)")
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "build_ref.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    code = ("import sys, os; sys.path[:0] = [%r, %r]; import mistral_inference.transformer as t, mistral_inference.cache as c; "
+            "assert t.__file__.endswith('.pyc') and c.__file__.endswith('.pyc'), t.__file__; "
+            "assert not os.path.exists(t.__file__[:-1]); print('ok')"
+            % (os.path.join(root, "oracle", "shim"), os.path.join(root, "oracle", "_ref")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
