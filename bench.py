@@ -427,6 +427,64 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
     return model, cache, nxt, dt, prefill_s
 
 
+def batch_run(opt, params: dict, B: int, dev: str, T0: int, K: int, Wm: int) -> dict:
+    """`--batch B` (evidence run, not the headline): B sequences decoded together, as `mistral-demo` does with its three prompts
+    (reference main.py:124,220) - the generate() loop's fused session at batch B on the launch path (the persistent engine is a
+    batch-1 kernel).  Every weight row is streamed once per step and reduced against B activation rows; each sequence reads its
+    own K/V ring: bytes per step = weights + B x ring window.  One JSON object; `value` = B tokens per step / step time."""
+    from mistral_inference.args import TransformerArgs
+    from mistral_inference.cache import BufferCache
+    from mistral_inference.transformer import Transformer
+    from mistral_inference import _hip
+    args = TransformerArgs.from_dict(params)
+    args.max_batch_size = B
+    with torch.device("meta"):
+        model = Transformer(args)
+    model = model.to(torch.bfloat16).to_empty(device=dev)
+    init_weights_(model, seed=42)
+    model._backend.invalidate()
+    model.eval()
+    a = model.args
+    cache = BufferCache(model.n_local_layers, B, T0 + K + max(Wm, 2) + 64, a.n_kv_heads, a.head_dim, a.sliding_window, device=dev,
+                        dtype=torch.bfloat16)
+    cache.reset()
+    g = torch.Generator().manual_seed(0)
+    prompts = torch.randint(0, a.vocab_size, (B * T0,), generator=g).to(dev)
+    with torch.inference_mode():
+        logits = model.forward(prompts, [T0] * B, cache)  # one batch of B x T0 prompt tokens
+        ends = torch.arange(1, B + 1, device=dev) * T0 - 1
+        nxt = torch.argmax(logits.index_select(0, ends), dim=-1)
+        del logits
+        sess = model.greedy_session(cache, nxt, graph=not opt.no_graph)
+        W = max(Wm, 2)
+        sess.run(W)
+        sess.collect()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sess.run(K)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sess.collect()
+    st = _hip.decode_engine_status(model._backend._workspace)
+    ctx_len = T0 + W + K // 2
+    w_bytes = decode_bytes_per_token(params, ctx_len)
+    Wn = params.get("sliding_window") or ctx_len
+    kv_one = params["n_layers"] * 2 * min(ctx_len, Wn) * params["n_kv_heads"] * params["head_dim"] * 2
+    step_bytes = w_bytes + (B - 1) * kv_one
+    gbs = step_bytes / (dt / K) / 1e9
+    return {"metric": f"decode tokens/sec/GPU (batch={B}, seq=1)", "value": round(B * K / dt, 2), "unit": "tokens/s", "n_gpus": 1,
+            "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{PRESETS[opt.model][1]} dims, {params['n_layers']} layers, random-init bf16, {B} x {T0}-token prefill then "
+                                   f"batch-{B} greedy decode, sliding_window={params.get('sliding_window')}",
+                       "batch": B, "prefill_tokens": T0, "context_at_timing": ctx_len,
+                       "decode_launch": ("persistent decode engine" if st["engine_launches"] > 0 else "6 launches per layer (launch path)")
+                       + ", greedy sample fused into the step, " + ("eager" if opt.no_graph else "hipGraph replay")},
+            "hbm_roofline_step": {"bytes_per_step": step_bytes, "weights_once_plus_kv_per_sequence": [w_bytes - kv_one, kv_one],
+                                  "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)},
+            "per_sequence_tokens_per_s": round(K / dt, 2)}
+
+
 def interleaved_run(opt, model, rank: int, world: int, dev: str, T0: int, K: int, Wm: int, sync):
     """N > 1: the pipeline's THROUGHPUT - `world` independent sequences, one per stage at any time
     (mistral_inference/pipeline_decode.py): every stage runs one batch-1 decode call per tick on a different sequence, the
@@ -486,6 +544,7 @@ def main() -> None:
     ap.add_argument("--loop", default="greedy", choices=["greedy", "forward"],
                     help="greedy: generate()'s temperature-0 loop (sample fused into the step); forward: forward() + torch.argmax per token")
     ap.add_argument("--no-mixtral", action="store_true", help="N > 1: skip the Mixtral sub-measurement")
+    ap.add_argument("--batch", type=int, default=1, help="evidence run: B sequences decoded together (mistral-demo runs 3); 1 = the headline")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1: skip the `nemo` / `mixtral` / `parity` sub-objects (the headline fields are the same either way)")
     ap.add_argument("--mixtral-layers", type=int, default=None, help="debug only: layers of the N > 1 Mixtral sub-measurement")
@@ -519,6 +578,11 @@ def main() -> None:
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if opt.batch > 1:
+        assert world == 1, "--batch is a single-GPU evidence run"
+        print(json.dumps(batch_run(opt, params, opt.batch, dev, T0, K, Wm)), flush=True)
+        return
 
     model, cache, nxt, dt, prefill_s = timed_run(opt, params, rank, world, dev, T0, K, Wm, sync)
     # N > 1: a single sequence is a relay through the stages (dt above: N GPUs decode no faster than one); the pipeline's

@@ -27,11 +27,13 @@ int mi_debug_set_engine_trace(void* dev_buffer);
 int mi_debug_set_engine_knobs(int thin, int depth);
 /* holder waves on (1) / off (0) / environment default (-1); results never depend on it (bit-identical either way) */
 int mi_debug_set_engine_holders(int on);
-/* The engine source is compiled twice: the shipped build (the headline shapes) and a "wide" build for the shapes that one
- * declines (GQA ratio 6 with a 32 KiB hid vector; rows of an even number of pieces that is not a multiple of 4) and for MoE
- * models (the batched router).  0 (default; environment MI_ENGINE_VARIANT): dense models the shipped build first, MoE models
- * the wide build first; 1: the wide build wherever it applies (tests compare its code paths with the launch path at small
- * sizes; also admits shapes that measured slower than the launch path); 2: the shipped build first for every model.
+/* The engine source is compiled four times: the default build (frozen since round 3: dense models), the `next` build (round 5:
+ * the dense GQA-4 shapes whose rows are multiples of 4 pieces, i.e. the headline model), a "wide" build for the shapes those
+ * decline (GQA ratio 6 with a 32 KiB hid vector; rows of an even number of pieces that is not a multiple of 4) and a MoE build
+ * (Mixtral-8x7B shapes).  0 (default; environment MI_ENGINE_VARIANT): dense models the `next` build where it applies, else the
+ * default build; MoE models the MoE build, else the wide build; 1: the wide build wherever it applies (tests compare its code
+ * paths with the launch path at small sizes; also admits shapes that measured slower than the launch path); 2: the default
+ * (frozen) build first for every model - the A/B partner of `next`, and the build that carries the timeline stamp sites.
  * Returns the previous setting. */
 int mi_debug_set_engine_variant(int variant);
 /* Test hook: the next `launches` engine launches on this workspace (hipGraph replays included: the count lives in the

@@ -21,8 +21,12 @@ namespace {
 
 using namespace attn_core;
 
-template <int R>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
+// SMALL (round 5, batches of >= 3 sequences - mistral-demo decodes three): the kernel sits at 170 VGPRs = 2 blocks per CU, so
+// 3 x 256 blocks ran as 1.5 rounds of the grid (20.7 us per layer against 9.0 at batch 1).  With half-size load sets (UK = 2:
+// 8 instead of 16 KiB in flight per wave) it fits 3 blocks per CU without spilling and the batch is ONE round.  A lane group
+// still visits its slots in ascending order: bit-identical results.
+template <int R, bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 3 : 1) void attn_decode_kernel(AttnDecodeArgs a) {
   __shared__ float sm_m[4 * R];
   __shared__ float sm_l[4 * R];
   __shared__ float sm_acc[4 * R * DH];
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
   // Each lane group walks slots s_begin + wid*4 + g + 16*j, UK slots (K and V rows = 2*UK loads) per step, two
   // steps in flight (ping-pong register sets A/B refilled in place, 16 KiB per wave outstanding): the kernel is pure
   // HBM latency/bandwidth, so depth is what matters.
-  constexpr int UK = (R <= 4) ? 4 : 2;  // R >= 6 needs the registers for its accumulators: half-size sets, no AGPR spills
+  constexpr int UK = (R <= 4 && !SMALL) ? 4 : 2;  // R >= 6 needs the registers for its accumulators: half-size sets, no AGPR spills
   const int s_first = s_begin + wid * 4 + g;
   const int s_clamp = max(kv_len - 1, 0);
   const int n_steps = (s_end > s_begin) ? (s_end - s_begin + 16 * UK - 1) / (16 * UK) : 0;  // block-uniform
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
 template <int R>
 void launch_r(const AttnDecodeArgs& a, hipStream_t s) {
   dim3 grid(a.n_splits * a.Hkv, a.B), block(256);
-  hipLaunchKernelGGL((attn_decode_kernel<R>), grid, block, 0, s, a);
+  if (R <= 4 && a.B >= 3) hipLaunchKernelGGL((attn_decode_kernel<R, (R <= 4)>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<R, false>), grid, block, 0, s, a);
   if (a.n_splits <= 16) hipLaunchKernelGGL((attn_decode_combine_kernel<16>), dim3(a.H, a.B), dim3(128), 0, s, a);
   else hipLaunchKernelGGL((attn_decode_combine_kernel<32>), dim3(a.H, a.B), dim3(128), 0, s, a);  // n_splits <= 32
 }

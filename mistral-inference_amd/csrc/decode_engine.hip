@@ -161,6 +161,11 @@ constexpr int NCONS = 4;
 #ifndef ENG_SADDR
 #define ENG_SADDR 0
 #endif
+// ENG_NOSTOP (bit mask: 1 h, 2 q, 4 split merge, 8 attn, 16 h1, 32 hid): sweeps during which this workgroup's loader is NOT stopped
+#ifndef ENG_NOSTOP
+#define ENG_NOSTOP 0
+#endif
+#define GATHER_FLAG(bit) ((ENG_NOSTOP & (bit)) ? 0u : 1u)
 #ifndef ENG_HOLD_STAGE
 #define ENG_HOLD_STAGE 3  // the holders' fetch of a layer's units may begin when the loader has issued: 0 nothing yet, 1 q|k|v, 2 + K/V, 3 + Wo
 #endif
@@ -483,7 +488,9 @@ struct Loader {
     const unsigned long long b = reinterpret_cast<unsigned long long>(sbase);
     const unsigned long long bu = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+    // (s_nop 4: hipcc does not pad hazards for the operands of an asm statement - should the base pair ever come straight
+    // from a v_readfirstlane, a VMEM read of a VALU-written SGPR needs 5 wait states; the M0 write needs 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
                  "global_load_lds_dwordx4 %1, %2 nt\n\t"
                  "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
                  "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
@@ -1333,7 +1340,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       for (int i = 0; i < 4; ++i) xr[i] = ld16(hin + (size_t)min(vt + i * 256, (a.D >> 3) - 1) * 8);
       for (int r = 2 * p.o0 + vt; r < 2 * p.o1; r += NCONS * 64) sh.res[r - 2 * p.o0] = hin[r];
     } else {
-      sh.ctl[C_GATHERING] = 1;
+      sh.ctl[C_GATHERING] = GATHER_FLAG(1);
       cs.norm_load_granules(xr, G + a.g_h, a.D, tag_of(l - 1, 0));
       sh.ctl[C_GATHERING] = 0;
     }
@@ -1427,7 +1434,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     if (p.att) {
       const int kv_real = p.kvh / a.kv_groups;
       const uint32_t tq = tag_of(l, 1);
-      sh.ctl[C_GATHERING] = 1;
+      sh.ctl[C_GATHERING] = GATHER_FLAG(2);
       {  // q of the R query heads | this step's k row | v row of the kv head: ONE sweep (q_lds, kn_lds, vn_lds are contiguous)
         const gu64* qg = G + a.g_qkv + (size_t)p.kvh * R * 64;
         const gu64* kg = G + a.g_qkv + nq / 2 + (size_t)kv_real * 64;
@@ -1552,7 +1559,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         // word t = (which * ns + sp) * ne + el: which = 0 acc, 1 m, 2 l of split sp for element 2 * e0 + el
         const gu64* part = G + a.g_part;
         const size_t ml_base = (size_t)a.Hs * ns * R * DH;
-        sh.ctl[C_GATHERING] = 1;
+        sh.ctl[C_GATHERING] = GATHER_FLAG(4);
         cs.gather_fn<8>(3 * ns * ne, tp, cmb_lds, [&](int t) {
           const int el = t % ne, sp = (t / ne) % ns, which = t / (ne * ns);
           const int e = 2 * p.e0 + el, hh = e / DH, d = e % DH, kvh = hh / R, r = hh % R;
@@ -1587,7 +1594,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     // the attention scratch is dead once wave 0 has merged ... unless the merge staging lies beyond the words the attn
     // vector overwrites (GQA ratio >= 2 at these head counts): then waves 1-3 start the next sweep while wave 0 merges
     if (!(ENG_LEAN_BARRIERS && R * 64 + 128 + 8 * R + 4 * R * DH >= nq / 2)) cs.cbar();
-    sh.ctl[C_GATHERING] = 1;
+    sh.ctl[C_GATHERING] = GATHER_FLAG(8);
     cs.gather(G + a.g_att, nq / 2, tag_of(l, 3), xs32);
     cs.cbar();
     sh.ctl[C_GATHERING] = 0;
@@ -1615,7 +1622,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
     // ================================================================ hid = silu(W1 x) * (W3 x), x = ffn_norm(h1)
     cs.norm_prefetch(nw, a.D, L.fn);
     cs.cbar();
-    sh.ctl[C_GATHERING] = 1;
+    sh.ctl[C_GATHERING] = GATHER_FLAG(16);
     cs.norm_load_granules(xr, G + a.g_h1, a.D, tag_of(l, 4));
     sh.ctl[C_GATHERING] = 0;
 #if ENG_QKV_HOLD == 2
@@ -1653,7 +1660,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         while (sh.ctl[C_HDONE] < hold_target)
           if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
       }
-      sh.ctl[C_GATHERING] = 1;
+      sh.ctl[C_GATHERING] = GATHER_FLAG(32);
       cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
       cs.cbar();
       sh.ctl[C_GATHERING] = 0;

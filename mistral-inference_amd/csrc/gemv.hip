@@ -179,17 +179,32 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   }
 }
 
+template <int TT, int MODE, int ROWS>
+hipError_t launch_tt(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (lds > 64 * 1024) {  // more than the default dynamic-LDS limit: an opt-in per function AND per device
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<TT, MODE, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)GEMV_LDS_BUDGET + 1024);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((gemv_kernel<TT, MODE, ROWS>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
 template <int MODE, int ROWS>
 hipError_t launch_mode(const GemvArgs& a, int TT, dim3 grid, size_t lds, hipStream_t s) {
   switch (TT) {
-    case 1: hipLaunchKernelGGL((gemv_kernel<1, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((gemv_kernel<2, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((gemv_kernel<3, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((gemv_kernel<4, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
-    case 6: hipLaunchKernelGGL((gemv_kernel<6, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
-    default: hipLaunchKernelGGL((gemv_kernel<8, MODE, ROWS>), grid, dim3(256), lds, s, a); break;
+    case 1: return launch_tt<1, MODE, ROWS>(a, grid, lds, s);
+    case 2: return launch_tt<2, MODE, ROWS>(a, grid, lds, s);
+    case 3: return launch_tt<3, MODE, ROWS>(a, grid, lds, s);
+    case 4: return launch_tt<4, MODE, ROWS>(a, grid, lds, s);
+    case 6: return launch_tt<6, MODE, ROWS>(a, grid, lds, s);
+    default: return launch_tt<8, MODE, ROWS>(a, grid, lds, s);
   }
-  return hipGetLastError();
 }
 
 int g_gemv_max_blocks = 0;
@@ -198,6 +213,7 @@ int g_gemv_max_blocks = 0;
 
 int gemv_max_tokens(int K) {
   int t = (int)(GEMV_LDS_BUDGET / ((size_t)K * 2));
+  if (t == 5 || t == 7) --t;  // (5 and 7 rows run on the 6- and 8-row instantiations, which stage 6 / 8 rows in LDS)
   return t < 1 ? 1 : (t > GEMV_MAX_T ? GEMV_MAX_T : t);
 }
 
@@ -249,6 +265,10 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   if (TT == 5) TT = 6;
   if (TT == 7) TT = 8;
   const size_t lds = (size_t)TT * a.K * 2 + 4 * TT * sizeof(float);
+  if (lds > 80 * 1024 && blocks > cus) {  // one such block fits a CU: one block per CU, every wave the same number of units
+    const int k = (units + 4 * cus - 1) / (4 * cus);
+    blocks = (units + 4 * k - 1) / (4 * k);
+  }
   dim3 grid(blocks, a.mode == GEMV_MOE_W13 ? a.T * a.top_k : 1);
   switch (a.mode) {
     case GEMV_STORE:

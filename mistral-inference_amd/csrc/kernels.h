@@ -20,7 +20,10 @@ enum GemvMode {
 };
 
 constexpr int GEMV_MAX_T = 8;
-constexpr size_t GEMV_LDS_BUDGET = 64 * 1024 - 256;
+// LDS a GEMV block may use for its T activation rows.  Round 5: up to 144 KiB (opt-in above 64 KiB per function) instead of 64:
+// with hidden_dim 14336 a row is 28 KiB, and a batch of three sequences (mistral-demo) ran the W2 GEMV as TWO passes - the
+// weights streamed twice per decode step (+24 us per layer).  Above 80 KiB one block fits a CU: the grid is one block per CU.
+constexpr size_t GEMV_LDS_BUDGET = 144 * 1024;
 
 struct GemvArgs {
   int mode;

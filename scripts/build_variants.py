@@ -104,14 +104,14 @@ _NS = _AP + ("-DENG_HOLD_STAGE=2", "-DENG_SADDR=2")
 ENGINE_SLOTS = {
     "copy": (),
     "nx": _AP + ("-DENG_HOLD_STAGE=2",),
-    "ns": _NS,                                                      # weight DMAs from inline asm in the SGPR-base form (K/V pieces: the builtin)
-    "ns_trace0": _NS + ("-DENG_TRACE=0",),
-    "ns_cache": _NS + ("-DENG_DONE_CACHE=1",),
-    "ns_b128": _NS + ("-DENG_DONE_B128=1",),
-    "ns_hold4": _NS + ("-DENG_SLP_HOLD=4",),
-    "ns_ring4": _NS + ("-DENG_SLP_RING=4",),
-    "ns_cbar2": _NS + ("-DENG_SLP_CBAR=2",),
-    "ns_prio2": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=2", "-DENG_HOLD_STAGE=2", "-DENG_SADDR=2"),
+    "ns": _NS,
+    "ns_trace0": _NS + ("-DENG_TRACE=0",),                          # = round-5 call 9's decode_engine_next.o
+    "nst_hid": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=32"),          # loader not stopped during the hid sweep (ring empty there)
+    "nst_hid_attn": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=40"),
+    "nst_hid_h": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=33"),
+    "ns_hid": _NS + ("-DENG_NOSTOP=32",),
+    "nst_hid_stage3": _AP + ("-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
+    "nst_hid_hold4": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=32", "-DENG_SLP_HOLD=4"),
 }
 
 
