@@ -49,9 +49,11 @@
 // consumer waves' W1|W3 units span exactly 8 fills, and the 7-fill ring of ENG_WIDE = 1 costs Mixtral-8x7B 6 % of its W1|W3
 // streaming rate (25.6 vs 27.2 GB/s per CU, profiles/r04_engine_trace_8x7b_*) - as much as the batched router saves.
 // ENG_SUFFIX (round 5): further compiles of this source under their own entry-point names - `_next` (decode_engine_next.o: the
-// dense GQA-4 headline shape with the round-5 switches below: ENG_ABORT_RARE, ENG_DONE_*, ENG_SLP_*) and the `_x<N>` slots
-// of an experiment library (scripts/build_variants.py engine_slots, scripts/engine_ab.py).  ENG_HEADLINE_ONLY = 1 instantiates
-// only decode_engine_kernel<4, dense, all rows multiples of 4 pieces>.
+// dense GQA-4 headline shape with the round-5 switches below: ENG_ABORT_RARE, ENG_CONS_PRIO, ENG_HOLD_STAGE, ENG_SADDR = 2 and
+// ENG_TRACE = 0 - build_native.py: ENGINE_NEXT_FLAGS) and the `_x<N>` slots of an experiment library (scripts/build_variants.py
+// engine_slots, scripts/engine_ab.py).  ENG_HEADLINE_ONLY = 1 instantiates only decode_engine_kernel<4, dense, all rows
+// multiples of 4 pieces>.  Why the default object is kept frozen and what made builds of this file differ by up to 30 % in speed
+// (hipcc's `s_waitcnt vmcnt(0)` in the loader's issue loop, ENG_SADDR below): DESIGN.md section 3, profiles/EXPERIMENTS.md round 5.
 #ifndef ENG_HEADLINE_ONLY
 #define ENG_HEADLINE_ONLY 0
 #endif
@@ -92,11 +94,12 @@ constexpr int NCONS = 4;
 #ifndef ENG_LEAN_BARRIERS
 #define ENG_LEAN_BARRIERS 0  // 1: waves 1-3 start the attn sweep while wave 0 still merges the splits (+45 us per step)
 #endif
-// ENG_TRACE = 1 (shipped): the phase-timeline stamp sites (mi_debug_set_engine_trace, scripts/engine_trace.py) stay in the
-// production kernel although they cost a test of a null pointer each.  MEASURED: compiling them out makes the step 17 % SLOWER
-// (3.17-3.19 vs 2.70-2.71 ms, same box, profiles/EXPERIMENTS.md) - the 26 sites per layer pin the compiler's placement of loads
-// and waits at the phase boundaries; without them hipcc moves memory operations across phases.  ENG_TRACE = 2 replaces the
-// stamps by bare compiler barriers (experiment).
+// ENG_TRACE = 1 (default, wide and MoE builds): the phase-timeline stamp sites (mi_debug_set_engine_trace, scripts/engine_trace.py)
+// stay in the kernel although they cost a test of a null pointer each.  MEASURED: compiling them out makes THOSE builds 14-19 %
+// SLOWER (profiles/EXPERIMENTS.md rounds 3-5): without the sites hipcc places `s_waitcnt vmcnt(0)` at the top of the loader's
+// per-unit loops (in front of the rewrite of a DMA's 64-bit VGPR address pair) - a drain of the DMA queue per unit.  With the
+// DMAs out of hipcc's sight (ENG_SADDR = 2) the build without the sites is as fast as the one with them: the `next` build ships
+// ENG_TRACE = 0.  ENG_TRACE = 2 replaces the stamps by bare compiler barriers (experiment).
 #ifndef ENG_TRACE
 #define ENG_TRACE 1
 #endif
