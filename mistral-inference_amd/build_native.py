@@ -34,8 +34,9 @@ ENGINE_NEXT_FLAGS = ["-DENG_SUFFIX=_next", "-DENG_HEADLINE_ONLY=1", "-DENG_ABORT
                      "-DENG_SADDR=2", "-DENG_TRACE=0"]
 VARIANT_OBJECTS = {"decode_engine_next.o": ("decode_engine.hip", ENGINE_NEXT_FLAGS),
                    # (the wide build also takes the two round-5 switches: +0.7 % on the 8x22B stage; the 8-fill MoE build does NOT -
-                   #  the same two switches make Mixtral-8x7B 4.5 % slower, profiles/EXPERIMENTS.md round 5)
-                   "decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1"]),   # 7-fill ring, GQA 4 / 6, contiguous units
+                   #  the same two switches make Mixtral-8x7B 4.5 % slower, profiles/EXPERIMENTS.md round 5; and the q|k|v holder
+                   #  waves, one unit each at rows of 12 pieces: +1.2 % on the 8x22B stage)
+                   "decode_engine_wide.o": ("decode_engine.hip", ["-DENG_WIDE=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1", "-DENG_QKV_HOLD=2"]),   # 7-fill ring, GQA 4 / 6, contiguous units
                    # 8-fill ring, MoE GQA 4 (Mixtral-8x7B); round 5: its idle holder waves keep six q|k|v units of the NEXT layer,
                    # fetched during the router bubble (ENG_QKV_HOLD = 2: +1.9 % on one box, +-0 on another)
                    "decode_engine_moe.o": ("decode_engine.hip", ["-DENG_WIDE=2", "-DENG_QKV_HOLD=2"]),

@@ -346,6 +346,10 @@ __device__ __forceinline__ int holder_units(const EngArgs& a, int n_f) {
 // q|k|v units (row pairs) of a workgroup that the holder waves keep in registers: the last 2 * NHOLD of the list q.., k.., v..
 __device__ __forceinline__ int qkv_held(const EngArgs& a, int n_u) {
   const int P = a.D >> 9;
+#if ENG_WIDE == 1
+  // rows of 9-12 pieces (Mixtral-8x22B: dim 6144): a holder keeps ONE unit (2 rows x 12 pieces = 96 VGPRs): run_qkv_holder1
+  if (NHOLD > 0 && a.holders && a.E > 0 && unit_group(P) == 4 && (P >> 2) == HOLD_GROUPS + 1 && n_u >= NCONS + NHOLD) return NHOLD;
+#endif
   return (NHOLD > 0 && a.holders && a.E > 0 && unit_group(P) == 4 && (P >> 2) <= HOLD_GROUPS && n_u >= NCONS + 2 * NHOLD) ? 2 * NHOLD : 0;
 }
 #endif
@@ -1935,6 +1939,103 @@ __device__ __forceinline__ void run_qkv_holder(const EngArgs& a, const Shared& s
     }
   }
 }
+#if ENG_WIDE == 1
+// The same for rows of 9-12 pieces (wide build, Mixtral-8x22B): ONE unit per holder - list index n_u - 3 + hi - in three 4-piece groups.
+__device__ __forceinline__ void run_qkv_holder1(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, int seq, uint32_t epoch) {
+  gu64* G = (gu64*)a.gran;
+  const int PD = a.D >> 9;
+  const lchar* xl = sh.xs + lane * 16;
+  const int nq = a.H * DH, nkv = a.Hkv * DH;
+  {
+    LayerPlan p0;
+    plan_layer(a, a.L[0], c, pos, p0);
+    if (!qkv_held(a, (p0.q1 - p0.q0) + 2 * (p0.k1 - p0.k0))) return;  // (the same answer for every layer: shapes do not change)
+  }
+  u32x4 hw[HOLD_GROUPS + 1][2][4];  // [group][row][piece in group]: constant indices only
+  // iteration l: reduce and publish the units of layer l (held since iteration l - 1), then fetch those of layer l + 1
+  for (int l = -1; l < a.n_layers; ++l) {
+    uint32_t spins = 0;
+    if (l >= 0) {
+      const EngLayer& L = a.L[l];
+      LayerPlan p;
+      plan_layer(a, L, c, pos, p);
+      const int n_u = (p.q1 - p.q0) + 2 * (p.k1 - p.k0);
+      int kind0, u0;
+      qkv_unit(p, n_u - NHOLD + hi, kind0, u0);
+      const float2 cs0 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + (((2 * u0) % DH) >> 1)) * 2);
+      while (sh.ctl[C_XA] < (uint32_t)(l + 1))
+        if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+      float acc[2] = {0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < HOLD_GROUPS + 1; ++grp)
+        if (grp * 4 < PD) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 xv = lds16(xl + (grp * 4 + q) * PIECE);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[r] = dot2_bf16(hw[grp][r][q][i], xv[i], acc[r]);
+          }
+        }
+      float v[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) v[r] = wave_sum(acc[r]);
+      if (lane == 0) {
+        const uint32_t tag = (epoch << 12) | (uint32_t)((a.seq_base + l) * 8 + 1 + 1);
+        auto finish = [&](int kind, int u, float2 cs2, float d0, float d1) {
+          float y0 = bf_round(d0), y1 = bf_round(d1);
+          if (kind < 2) {  // rope.py:13-23 on the adjacent pair
+            float re, im;
+            rope_pair(y0, y1, cs2.x, cs2.y, re, im);
+            y0 = re;
+            y1 = im;
+          }
+          const uint32_t packed = pack_bf2(y0, y1);
+          if (kind > 0) {  // cache.py:83-92
+            const size_t slot = (size_t)seq * L.W + p.cur_slot;
+            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + 2 * u;
+            *reinterpret_cast<uint32_t*>(ring) = packed;
+          }
+          const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
+          __hip_atomic_store(G + a.g_qkv + gi, ((unsigned long long)tag << 32) | packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        finish(kind0, u0, cs0, v[0], v[1]);
+        __hip_atomic_fetch_add((lu32*)(sh.ctl + C_HQDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    if (l + 1 < a.n_layers) {
+      if (l >= 0) {
+        spins = 0;
+        // ENG_QKV_HOLD = 1: the loader has issued layer l's Wo rows (it flushes and waits for the router next); 2: this workgroup
+        // has gathered h1 - the attention block's sweeps are over, the router's arithmetic begins
+        while (sh.ctl[ENG_QKV_HOLD == 2 ? C_HGO : C_LSTAGE] < (uint32_t)(l + 1))
+          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+      }
+      const EngLayer& L = a.L[l + 1];
+      LayerPlan p;
+      plan_layer(a, L, c, pos, p);
+      const int n_u = (p.q1 - p.q0) + 2 * (p.k1 - p.k0);
+      int kind0, u0;
+      qkv_unit(p, n_u - NHOLD + hi, kind0, u0);
+      const bf16_t* b0 = (kind0 == 0 ? L.wq : (kind0 == 1 ? L.wk : L.wv)) + (size_t)(2 * u0) * a.D + lane * 8;
+      const bf16_t* rows[2] = {b0, b0 + a.D};
+#pragma unroll
+      for (int grp = 0; grp < HOLD_GROUPS + 1; ++grp) {
+        {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
+          spins = 0;
+          while (sh.ctl[C_GATHERING])
+            if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hw[grp][r][q] = ld16_nt(rows[r] + (size_t)min(grp * 4 + q, PD - 1) * 512);
+        }
+      }
+    }
+  }
+}
+#endif
 #endif
 
 __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, int c, int hi, int lane, int pos, uint32_t epoch) {
@@ -2036,6 +2137,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void decode_engine_kernel(const EngArg
   const uint32_t epoch = (__hip_atomic_load(sh.ctrl + G_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
   if (w == NCONS) run_loader<MOE>(a, sh, c, lane, pos, seq);
 #if ENG_QKV_HOLD
+#if ENG_WIDE == 1
+  else if (w > NCONS && MOE && ((a.D >> 9) >> 2) == HOLD_GROUPS + 1) run_qkv_holder1(a, sh, c, w - NCONS - 1, lane, pos, seq, epoch);
+#endif
   else if (w > NCONS && MOE) run_qkv_holder(a, sh, c, w - NCONS - 1, lane, pos, seq, epoch);
 #endif
   else if (w > NCONS) run_holder(a, sh, c, w - NCONS - 1, lane, pos, epoch);

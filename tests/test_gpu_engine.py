@@ -226,6 +226,10 @@ WIDE_SHAPES = {
     # Mixtral-8x22B in small: GQA ratio 6 (48 / 8 heads), every row a multiple of 4 pieces, top-2 MoE
     "gqa6_moe_rows_of_4": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=48, n_kv_heads=8, norm_eps=1e-5,
                                vocab_size=1000, sliding_window=48, num_experts=4, num_experts_per_tok=2),
+    # Mixtral-8x22B's rows: dim 6144 = 12 pieces, GQA ratio 6, MoE: the holder waves keep ONE q|k|v unit each of the next layer
+    # (run_qkv_holder1: three 4-piece groups per row)
+    "gqa6_moe_rows_of_12": dict(dim=6144, n_layers=2, head_dim=128, hidden_dim=2048, n_heads=48, n_kv_heads=8, norm_eps=1e-5,
+                                vocab_size=1000, sliding_window=48, num_experts=4, num_experts_per_tok=2),
     # Mistral-Nemo's rows: dim 5120 = 10 pieces (contiguous units of 20 and 40 pieces), n_heads * 128 != dim
     "rows_of_10_pieces": dict(dim=5120, n_layers=2, head_dim=128, hidden_dim=1024, n_heads=8, n_kv_heads=2, norm_eps=1e-5,
                               vocab_size=1002, sliding_window=48),
