@@ -169,6 +169,7 @@ def _interleaved_worker(rank, world, port, q, n_dec):
             first.append(int(torch.argmax(logits[-1])))
         dec = InterleavedDecoder(m, caches, torch.tensor(first))
         toks, lps = dec.run(n_dec)
+        assert dec.tick_host_us > 0.0  # host time per tick of the loop (bench.py: pipeline_throughput.tick_host_us)
         toks2, _ = dec.run(2)  # a second call continues every sequence
         q.put((rank, first, toks.tolist(), lps.tolist(), toks2.tolist(), traffic))
     finally:
