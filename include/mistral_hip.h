@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)        /* null pointer / non-positive size                        */
@@ -65,9 +65,20 @@ int mi_rope_inplace(void* qkv, int ld, int T, int n_heads, int n_kv_heads, int h
 /* cache.py:83-92 CacheView.update with to_cache_mask / cache_positions of cache.py:226-235:
  * token t (sequence b = tok_seq[t], index i = t - q_start[b] of s_b = q_start[b+1]-q_start[b] new
  * tokens) is stored iff i >= s_b - W, into ring slot tok_pos[t] % W of row b.
- * k/v: [T, ld] activation views (already at the k / v column), cache_k/v: [max_batch, W, n_kv*Dh]. */
+ * k/v: [T, ld] activation views (already at the k / v column), cache_k/v: one layer's rings in `kv_layout` (below). */
 int mi_kv_write(void* cache_k, void* cache_v, int W, const void* k, const void* v, int ld, int T, int kv_dim,
-                const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, mi_stream_t stream);
+                const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, int kv_layout, int head_dim,
+                mi_stream_t stream);
+
+/* ABI v7 - layout of a layer's K/V rings in HBM.  A kv head's head_dim elements are contiguous in both:
+ *   MI_KV_SLOT_MAJOR  [max_batch, W, n_kv_heads, head_dim]: the reference's torch.empty shape (cache.py:163-167)
+ *   MI_KV_HEAD_MAJOR  [max_batch, n_kv_heads, W, head_dim]: the slots of ONE kv head are contiguous, so the keys a decode work
+ *                     item (kv head, range of slots) reads are a single run - 4-KiB runs that the persistent engine streams at
+ *                     its weight rate; the strided form costs it 1.2 us per 16 KiB against 0.66.  What
+ *                     mistral_inference.cache.BufferCache allocates (exposed to Python as a permuted view of the reference's shape).
+ * Every entry point that touches a ring takes the layout; all rings of one mi_forward call share it (mi_batch_t.kv_layout). */
+#define MI_KV_SLOT_MAJOR 0
+#define MI_KV_HEAD_MAJOR 1
 
 /* Epilogues of the dense contractions */
 enum mi_epilogue {
@@ -120,7 +131,7 @@ int mi_sample_top_p(const float* logits, int ld, int B, int vocab, float tempera
  * must be zero at the first call (the kernel leaves them zero). */
 size_t mi_attn_decode_scratch_bytes(int B, int n_heads, int n_kv_heads, int head_dim, int W);
 int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const void* cache_v, int W, int B,
-                   int n_heads, int n_kv_heads, int head_dim, const int32_t* tok_pos, void* scratch,
+                   int n_heads, int n_kv_heads, int head_dim, const int32_t* tok_pos, void* scratch, int kv_layout,
                    mi_stream_t stream);
 
 /* Prefill-branch attention (transformer_layers.py:74-76,84-89; keys of cache.py:94-117 interleave_kv;
@@ -135,7 +146,7 @@ int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const
  * out: [T, H*Dh]. */
 int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, const void* cache_v, int W, int B,
                     int max_q_len, int n_heads, int n_kv_heads, int head_dim, const int32_t* q_start,
-                    const int32_t* kv_before, int causal, float softmax_scale, mi_stream_t stream);
+                    const int32_t* kv_before, int causal, float softmax_scale, int kv_layout, mi_stream_t stream);
 
 /* nn.GELU() of the vision-language adapter (vision_encoder.py:112-116; exact erf form): x <- bf16(gelu(x)) in place
  * over [T, N] bf16 rows with row pitch ldx. */
@@ -156,7 +167,7 @@ int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T,
 int mi_qkv_rope_kvwrite(void* qkv, int ldo, const void* x, int ldx, int T, int D, const void* wq, const void* wk,
                         const void* wv, int n_heads, int n_kv_heads, int head_dim, const void* norm_w, float eps,
                         const float* rope_cs, int rope_len, const int32_t* tok_pos, const int32_t* tok_seq, void* cache_k,
-                        void* cache_v, int W, mi_stream_t stream);
+                        void* cache_v, int W, int kv_layout, mi_stream_t stream);
 
 /* moe.py:28-32 (+ the residual add of transformer_layers.py:168) for T <= 8 tokens, two launches, no host sync:
  * out[t] = bf16(residual[t] + R_t), R_t = sum over the token's picked experts in ascending expert id of
@@ -226,7 +237,8 @@ typedef struct mi_batch {
   int32_t* tok_pos;             /* [T]   */
   int64_t* kv_seqlens;          /* dev [B] BufferCache.kv_seqlens (cache.py:170,193-195); DECODE reads
                                    positions from it and adds 1 on the device; NULL for NOCACHE */
-  void* const* cache_k;         /* host array [n_layers] of dev [max_batch, W_l, Hkv, Dh] (cache.py:163-167) */
+  void* const* cache_k;         /* host array [n_layers] of dev rings: [max_batch, W_l, Hkv, Dh] (cache.py:163-167) or head-major
+                                   [max_batch, Hkv, W_l, Dh], as kv_layout (last field) says */
   void* const* cache_v;
   const int32_t* cache_sizes;   /* host [n_layers] W_l (cache.py:13-24) */
   void* h;                      /* dev [T, D] bf16, in/out: the residual stream.  rank 0: overwritten by
@@ -263,6 +275,8 @@ typedef struct mi_batch {
   float sample_top_p;
   uint64_t sample_seed;
   uint64_t sample_offset;
+  /* ABI v7 */
+  int32_t kv_layout;            /* MI_KV_SLOT_MAJOR (0, the reference's shape) or MI_KV_HEAD_MAJOR: layout of EVERY ring in cache_k / cache_v */
 } mi_batch_t;
 
 size_t mi_workspace_bytes(const mi_model_t* model, int T, int B, int max_cache_size);

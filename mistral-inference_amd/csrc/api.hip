@@ -33,6 +33,7 @@ namespace {
 
 thread_local char g_detail[512] = "";
 
+bool kv_layout_ok(int layout) { return layout == MI_KV_SLOT_MAJOR || layout == MI_KV_HEAD_MAJOR; }
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -222,11 +223,13 @@ int mi_rope_inplace(void* qkv, int ld, int T, int n_heads, int n_kv_heads, int h
 }
 
 int mi_kv_write(void* cache_k, void* cache_v, int W, const void* k, const void* v, int ld, int T, int kv_dim,
-                const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, mi_stream_t stream) {
+                const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, int kv_layout, int head_dim,
+                mi_stream_t stream) {
   if (!cache_k || !cache_v || !k || !v || !tok_seq || !tok_pos || !q_start || W <= 0 || T <= 0 || kv_dim % 8)
     return fail(MI_ERR_ARG, "mi_kv_write");
-  return hip_rc(launch_kv_write(cache_k, cache_v, W, k, v, ld, T, kv_dim, tok_seq, tok_pos, q_start, (hipStream_t)stream),
-                "kv_write");
+  if (!kv_layout_ok(kv_layout) || head_dim <= 0 || head_dim % 8 || kv_dim % head_dim) return fail(MI_ERR_ARG, "mi_kv_write: layout / head_dim");
+  return hip_rc(launch_kv_write(cache_k, cache_v, W, k, v, ld, T, kv_dim, tok_seq, tok_pos, q_start, kv_layout, head_dim,
+                                (hipStream_t)stream), "kv_write");
 }
 
 int mi_linear(void* out, int ldo, const void* x, int ldx, int M, int K, const void* const w[3], const int n_rows[3],
@@ -318,13 +321,15 @@ size_t mi_attn_decode_scratch_bytes(int B, int n_heads, int n_kv_heads, int head
 }
 
 int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const void* cache_v, int W, int B,
-                   int n_heads, int n_kv_heads, int head_dim, const int32_t* tok_pos, void* scratch,
+                   int n_heads, int n_kv_heads, int head_dim, const int32_t* tok_pos, void* scratch, int kv_layout,
                    mi_stream_t stream) {
-  if (!out || !q || !cache_k || !cache_v || !tok_pos || !scratch || W <= 0 || B <= 0) return fail(MI_ERR_ARG, "mi_attn_decode");
+  if (!out || !q || !cache_k || !cache_v || !tok_pos || !scratch || W <= 0 || B <= 0 || !kv_layout_ok(kv_layout))
+    return fail(MI_ERR_ARG, "mi_attn_decode");
   if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
   if ((size_t)B * n_kv_heads * 4 > TICKET_BYTES) return fail(MI_ERR_SHAPE, "B * n_kv_heads > 1024");
   AttnDecodeArgs a;
   a.out = out; a.q = (const bf16_t*)q; a.ldq = ldq; a.cache_k = (const bf16_t*)cache_k; a.cache_v = (const bf16_t*)cache_v;
+  a.kv_layout = kv_layout;
   a.W = W; a.B = B; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim; a.tok_pos = tok_pos;
   a.tickets = (int32_t*)scratch; a.partial = (float*)((char*)scratch + TICKET_BYTES);
   a.n_splits = attn_decode_splits(W);
@@ -333,8 +338,8 @@ int mi_attn_decode(void* out, const void* q, int ldq, const void* cache_k, const
 
 int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, const void* cache_v, int W, int B,
                     int max_q_len, int n_heads, int n_kv_heads, int head_dim, const int32_t* q_start,
-                    const int32_t* kv_before, int causal, float softmax_scale, mi_stream_t stream) {
-  if (!out || !qkv || B <= 0 || max_q_len <= 0 || W <= 0) return fail(MI_ERR_ARG, "mi_attn_prefill");
+                    const int32_t* kv_before, int causal, float softmax_scale, int kv_layout, mi_stream_t stream) {
+  if (!out || !qkv || B <= 0 || max_q_len <= 0 || W <= 0 || !kv_layout_ok(kv_layout)) return fail(MI_ERR_ARG, "mi_attn_prefill");
   if (causal && (!q_start || !kv_before)) return fail(MI_ERR_ARG, "mi_attn_prefill: metadata");
   if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
   // the kernel forms 32-bit element offsets inside one ring (W * kv_dim) and inside the activation matrix (rows * ld)
@@ -342,6 +347,7 @@ int mi_attn_prefill(void* out, const void* qkv, int ld, const void* cache_k, con
     return fail(MI_ERR_UNSUPPORTED, "mi_attn_prefill: ring or activation matrix larger than 2^31 elements");
   AttnPrefillArgs a;
   a.out = out; a.qkv = (const bf16_t*)qkv; a.ld = ld; a.cache_k = (const bf16_t*)cache_k; a.cache_v = (const bf16_t*)cache_v;
+  a.kv_layout = kv_layout;
   a.W = W; a.B = B; a.max_q_len = max_q_len; a.H = n_heads; a.Hkv = n_kv_heads; a.Dh = head_dim;
   a.q_start = q_start; a.kv_before = kv_before; a.causal = causal;
   a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)head_dim);
@@ -363,8 +369,8 @@ int mi_moe_router(int32_t* sel_idx, float* sel_w, const void* x, int ldx, int T,
 int mi_qkv_rope_kvwrite(void* qkv, int ldo, const void* x, int ldx, int T, int D, const void* wq, const void* wk,
                         const void* wv, int n_heads, int n_kv_heads, int head_dim, const void* norm_w, float eps,
                         const float* rope_cs, int rope_len, const int32_t* tok_pos, const int32_t* tok_seq, void* cache_k,
-                        void* cache_v, int W, mi_stream_t stream) {
-  if (!qkv || !x || !wq || !wk || !wv || !rope_cs || !tok_pos || T <= 0 || D <= 0 || D % 8 || rope_len <= 0)
+                        void* cache_v, int W, int kv_layout, mi_stream_t stream) {
+  if (!qkv || !x || !wq || !wk || !wv || !rope_cs || !tok_pos || T <= 0 || D <= 0 || D % 8 || rope_len <= 0 || !kv_layout_ok(kv_layout))
     return fail(MI_ERR_ARG, "mi_qkv_rope_kvwrite");
   if (head_dim != 128) return fail(MI_ERR_SHAPE, "head_dim must be 128");
   if ((cache_k == nullptr) != (cache_v == nullptr) || (cache_k && W <= 0)) return fail(MI_ERR_ARG, "mi_qkv_rope_kvwrite: cache");
@@ -379,7 +385,7 @@ int mi_qkv_rope_kvwrite(void* qkv, int ldo, const void* x, int ldx, int T, int D
   a.w0 = (const bf16_t*)wq; a.w1 = (const bf16_t*)wk; a.w2 = (const bf16_t*)wv; a.n0 = nq; a.n1 = nq + nkv;
   a.out = qkv; a.ldo = ldo;
   a.rope_cs = rope_cs; a.tok_pos = tok_pos; a.tok_seq = tok_seq; a.head_dim = head_dim;
-  a.write_kv = cache_k != nullptr; a.cache_k = cache_k; a.cache_v = cache_v; a.W = W;
+  a.write_kv = cache_k != nullptr; a.cache_k = cache_k; a.cache_v = cache_v; a.W = W; a.kv_layout = kv_layout;
   return gemv_passes(a, T, (hipStream_t)stream, "qkv gemv");
 }
 
@@ -583,6 +589,8 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
   const int T = bt->T, B = bt->B, branch = bt->branch;
   const bool has_cache = branch != MI_BRANCH_NOCACHE;
   if (has_cache && (!bt->cache_k || !bt->cache_v || !bt->cache_sizes)) return fail(MI_ERR_ARG, "mi_forward: cache");
+  if (!kv_layout_ok(bt->kv_layout)) return fail(MI_ERR_ARG, "mi_forward: kv_layout");
+  const int kvl = bt->kv_layout;
   if (branch == MI_BRANCH_DECODE && (T != B || !bt->kv_seqlens)) return fail(MI_ERR_ARG, "mi_forward: decode needs T == B");
   if ((size_t)B * m->n_kv_heads * 4 > TICKET_BYTES) return fail(MI_ERR_SHAPE, "B * n_kv_heads > 1024");
   if (bt->logits && (!m->final_norm || !m->output)) return fail(MI_ERR_ARG, "mi_forward: logits on a rank without LM head");
@@ -628,7 +636,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
     EngProblem pr;
     memset(&pr, 0, sizeof(pr));
     pr.D = D; pr.H = H; pr.Hkv = Hkv; pr.F = F; pr.V = m->vocab_size; pr.n_layers = m->n_layers; pr.NB = device_cus();
-    pr.eps = m->norm_eps; pr.layers = m->layers; pr.cache_k = bt->cache_k; pr.cache_v = bt->cache_v; pr.W = bt->cache_sizes;
+    pr.eps = m->norm_eps; pr.layers = m->layers; pr.cache_k = bt->cache_k; pr.cache_v = bt->cache_v; pr.W = bt->cache_sizes; pr.kv_layout = kvl;
     pr.h = h; pr.rope_cs = m->rope_cs;
     pr.emb = embed ? m->tok_embeddings : nullptr; pr.ids = bt->input_ids; pr.kv_seqlens = bt->kv_seqlens;
     pr.q_start = bt->q_start; pr.kv_before = bt->kv_before; pr.tok_seq = bt->tok_seq; pr.tok_pos = bt->tok_pos;
@@ -719,7 +727,7 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       a.w0 = (const bf16_t*)L.wq; a.w1 = (const bf16_t*)L.wk; a.w2 = (const bf16_t*)L.wv; a.n0 = nq; a.n1 = nq + nkv;
       a.out = ws.qkv; a.ldo = qkv_cols;
       a.rope_cs = m->rope_cs; a.tok_pos = bt->tok_pos; a.tok_seq = bt->tok_seq; a.head_dim = Dh;
-      a.write_kv = branch == MI_BRANCH_DECODE; a.cache_k = ck; a.cache_v = cv; a.W = W;
+      a.write_kv = branch == MI_BRANCH_DECODE; a.cache_k = ck; a.cache_v = cv; a.W = W; a.kv_layout = kvl;
       MI_TRY(gemv_passes(a, T, s, "qkv gemv"));
     } else {
       MI_TRY(hip_rc(launch_rmsnorm(ws.xn, h, L.attention_norm, T, D, m->norm_eps, s), "attention_norm"));
@@ -738,26 +746,28 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       // precede the attention (cache.py:83-92 `update` then read, transformer_layers.py:77-81)
       if (branch == MI_BRANCH_DECODE)
         MI_TRY(hip_rc(launch_kv_write(ck, cv, W, ws.qkv + nq, ws.qkv + nq + nkv, qkv_cols, T, nkv, bt->tok_seq, bt->tok_pos,
-                                      bt->q_start, s), "kv_write (decode)"));
+                                      bt->q_start, kvl, Dh, s), "kv_write (decode)"));
     }
 
     // ---- attention
     if (branch == MI_BRANCH_DECODE) {
       AttnDecodeArgs a;
       a.out = ws.attn; a.q = ws.qkv; a.ldq = qkv_cols; a.cache_k = (const bf16_t*)ck; a.cache_v = (const bf16_t*)cv;
+      a.kv_layout = kvl;
       a.W = W; a.B = B; a.H = H; a.Hkv = Hkv; a.Dh = Dh; a.tok_pos = bt->tok_pos;
       a.partial = ws.partial; a.tickets = ws.tickets; a.n_splits = attn_decode_splits(W);
       MI_TRY(hip_rc(launch_attn_decode(a, s), "attn_decode"));
     } else {
       AttnPrefillArgs a;
       a.out = ws.attn; a.qkv = ws.qkv; a.ld = qkv_cols; a.cache_k = (const bf16_t*)ck; a.cache_v = (const bf16_t*)cv;
+      a.kv_layout = kvl;
       a.W = has_cache ? W : T; a.B = B; a.max_q_len = has_cache ? bt->max_q_len : T; a.H = H; a.Hkv = Hkv; a.Dh = Dh;
       a.q_start = bt->q_start; a.kv_before = bt->kv_before; a.causal = has_cache ? 1 : 0;
       a.scale = 1.0f / sqrtf((float)m->head_dim);
       MI_TRY(hip_rc(launch_attn_prefill(a, s), "attn_prefill"));
       if (has_cache)
         MI_TRY(hip_rc(launch_kv_write(ck, cv, W, ws.qkv + nq, ws.qkv + nq + nkv, qkv_cols, T, nkv, bt->tok_seq, bt->tok_pos,
-                                      bt->q_start, s), "kv_write"));
+                                      bt->q_start, kvl, Dh, s), "kv_write"));
     }
 
     // ---- h = h + attn @ Wo^T
@@ -1025,6 +1035,8 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
   const int T = bt->T, B = bt->B, branch = bt->branch;
   const bool has_cache = branch != MI_BRANCH_NOCACHE;
   if (has_cache && (!bt->cache_k || !bt->cache_v || !bt->cache_sizes)) return fail(MI_ERR_ARG, "mi_forward_generic: cache");
+  if (!kv_layout_ok(bt->kv_layout)) return fail(MI_ERR_ARG, "mi_forward_generic: kv_layout");
+  const int kvl = bt->kv_layout;
   if (branch == MI_BRANCH_DECODE && (T != B || !bt->kv_seqlens)) return fail(MI_ERR_ARG, "mi_forward_generic: decode needs T == B");
   if (bt->logits && (!m->final_norm || !m->output)) return fail(MI_ERR_ARG, "mi_forward_generic: logits on a rank without LM head");
   hipStream_t s = (hipStream_t)stream;
@@ -1127,7 +1139,7 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     // ---- attention over [surviving ring entries ++ this forward's keys], then the ring write (cache.py:83-117)
     GAttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.out = ws.attn; a.ldo = nq; a.qkv = ws.qkv; a.ld = qkv_cols; a.cache_k = ck; a.cache_v = cv;
+    a.out = ws.attn; a.ldo = nq; a.qkv = ws.qkv; a.ld = qkv_cols; a.cache_k = ck; a.cache_v = cv; a.kv_layout = kvl;
     a.W = W; a.T = T; a.H = H; a.Hkv = Hkv; a.Dh = Dh;
     a.q_start = bt->q_start; a.kv_before = bt->kv_before; a.tok_seq = bt->tok_seq; a.tok_pos = bt->tok_pos;
     a.causal = has_cache ? 1 : 0;
@@ -1137,7 +1149,7 @@ int mi_forward_generic(const mi_model_t* m, const mi_batch_t* bt, int dtype, mi_
     MI_TRY(hip_rc(launch_g_attention(dt, a, s), "attention"));
     if (has_cache)
       MI_TRY(hip_rc(launch_g_kv_write(dt, ck, cv, W, ws.qkv + (size_t)nq * es, ws.qkv + (size_t)(nq + nkv) * es, qkv_cols, T, nkv,
-                                      bt->tok_seq, bt->tok_pos, bt->q_start, s), "kv_write"));
+                                      bt->tok_seq, bt->tok_pos, bt->q_start, kvl, Dh, s), "kv_write"));
     // ---- h = h + wo(attn)
     if (rows16) {
       GemvArgs a;

@@ -56,9 +56,13 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 1) void attn_decode_kernel(AttnDec
   // `kvh` is a SCHEDULED kv head: when a GQA ratio is split into groups, kv_groups consecutive scheduled heads read the
   // same real head's K/V (the repeat hits the XCD's L2) and own consecutive slices of its query heads.
   const int kv_real = kvh / a.kv_groups;
-  const size_t row_stride = (size_t)(a.Hkv / a.kv_groups) * DH;  // elements between consecutive slots
-  const bf16_t* kbase = a.cache_k + ((size_t)b * a.W) * row_stride + (size_t)kv_real * DH + dl * 8;
-  const bf16_t* vbase = a.cache_v + ((size_t)b * a.W) * row_stride + (size_t)kv_real * DH + dl * 8;
+  // elements between consecutive slots: a whole row of kv heads in the reference's layout, ONE head row in the head-major
+  // layout (common.cuh) - there the four lane groups of a wave read four consecutive slots = one contiguous KiB per load
+  const int hkv_real = a.Hkv / a.kv_groups;
+  const size_t row_stride = a.kv_layout ? (size_t)DH : (size_t)hkv_real * DH;
+  const size_t ring0 = kv_offset(a.kv_layout, a.W, hkv_real * DH, DH, (size_t)b, 0, kv_real * DH) + dl * 8;
+  const bf16_t* kbase = a.cache_k + ring0;
+  const bf16_t* vbase = a.cache_v + ring0;
 
   // Each lane group walks slots s_begin + wid*4 + g + 16*j, UK slots (K and V rows = 2*UK loads) per step, two
   // steps in flight (ping-pong register sets A/B refilled in place, 16 KiB per wave outstanding): the kernel is pure

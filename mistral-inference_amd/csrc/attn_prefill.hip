@@ -139,8 +139,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
   // clamped position: a `cond ? load : 0` makes hipcc branch around every load and wait vmcnt(0) after each one
   // (cdna_hip_programming.md ".s-level traps" (c)), which serialised this staging to one load in flight.
   // Keys past kp_hi are masked in the softmax (their P is exactly 0), so the clamped duplicates are harmless.
-  const bf16_t* ring_k0 = a.cache_k ? a.cache_k + ((size_t)b * W) * kv_dim + (size_t)kvh * DH : a.qkv;
-  const bf16_t* ring_v0 = a.cache_v ? a.cache_v + ((size_t)b * W) * kv_dim + (size_t)kvh * DH : a.qkv;
+  const size_t ring0 = kv_offset(a.kv_layout, W, kv_dim, DH, (size_t)b, 0, kvh * DH);
+  const int ring_stride = a.kv_layout ? DH : kv_dim;  // elements between consecutive ring slots of this kv head (common.cuh)
+  const bf16_t* ring_k0 = a.cache_k ? a.cache_k + ring0 : a.qkv;
+  const bf16_t* ring_v0 = a.cache_v ? a.cache_v + ring0 : a.qkv;
   const bf16_t* act_k0 = a.qkv + nq_cols + (size_t)kvh * DH;
   const bf16_t* act_v0 = act_k0 + kv_dim;
   // kp % W costs ~17 VALU instructions per load when done per lane (there is no integer divide); the tile's first key
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
       if constexpr (BIG) slot = (slot >= W) ? slot - W : slot;
       else slot = kp % W;
       const int arow = row0 + kp - p_b;
-      return (kp < p_b) ? slot * kv_dim : arow * a.ld;
+      return (kp < p_b) ? slot * ring_stride : arow * a.ld;
     };
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {

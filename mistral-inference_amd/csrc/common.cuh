@@ -36,6 +36,22 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
 }
 
+// K/V ring layouts (data layout in HBM is ours to choose; a kv head's head_dim elements are contiguous in both):
+//   0  [max_batch, W, n_kv_heads, head_dim] - the reference's (cache.py:163-167); leaf operators called with a caller's own rings
+//   1  [max_batch, n_kv_heads, W, head_dim] - head-major: the slots of ONE kv head are contiguous, so a decode split's keys are a
+//      single run (4 slots = one 1-KiB DMA piece, 16 slots = a 4-KiB run: what the persistent engine's loader streams at the
+//      weight rate; the strided form costs it 1.2 us per 16 KiB against 0.66 - profiles/EXPERIMENTS.md round 6).  BufferCache
+//      allocates this form and exposes it as a permuted view of the reference's shape.
+#ifndef MI_KV_SLOT_MAJOR
+#define MI_KV_SLOT_MAJOR 0
+#define MI_KV_HEAD_MAJOR 1
+#endif
+// element offset of (sequence, slot, column c = kv_head * head_dim + d) inside a ring of W slots
+__host__ __device__ __forceinline__ size_t kv_offset(int layout, int W, int kv_dim, int Dh, size_t seq, int slot, int c) {
+  return layout ? ((seq * (size_t)(kv_dim / Dh) + (size_t)(c / Dh)) * (size_t)W + (size_t)slot) * (size_t)Dh + (size_t)(c % Dh)
+                : (seq * (size_t)W + (size_t)slot) * (size_t)kv_dim + (size_t)c;
+}
+
 // 16-byte loads.  `nt` marks streamed-once data (weights at decode): MI355X_MICROARCH "nt-weights".
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) {

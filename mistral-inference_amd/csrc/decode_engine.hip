@@ -169,6 +169,10 @@ constexpr int NCONS = 4;
 #define ENG_NOSTOP 0
 #endif
 #define GATHER_FLAG(bit) ((ENG_NOSTOP & (bit)) ? 0u : 1u)
+// ENG_CLEAN_ENTRY = 1: run_loader begins with a wait-count instruction that hipcc models (see there; round 6)
+#ifndef ENG_CLEAN_ENTRY
+#define ENG_CLEAN_ENTRY 0
+#endif
 #ifndef ENG_HOLD_STAGE
 #define ENG_HOLD_STAGE 3  // the holders' fetch of a layer's units may begin when the loader has issued: 0 nothing yet, 1 q|k|v, 2 + K/V, 3 + Wo
 #endif
@@ -331,6 +335,18 @@ __device__ __forceinline__ void plan_layer(const EngArgs& a, const EngLayer& L, 
 
 // pieces per group of a unit's interleaved stream (loader and consumers must agree)
 __device__ __forceinline__ int unit_group(int P) { return (P & 3) == 0 ? 4 : ((P & 1) == 0 ? 2 : 1); }
+
+// K/V pieces of a workgroup's attention work item.  Ring layout MI_KV_HEAD_MAJOR (common.cuh): the slots of a kv head are
+// contiguous, a piece (4 slots x 256 B) is ONE KiB of memory and 4 pieces a 4-KiB run - streamed like a weight row, four pieces
+// per address computation, as [K j .. j+3][V j .. j+3] (kv_runs): 0.66 us per 16 KiB instead of 1.2 for single strided pieces
+// (the K/V issue sat on the attention block's critical path: profiles/EXPERIMENTS.md round 6).  Otherwise (the reference's
+// layout, a split that is not whole groups of 16 slots, a stream position that is not a multiple of 4): [K j][V j] single pieces.
+__device__ __forceinline__ bool kv_runs(const EngLayer& L, const LayerPlan& p, uint32_t g) {
+  return L.kv_layout == MI_KV_HEAD_MAJOR && p.n_att > 0 && (p.n_att & 3) == 0 && (g & 3u) == 0 && p.s_begin + 4 * p.n_att <= L.W;
+}
+// ring piece (relative to the first K/V piece) of K piece j / V piece j
+__device__ __forceinline__ uint32_t kv_piece_k(bool runs, int j) { return runs ? (uint32_t)(8 * (j >> 2) + (j & 3)) : (uint32_t)(2 * j); }
+__device__ __forceinline__ uint32_t kv_piece_v(bool runs, int j) { return runs ? (uint32_t)(8 * (j >> 2) + (j & 3) + 4) : (uint32_t)(2 * j + 1); }
 
 // HOLDER waves: the last holder_units() W1|W3 units of a CU's slab never pass through the ring.  A holder wave fetches
 // its unit (4 rows x D bf16 = 32 KiB at D = 4096) straight into 128 of its VGPRs while the attention block of the layer
@@ -607,6 +623,17 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
 #if ENG_SADDR
   ld.lane16 = (uint32_t)lane * 16u;
 #endif
+#if ENG_CLEAN_ENTRY
+  // hipcc structurizes the role split of the kernel into a chain of `Flow` blocks, so that - statically - the loader's code is
+  // reachable from the holders' and the consumers' code, and its wait-count pass carries THEIR outstanding register loads into
+  // this function: wherever the loader first writes a VGPR that such a load names, it places `s_waitcnt vmcnt(N)` - inside
+  // the loader's issue loops, where the same instruction then drains the DMA queue on every pass (N = 4: +30 % per step; which
+  // registers collide changes with every edit: the "regimes" of rounds 3-5, profiles/EXPERIMENTS.md round 6).  One wait that the
+  // pass understands, executed once at the role's entry, empties its scoreboard.  (Measured 0.3-0.4 % slower than a build whose
+  // loader happens to be clean without it - scripts/engine_loader_waits.py checks that statically - so the shipped builds leave
+  // it off and are held to the check instead: tests/test_engine_build.py.)
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
   __builtin_amdgcn_s_setprio(3);  // the loader shares a SIMD with one consumer wave: its few instructions go first
   const int PD = a.D >> 9;
   for (int l = 0; l < a.n_layers; ++l) {
@@ -637,12 +664,27 @@ __device__ __forceinline__ void run_loader(const EngArgs& a, const Shared& sh, i
     if (NHOLD && ENG_HOLD_STAGE == 1) sh.ctl[C_LSTAGE] = (uint32_t)(l + 1);
     if (p.n_att) {  // K piece j, V piece j: 4 ring slots x 256 B each (slots past the ring end are clamped; masked later)
       const int kv_real = p.kvh / a.kv_groups;
-      const size_t row_stride = (size_t)a.Hkv * DH;
-      const size_t base = ((size_t)seq * L.W) * row_stride + (size_t)kv_real * DH + (lane & 15) * 8;
-      for (int j = 0; j < p.n_att; ++j) {
-        const int slot = min(p.s_begin + 4 * j + (lane >> 4), L.W - 1);
-        ld.piece(L.ck + base + (size_t)slot * row_stride);
-        ld.piece(L.cv + base + (size_t)slot * row_stride);
+      const size_t row_stride = L.kv_layout ? (size_t)DH : (size_t)a.Hkv * DH;  // elements between consecutive slots of this kv head
+      const size_t ring0 = kv_offset(L.kv_layout, L.W, a.Hkv * DH, DH, (size_t)seq, 0, kv_real * DH);
+      if (kv_runs(L, p, ld.g)) {  // (head-major rings) 16 slots = 4 pieces = one 4-KiB run, K then V
+        const bf16_t* kb = L.ck + ring0 + (size_t)p.s_begin * DH;
+        const bf16_t* vb = L.cv + ring0 + (size_t)p.s_begin * DH;
+        for (int j = 0; j < p.n_att; j += 4) {
+#if ENG_SADDR
+          ld.piece4_s(reinterpret_cast<const char*>(kb) + (size_t)j * PIECE);
+          ld.piece4_s(reinterpret_cast<const char*>(vb) + (size_t)j * PIECE);
+#else
+          ld.piece4(reinterpret_cast<const char*>(kb) + (size_t)j * PIECE + lane * 16);
+          ld.piece4(reinterpret_cast<const char*>(vb) + (size_t)j * PIECE + lane * 16);
+#endif
+        }
+      } else {
+        const size_t base = ring0 + (lane & 15) * 8;
+        for (int j = 0; j < p.n_att; ++j) {
+          const int slot = min(p.s_begin + 4 * j + (lane >> 4), L.W - 1);
+          ld.piece(L.ck + base + (size_t)slot * row_stride);
+          ld.piece(L.cv + base + (size_t)slot * row_stride);
+        }
       }
     }
     trace_ev(sh, c, l, TR_CONS + 2, tr);
@@ -1414,8 +1456,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
           }
           const uint32_t packed = pack_bf2(y0, y1);
           if (kind > 0) {  // cache.py:83-92
-            const size_t slot = (size_t)seq * L.W + p.cur_slot;
-            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + r0;
+            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + kv_offset(L.kv_layout, L.W, nkv, DH, (size_t)seq, p.cur_slot, r0);
             *reinterpret_cast<uint32_t*>(ring) = packed;
           }
           const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
@@ -1462,6 +1503,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       // partials are the same bits.
       if constexpr (R == 6) {
         {  // (never `streamed`: decode_engine_applicable declines rings whose split does not fit the LDS ring at this ratio)
+          const bool runs = kv_runs(L, p, g);
           if (p.n_att) cs.need_fill(g + 2 * p.n_att - 1);
 #pragma unroll
           for (int pass = 0; pass < 2; ++pass) {
@@ -1477,9 +1519,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
             State<RP> sp;
             init_state<RP>(sp);
             for (int j = w; j < p.n_att; j += NCONS) {
-              const uint32_t gk = g + 2 * j;
-              u32x4 kraw = lds16(sh.ring + RING_IDX(sh, gk) * PIECE + lane * 16);
-              u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gk + 1) * PIECE + lane * 16);
+              u32x4 kraw = lds16(sh.ring + RING_IDX(sh, g + kv_piece_k(runs, j)) * PIECE + lane * 16);
+              u32x4 vraw = lds16(sh.ring + RING_IDX(sh, g + kv_piece_v(runs, j)) * PIECE + lane * 16);
               const int slot = p.s_begin + 4 * j + gl;
               if (slot == p.cur_slot) {
                 kraw = lds16(kn_lds + dl * 4);
@@ -1513,15 +1554,16 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       // ONE wait for the last of them instead of a wait + ring bookkeeping per piece ... as long as they all fit the ring
       // while this wave pins its position (a 272-slot split of an 8K ring is 136 pieces: per-piece bookkeeping then)
       const bool streamed = 2 * p.n_att > (RING_FILLS - 2) * FILL;
+      const bool runs = kv_runs(L, p, g);  // the loader's piece order: [K j .. j+3][V j .. j+3] runs or [K j][V j]
       if (p.n_att && !streamed) cs.need_fill(g + 2 * p.n_att - 1);
       for (int j = w; j < p.n_att; j += NCONS) {  // virtual wave w of the stand-alone kernel
-        const uint32_t gk = g + 2 * j;
-        if (streamed) {
-          cs.set_done(gk);
-          cs.need_fill(gk + 1);
+        const uint32_t gk = g + kv_piece_k(runs, j), gv = g + kv_piece_v(runs, j);
+        if (streamed) {  // (runs: this wave's next pieces lie in the group of 8 that begins at gk - (j & 3))
+          cs.set_done(runs ? gk - (uint32_t)(j & 3) : gk);
+          cs.need_fill(gv);
         }
         u32x4 kraw = lds16(sh.ring + RING_IDX(sh, gk) * PIECE + lane * 16);
-        u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gk + 1) * PIECE + lane * 16);
+        u32x4 vraw = lds16(sh.ring + RING_IDX(sh, gv) * PIECE + lane * 16);
         const int slot = p.s_begin + 4 * j + gl;
         if (slot == p.cur_slot) {  // this step's K/V row: taken from the granules, its ring write may still be in flight
           kraw = lds16(kn_lds + dl * 4);
@@ -1893,8 +1935,7 @@ __device__ __forceinline__ void run_qkv_holder(const EngArgs& a, const Shared& s
           }
           const uint32_t packed = pack_bf2(y0, y1);
           if (kind > 0) {  // cache.py:83-92
-            const size_t slot = (size_t)seq * L.W + p.cur_slot;
-            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + 2 * u;
+            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + kv_offset(L.kv_layout, L.W, nkv, DH, (size_t)seq, p.cur_slot, 2 * u);
             *reinterpret_cast<uint32_t*>(ring) = packed;
           }
           const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
@@ -1993,8 +2034,7 @@ __device__ __forceinline__ void run_qkv_holder1(const EngArgs& a, const Shared& 
           }
           const uint32_t packed = pack_bf2(y0, y1);
           if (kind > 0) {  // cache.py:83-92
-            const size_t slot = (size_t)seq * L.W + p.cur_slot;
-            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + slot * nkv + 2 * u;
+            bf16_t* ring = (kind == 1 ? L.ck : L.cv) + kv_offset(L.kv_layout, L.W, nkv, DH, (size_t)seq, p.cur_slot, 2 * u);
             *reinterpret_cast<uint32_t*>(ring) = packed;
           }
           const int gi = (kind == 0 ? 0 : (kind == 1 ? nq / 2 : nq / 2 + nkv / 2)) + u;
@@ -2404,6 +2444,7 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
       }
       L.ck = (bf16_t*)pr.cache_k[l0 + l]; L.cv = (bf16_t*)pr.cache_v[l0 + l];
       L.W = pr.W[l0 + l];
+      L.kv_layout = pr.kv_layout;
       L.n_splits = attn_decode_splits(L.W);
       L.chunk = attn_core::split_chunk(L.W, L.n_splits);
     }

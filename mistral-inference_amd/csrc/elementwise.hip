@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qkv, int ld, int T, i
 // cache.py:83-92 + 226-235
 __global__ __launch_bounds__(256) void kv_write_kernel(bf16_t* ck, bf16_t* cv, int W, const bf16_t* k, const bf16_t* v,
                                                        int ld, int T, int kv_dim, const int32_t* tok_seq,
-                                                       const int32_t* tok_pos, const int32_t* q_start) {
+                                                       const int32_t* tok_pos, const int32_t* q_start, int layout, int Dh) {
   const int pieces = kv_dim >> 3;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long)T * pieces) return;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void kv_write_kernel(bf16_t* ck, bf16_t* cv, i
   const int i = t - q_start[b];
   const int s = q_start[b + 1] - q_start[b];
   if (i < s - W) return;  // to_cache_mask: only the last W tokens of the chunk are stored
-  const size_t slot = (size_t)b * W + (tok_pos[t] % W);
-  st16(ck + slot * kv_dim + p * 8, ld16(k + (size_t)t * ld + p * 8));
-  st16(cv + slot * kv_dim + p * 8, ld16(v + (size_t)t * ld + p * 8));
+  const size_t off = kv_offset(layout, W, kv_dim, Dh, (size_t)b, tok_pos[t] % W, p * 8);  // (Dh % 8 == 0: a piece stays inside a head)
+  st16(ck + off, ld16(k + (size_t)t * ld + p * 8));
+  st16(cv + off, ld16(v + (size_t)t * ld + p * 8));
 }
 
 // Decode step metadata from the device-resident kv_seqlens (no host round trip), then
@@ -461,10 +461,11 @@ hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const f
   return hipGetLastError();
 }
 hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
-                           const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s) {
+                           const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, int kv_layout, int Dh, hipStream_t s) {
+  if (Dh <= 0 || Dh % 8 || kv_dim % Dh) return hipErrorInvalidValue;
   const long n = (long)T * (kv_dim >> 3);
   hipLaunchKernelGGL(kv_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)ck, (bf16_t*)cv, W,
-                     (const bf16_t*)k, (const bf16_t*)v, ld, T, kv_dim, tok_seq, tok_pos, q_start);
+                     (const bf16_t*)k, (const bf16_t*)v, ld, T, kv_dim, tok_seq, tok_pos, q_start, kv_layout, Dh);
   return hipGetLastError();
 }
 hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,

@@ -343,9 +343,8 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
             if (a.write_kv && r0 >= a.n0) {  // cache.py:83-92: ring slot pos % W of this sequence's row
               const int kv_dim = a.n1 - a.n0;
               const int seq = a.tok_seq ? a.tok_seq[t] : t;
-              const size_t slot = (size_t)seq * a.W + (pos % a.W);
-              bf16_t* ring = (r0 < a.n1) ? reinterpret_cast<bf16_t*>(a.cache_k) + slot * kv_dim + (r0 - a.n0)
-                                         : reinterpret_cast<bf16_t*>(a.cache_v) + slot * kv_dim + (r0 - a.n1);
+              const size_t off = kv_offset(a.kv_layout, a.W, kv_dim, a.head_dim, (size_t)seq, pos % a.W, (r0 < a.n1) ? r0 - a.n0 : r0 - a.n1);
+              bf16_t* ring = ((r0 < a.n1) ? reinterpret_cast<bf16_t*>(a.cache_k) : reinterpret_cast<bf16_t*>(a.cache_v)) + off;
               *reinterpret_cast<uint32_t*>(ring) = pack_bf2(y0, y1);
             }
           }

@@ -514,7 +514,8 @@ __global__ __launch_bounds__(256) void g_rope_kernel(T* qkv, int ld, int T_rows,
 // cache.py:83-92 + 226-235 (kv_write_kernel for any element type): only the last W tokens of a chunk are stored.
 template <typename T>
 __global__ __launch_bounds__(256) void g_kv_write_kernel(T* ck, T* cv, int W, const T* k, const T* v, int ld, int T_rows, int kv_dim,
-                                                         const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start) {
+                                                         const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start,
+                                                         int layout, int Dh) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long)T_rows * kv_dim) return;
   const int t = (int)(gid / kv_dim), c = (int)(gid % kv_dim);
@@ -522,9 +523,9 @@ __global__ __launch_bounds__(256) void g_kv_write_kernel(T* ck, T* cv, int W, co
   const int i = t - q_start[b];
   const int s = q_start[b + 1] - q_start[b];
   if (i < s - W) return;
-  const size_t slot = (size_t)b * W + (tok_pos[t] % W);
-  ck[slot * kv_dim + c] = k[(size_t)t * ld + c];
-  cv[slot * kv_dim + c] = v[(size_t)t * ld + c];
+  const size_t off = kv_offset(layout, W, kv_dim, Dh, (size_t)b, tok_pos[t] % W, c);
+  ck[off] = k[(size_t)t * ld + c];
+  cv[off] = v[(size_t)t * ld + c];
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -606,8 +607,10 @@ __global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
   g_row_load<T, EPL>(qkv + (size_t)t * a.ld + (size_t)h * Dh, lane, Dh, q);
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
-  const T* ring_k = a.cache_k ? reinterpret_cast<const T*>(a.cache_k) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : qkv;
-  const T* ring_v = a.cache_v ? reinterpret_cast<const T*>(a.cache_v) + ((size_t)b * W) * kv_dim + (size_t)kvh * Dh : qkv;
+  const size_t ring0 = kv_offset(a.kv_layout, W, kv_dim, Dh, (size_t)b, 0, kvh * Dh);
+  const size_t ring_stride = a.kv_layout ? (size_t)Dh : (size_t)kv_dim;  // elements between consecutive ring slots of this kv head
+  const T* ring_k = a.cache_k ? reinterpret_cast<const T*>(a.cache_k) + ring0 : qkv;
+  const T* ring_v = a.cache_v ? reinterpret_cast<const T*>(a.cache_v) + ring0 : qkv;
   const T* act_k = qkv + nq + (size_t)kvh * Dh;
   const T* act_v = act_k + kv_dim;
   float m_run = -INFINITY, l_run = 0.f;
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void g_attention_kernel(GAttnArgs a) {
       const int kp = min(base + u, kp_hi);
       const T *kr, *vr;
       if (kp < p_b) {  // wave-uniform
-        const size_t off = (size_t)(kp % W) * kv_dim;
+        const size_t off = (size_t)(kp % W) * ring_stride;
         kr = ring_k + off;
         vr = ring_v + off;
       } else {
@@ -980,9 +983,10 @@ hipError_t launch_g_rope(int dt, void* qkv, int ld, int T_rows, int n_rot_cols, 
 }
 
 hipError_t launch_g_kv_write(int dt, void* ck, void* cv, int W, const void* k, const void* v, int ld, int T_rows, int kv_dim,
-                             const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s) {
+                             const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, int kv_layout, int Dh, hipStream_t s) {
+  if (Dh <= 0 || kv_dim % Dh) return hipErrorInvalidValue;
   G_DISPATCH(dt, hipLaunchKernelGGL((g_kv_write_kernel<T>), dim3(blocks_for((size_t)T_rows * kv_dim)), dim3(256), 0, s, (T*)ck, (T*)cv, W,
-                                    (const T*)k, (const T*)v, ld, T_rows, kv_dim, tok_seq, tok_pos, q_start))
+                                    (const T*)k, (const T*)v, ld, T_rows, kv_dim, tok_seq, tok_pos, q_start, kv_layout, Dh))
 }
 
 hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s) {
@@ -1001,6 +1005,7 @@ hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s) {
     AttnPrefillArgs p;
     p.out = a.out; p.qkv = reinterpret_cast<const bf16_t*>(a.qkv); p.ld = a.ld;
     p.cache_k = reinterpret_cast<const bf16_t*>(a.cache_k); p.cache_v = reinterpret_cast<const bf16_t*>(a.cache_v);
+    p.kv_layout = a.kv_layout;
     p.W = a.W; p.B = a.B; p.max_q_len = a.max_q_len; p.H = a.H; p.Hkv = a.Hkv; p.Dh = a.Dh;
     p.q_start = a.q_start; p.kv_before = a.kv_before; p.causal = a.causal; p.scale = a.scale;
     return launch_attn_prefill_f16(p, s);

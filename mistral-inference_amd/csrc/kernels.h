@@ -50,6 +50,7 @@ struct GemvArgs {
   void* cache_k;
   void* cache_v;
   int W;
+  int kv_layout;  // MI_KV_SLOT_MAJOR / MI_KV_HEAD_MAJOR (common.cuh)
   // MoE
   const void* const* expert_tab;  // device [E][3]
   const int32_t* sel_idx;         // device [T*top_k]
@@ -115,8 +116,9 @@ struct AttnDecodeArgs {
   void* out;            // [B, H*Dh]
   const bf16_t* q;      // [B, ldq]
   int ldq;
-  const bf16_t* cache_k;  // [maxB, W, Hkv*Dh]
+  const bf16_t* cache_k;  // [maxB, W, Hkv*Dh] (kv_layout 0) or [maxB, Hkv, W, Dh] (1)
   const bf16_t* cache_v;
+  int kv_layout;
   int W, B, H, Hkv, Dh;    // Hkv: kv heads AS SCHEDULED = real kv heads x kv_groups (launch_attn_decode sets both)
   int kv_groups;           // query-head groups per real kv head (1 unless the GQA ratio is split, see launch_attn_decode)
   const int32_t* tok_pos;  // [B]
@@ -135,6 +137,7 @@ struct AttnPrefillArgs {
   int ld;
   const bf16_t* cache_k;
   const bf16_t* cache_v;
+  int kv_layout;  // MI_KV_SLOT_MAJOR / MI_KV_HEAD_MAJOR (common.cuh)
   int W, B, max_q_len, H, Hkv, Dh;
   const int32_t* q_start;    // [B+1]
   const int32_t* kv_before;  // [B]
@@ -172,7 +175,7 @@ hipError_t launch_rmsnorm(void* out, const void* x, const void* w, int T, int D,
 hipError_t launch_rope(void* qkv, int ld, int T, int H, int Hkv, int Dh, const float* rope_cs, const int32_t* tok_pos,
                        hipStream_t s);
 hipError_t launch_kv_write(void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
-                           const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s);
+                           const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, int kv_layout, int Dh, hipStream_t s);
 // engine_ctrl (nullable): control words of the workspace - [0] step epoch of the persistent decode engine (incremented
 // here), [2] its per-step abort broadcast (cleared here), [3] out-of-range token id flag (launch_embedding)
 hipError_t launch_decode_prep(int64_t* kv_seqlens, int32_t* q_start, int32_t* kv_before, int32_t* tok_seq,
@@ -215,7 +218,7 @@ constexpr int ENG_MAXL = 32;  // layers per launch: bounded by the 4 KiB kernel-
 struct EngLayer {
   const bf16_t *an, *wq, *wk, *wv, *wo, *fn, *w1, *w2, *w3;
   bf16_t *ck, *cv;
-  int W, n_splits, chunk, pad;
+  int W, n_splits, chunk, kv_layout;  // kv_layout: MI_KV_SLOT_MAJOR / MI_KV_HEAD_MAJOR (common.cuh)
 };
 
 struct EngArgs {
@@ -258,6 +261,7 @@ struct EngProblem {
   void* const* cache_k;      // host [n_layers]
   void* const* cache_v;
   const int32_t* W;          // host [n_layers]
+  int kv_layout;             // layout of every ring (common.cuh)
   void* h;
   const float* rope_cs;
   const void* emb;           // nullptr: h holds the step's input
@@ -347,8 +351,9 @@ struct GAttnArgs {
   int ldo;
   const void* qkv;       // [T, ld]: q | k | v after RoPE
   int ld;
-  const void* cache_k;   // rings [max_batch, W, Hkv, Dh] (nullptr: cache=None call)
+  const void* cache_k;   // rings [max_batch, W, Hkv, Dh] or head-major [max_batch, Hkv, W, Dh] (nullptr: cache=None call)
   const void* cache_v;
+  int kv_layout;
   int W, T, H, Hkv, Dh;
   const int32_t* q_start;
   const int32_t* kv_before;
@@ -370,7 +375,7 @@ hipError_t launch_g_linear(int dt, const GLinearArgs& g, hipStream_t s);
 hipError_t launch_g_rope(int dt, void* qkv, int ld, int T, int n_rot_cols, int Dh, const float* rope_cs, const int32_t* tok_pos,
                          hipStream_t s);
 hipError_t launch_g_kv_write(int dt, void* ck, void* cv, int W, const void* k, const void* v, int ld, int T, int kv_dim,
-                             const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, hipStream_t s);
+                             const int32_t* tok_seq, const int32_t* tok_pos, const int32_t* q_start, int kv_layout, int Dh, hipStream_t s);
 hipError_t launch_g_attention(int dt, const GAttnArgs& a, hipStream_t s);
 hipError_t launch_g_swiglu(int dt, void* a, const void* b, int T, int F, const int32_t* active, hipStream_t s);
 hipError_t launch_g_moe_topk(int dt, const void* logits, int T, int E, int k, int32_t* sel_idx, float* sel_w, hipStream_t s);

@@ -21,7 +21,7 @@ def _default_lib() -> str:
 
 LIB_PATH = os.environ.get("MISTRAL_HIP_LIB", _default_lib())
 
-MI_ABI_VERSION = 6
+MI_ABI_VERSION = 7
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_LOGITS = 0, 1, 2, 3
 BRANCH_NOCACHE, BRANCH_PREFILL, BRANCH_DECODE = 0, 1, 2
 GEMV_MAX_T = 8
@@ -56,6 +56,7 @@ class MiBatch(C.Structure):
         ("workspace_bytes", C.c_size_t),
         ("greedy_token", _vp), ("greedy_logprob", _vp), ("hist_token", _vp), ("hist_logprob", _vp), ("hist_len", C.c_int32),
         ("sample_temperature", C.c_float), ("sample_top_p", C.c_float), ("sample_seed", C.c_uint64), ("sample_offset", C.c_uint64),  # ABI v5
+        ("kv_layout", C.c_int32),  # ABI v7: KV_SLOT_MAJOR / KV_HEAD_MAJOR, the layout of every ring in cache_k / cache_v
     ]
 
 
@@ -68,13 +69,13 @@ _SIGS = {
     "mi_embedding": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "mi_rmsnorm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
     "mi_rope_inplace": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
-    "mi_kv_write": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "mi_kv_write": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "mi_linear": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.c_int,
                             _vp, _vp, C.c_float, _vp]),
     "mi_attn_decode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "mi_attn_decode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mi_attn_decode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "mi_attn_prefill": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp,
-                                  _vp, C.c_int, C.c_float, _vp]),
+                                  _vp, C.c_int, C.c_float, C.c_int, _vp]),
     "mi_gelu": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "mi_greedy_sample": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "mi_sample_top_p": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
@@ -82,7 +83,7 @@ _SIGS = {
     "mi_lm_head_logprobs": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "mi_moe_router": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_float, _vp]),
     "mi_qkv_rope_kvwrite": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp,
-                                      C.c_float, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+                                      C.c_float, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "mi_moe_experts_decode": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_float,
                                         _vp, _vp]),
     "mi_moe_grouped_gemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -281,14 +282,37 @@ def rope_inplace(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int
                                 stream_ptr(qkv.device)), "mi_rope_inplace")
 
 
+KV_SLOT_MAJOR, KV_HEAD_MAJOR = 0, 1  # include/mistral_hip.h: MI_KV_SLOT_MAJOR / MI_KV_HEAD_MAJOR
+
+
+def kv_layout_of(ring: torch.Tensor) -> int:
+    """Layout of a K/V ring given in the reference's SHAPE [max_batch, W, n_kv_heads, head_dim] (cache.py:163-167): contiguous =
+    the reference's layout; a permuted view of a contiguous [max_batch, n_kv_heads, W, head_dim] tensor = head-major (what
+    `BufferCache` allocates: one kv head's slots are contiguous).  Anything else is rejected."""
+    assert ring.ndim == 4, f"K/V ring: expected [max_batch, W, n_kv_heads, head_dim], got {tuple(ring.shape)}"
+    B, W, H, D = ring.shape
+    st = ring.stride()
+    if ring.is_contiguous():
+        return KV_SLOT_MAJOR  # (also every degenerate shape whose two layouts coincide)
+    if st[3] == 1 and st[1] == D and st[2] == W * D and (B == 1 or st[0] == H * W * D):
+        return KV_HEAD_MAJOR
+    raise ValueError(f"K/V ring of shape {tuple(ring.shape)} with strides {st}: neither [B, W, H, D] contiguous nor a "
+                     "permuted view of a contiguous [B, H, W, D] tensor")
+
+
+def _kv_layout2(cache_k: torch.Tensor, cache_v: torch.Tensor) -> int:
+    assert cache_k.shape == cache_v.shape and cache_k.stride() == cache_v.stride(), "cache_k and cache_v must share shape and layout"
+    return kv_layout_of(cache_k)
+
+
 def kv_write(cache_k: torch.Tensor, cache_v: torch.Tensor, k: torch.Tensor, v: torch.Tensor, tok_seq: torch.Tensor,
              tok_pos: torch.Tensor, q_start: torch.Tensor) -> None:
     W = cache_k.shape[1]
     kv_dim = cache_k.shape[2] * cache_k.shape[3]
-    assert cache_k.is_contiguous() and cache_v.is_contiguous() and k.stride(0) == v.stride(0)
+    assert k.stride(0) == v.stride(0)
     check(lib().mi_kv_write(dev_ptr(cache_k), dev_ptr(cache_v), W, dev_ptr(k), dev_ptr(v), k.stride(0), k.shape[0], kv_dim,
                             dev_ptr(tok_seq, torch.int32), dev_ptr(tok_pos, torch.int32), dev_ptr(q_start, torch.int32),
-                            stream_ptr(k.device)), "mi_kv_write")
+                            _kv_layout2(cache_k, cache_v), cache_k.shape[3], stream_ptr(k.device)), "mi_kv_write")
 
 
 _decode_scratch = {}
@@ -305,7 +329,7 @@ def attn_decode(q: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, n
     out = torch.empty((B, n_heads * Dh), dtype=q.dtype, device=q.device)
     check(lib().mi_attn_decode(dev_ptr(out), dev_ptr(q), q.stride(0), dev_ptr(cache_k), dev_ptr(cache_v), W, B, n_heads, Hkv,
                                Dh, dev_ptr(tok_pos, torch.int32), dev_ptr(_decode_scratch[key], torch.uint8),
-                               stream_ptr(q.device)), "mi_attn_decode")
+                               _kv_layout2(cache_k, cache_v), stream_ptr(q.device)), "mi_attn_decode")
     return out
 
 
@@ -327,6 +351,7 @@ def attn_prefill(qkv: torch.Tensor, n_heads: int, n_kv_heads: int, head_dim: int
     check(lib().mi_attn_prefill(dev_ptr(out), dev_ptr(qkv), qkv.stride(0), dev_ptr(cache_k), dev_ptr(cache_v), W, B,
                                 max_q_len, n_heads, n_kv_heads, head_dim, dev_ptr(q_start, torch.int32),
                                 dev_ptr(kv_before, torch.int32), 1 if causal else 0, float(softmax_scale),
+                                _kv_layout2(cache_k, cache_v) if cache_k is not None else KV_SLOT_MAJOR,
                                 stream_ptr(qkv.device)), "mi_attn_prefill")
     return out
 
@@ -411,6 +436,7 @@ def qkv_rope_kvwrite(x: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: to
                                     dev_ptr(wv), nq // head_dim, nkv // head_dim, head_dim, dev_ptr(norm_w), float(eps),
                                     dev_ptr(rope_cs, torch.float32), rope_cs.shape[0], dev_ptr(tok_pos, torch.int32),
                                     dev_ptr(tok_seq, torch.int32), dev_ptr(cache_k), dev_ptr(cache_v), W,
+                                    _kv_layout2(cache_k, cache_v) if cache_k is not None else KV_SLOT_MAJOR,
                                     stream_ptr(x.device)), "mi_qkv_rope_kvwrite")
     return out
 

@@ -3,7 +3,8 @@
 Same constructor, attributes and methods as the reference's `BufferCache` (exported also under the
 historical name `RotatingBufferCache`), same ring semantics: layer l keeps the last W_l tokens of each
 sequence at slot `pos % W_l` of row b of `cache_k[l]` / `cache_v[l]` ([max_batch, W_l, n_kv_heads,
-head_dim]).  What differs is how a forward learns about it:
+head_dim] - the reference's shape; the STORAGE behind it is head-major, see `BufferCache.__init__`).  What differs is how a
+forward learns about it:
 
 * the reference rebuilds five small tensors + an xformers mask per LAYER per forward on the host and
   syncs the device several times (cache.py:217,246,253); here one int32 metadata block per FORWARD is
@@ -15,6 +16,7 @@ head_dim]).  What differs is how a forward learns about it:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -160,13 +162,33 @@ class BufferCache:
         kw = dict(device=device, dtype=dtype)
         self.cache_k: Dict[int, torch.Tensor] = {}
         self.cache_v: Dict[int, torch.Tensor] = {}
+        # Layout in HBM: head-major [max_batch, n_kv_heads, W, head_dim] - the slots of one kv head are
+        # contiguous, so what a decode work item (kv head, range of slots) reads is one run - exposed in the reference's SHAPE
+        # [max_batch, W, n_kv_heads, head_dim] (cache.py:163-167) as a permuted view: indexing, `torch.equal`, `CacheView.key`
+        # behave as in the reference; only `.view()` / `.is_contiguous()` can tell.  MI_KV_LAYOUT=0 allocates the reference's
+        # layout (A/B runs, tests); the kernels take both (`_hip.kv_layout_of`).
+        self.head_major = os.environ.get("MI_KV_LAYOUT", "1") != "0"
         for i, w in enumerate(self.cache_sizes):
-            self.cache_k[i] = torch.empty((max_batch_size, w, n_kv_heads, head_dim), **kw)
-            self.cache_v[i] = torch.empty((max_batch_size, w, n_kv_heads, head_dim), **kw)
+            self.cache_k[i] = self._alloc(max_batch_size, w, **kw)
+            self.cache_v[i] = self._alloc(max_batch_size, w, **kw)
         self.kv_seqlens: Optional[torch.Tensor] = None  # device int64 [B], as in the reference
         self._seen: Optional[List[int]] = None          # host mirror of kv_seqlens
         self._decode_meta: Optional[torch.Tensor] = None
         self._ptr_tables = None
+
+    def _alloc(self, B: int, w: int, **kw) -> torch.Tensor:
+        if self.head_major:
+            return torch.empty((B, self.n_kv_heads, w, self.head_dim), **kw).permute(0, 2, 1, 3)
+        return torch.empty((B, w, self.n_kv_heads, self.head_dim), **kw)
+
+    @property
+    def kv_layout(self) -> int:
+        """`_hip.KV_SLOT_MAJOR` / `_hip.KV_HEAD_MAJOR` of every ring (checked: a caller may have replaced tensors)."""
+        if self.n_layers == 0:
+            return _hip.KV_SLOT_MAJOR
+        lay = {_hip.kv_layout_of(t) for d in (self.cache_k, self.cache_v) for i, t in d.items() if self.cache_sizes[i] > 1 and self.n_kv_heads > 1}
+        assert len(lay) <= 1, "K/V rings of one cache in different layouts"
+        return lay.pop() if lay else _hip.KV_SLOT_MAJOR
 
     # ---- reference API ----------------------------------------------------------------------
     def get_view(self, layer_id: int, metadata: CacheInputMetadata) -> CacheView:
@@ -186,9 +208,13 @@ class BufferCache:
         return self.cache_k[0].device
 
     def to(self, device: Union[str, torch.device], dtype: torch.dtype) -> "BufferCache":
+        def move(t: torch.Tensor) -> torch.Tensor:  # (keeps the layout: a head-major ring stays a permuted view of dense storage)
+            if _hip.kv_layout_of(t) == _hip.KV_HEAD_MAJOR:
+                return t.permute(0, 2, 1, 3).to(device=device, dtype=dtype).contiguous().permute(0, 2, 1, 3)
+            return t.to(device=device, dtype=dtype)
         for i in range(self.n_layers):
-            self.cache_k[i] = self.cache_k[i].to(device=device, dtype=dtype)
-            self.cache_v[i] = self.cache_v[i].to(device=device, dtype=dtype)
+            self.cache_k[i] = move(self.cache_k[i])
+            self.cache_v[i] = move(self.cache_v[i])
         self._ptr_tables = None
         self._decode_meta = None
         if self.kv_seqlens is not None:
@@ -265,14 +291,14 @@ class BufferCache:
         self._seen = [p + s for p, s in zip(self._seen, seqlens)]
 
     def pointer_tables(self):
-        """ctypes arrays (host) of the per-layer ring pointers and sizes for mi_batch_t."""
+        """ctypes arrays (host) of the per-layer ring pointers and sizes for mi_batch_t, and the rings' layout code."""
         if self._ptr_tables is None:
             import ctypes as C
             dt = self.cache_k[0].dtype  # (the model checks it against its own storage dtype: HipStackBackend.run_stack)
             ks = _hip.ptr_array([_hip.dev_ptr(self.cache_k[i], dt) for i in range(self.n_layers)])
             vs = _hip.ptr_array([_hip.dev_ptr(self.cache_v[i], dt) for i in range(self.n_layers)])
             ws = (C.c_int32 * self.n_layers)(*self.cache_sizes)
-            self._ptr_tables = (ks, vs, ws)
+            self._ptr_tables = (ks, vs, ws, self.kv_layout)  # (the layout is checked once per table build, not per forward)
         return self._ptr_tables
 
 

@@ -216,7 +216,7 @@ class HipStackBackend:
         if cache is not None:
             if cache.n_layers and cache.cache_k[0].dtype != model.dtype:
                 raise RuntimeError(f"cache dtype {cache.cache_k[0].dtype} != model dtype {model.dtype} (BufferCache.to(device, dtype))")
-            ks, vs, ws = cache.pointer_tables()
+            ks, vs, ws, bt.kv_layout = cache.pointer_tables()
             bt.cache_k, bt.cache_v = C.cast(ks, C.POINTER(C.c_void_p)), C.cast(vs, C.POINTER(C.c_void_p))
             bt.cache_sizes = C.cast(ws, C.POINTER(C.c_int32))
             bt.kv_seqlens = _hip.dev_ptr(cache.kv_seqlens, torch.long)

@@ -78,7 +78,11 @@ def test_unsupported_shapes_fail_loudly_before_any_device_work():
     assert L.mi_forward(C.byref(m), C.byref(bt), None) == -2 and b"MoE" in L.mi_last_error_detail()
     m.num_experts = m.top_k = 0
     assert L.mi_forward(C.byref(m), C.byref(bt), None) == -1     # valid model, empty batch -> MI_ERR_ARG
-    assert L.mi_attn_decode(1, 1, 128, 1, 1, 16, 1, 4, 2, 64, 1, 1, None) == -2   # head_dim 64
+    assert L.mi_attn_decode(1, 1, 128, 1, 1, 16, 1, 4, 2, 64, 1, 1, 0, None) == -2   # head_dim 64
+    assert L.mi_attn_decode(1, 1, 128, 1, 1, 16, 1, 4, 2, 128, 1, 1, 2, None) == -1  # ABI v7: an unknown K/V ring layout code
+    bt.kv_layout = 7
+    assert L.mi_forward(C.byref(m), C.byref(bt), None) == -1
+    bt.kv_layout = 0
 
 
 def test_generic_entry_takes_what_mi_forward_declines():

@@ -261,3 +261,33 @@ def test_pipeline_transport_selection_without_a_gpu_process_group():
     import torch as _torch
     from mistral_inference.distributed import TorchDistComm, pipeline_comm
     assert isinstance(pipeline_comm(_torch.device("cpu")), TorchDistComm)
+
+
+def test_buffer_cache_head_major_storage_keeps_the_reference_shape(monkeypatch):
+    """BufferCache stores its rings head-major ([max_batch, n_kv_heads, W, head_dim]: one kv head's slots contiguous, DESIGN.md
+    section 2) and shows them in the reference's shape (cache.py:163-167): indexing, CacheView.key / .value, interleave_kv,
+    .to() behave as with the reference's layout; MI_KV_LAYOUT=0 allocates that layout; `_hip.kv_layout_of` tells them apart and
+    rejects anything else."""
+    from mistral_inference import _hip
+    from mistral_inference.cache import BufferCache
+    c = BufferCache(2, 3, 10, 4, 8, sliding_window=[6, None], dtype=torch.float32)
+    assert [tuple(c.cache_k[i].shape) for i in range(2)] == [(3, 6, 4, 8), (3, 10, 4, 8)]
+    assert c.kv_layout == _hip.KV_HEAD_MAJOR and not c.cache_k[0].is_contiguous()
+    assert c.cache_k[1].stride() == (4 * 10 * 8, 8, 10 * 8, 1)            # slot stride = head_dim, head stride = W * head_dim
+    c.cache_k[0][1, 5, 2] = torch.arange(8.0)
+    assert torch.equal(c.cache_k[0].permute(0, 2, 1, 3)[1, 2, 5], torch.arange(8.0))   # the same element through the storage's own shape
+    c.init_kvseqlens(2)
+    view = c.get_view(0, None)
+    assert tuple(view.key.shape) == (2, 6, 4, 8) and view.max_seq_len == 6
+    c2 = c.to("cpu", torch.bfloat16)
+    assert c2.kv_layout == _hip.KV_HEAD_MAJOR and c2.cache_k[0].dtype == torch.bfloat16 and float(c2.cache_k[0][1, 5, 2, 3]) == 3.0
+    monkeypatch.setenv("MI_KV_LAYOUT", "0")
+    r = BufferCache(2, 3, 10, 4, 8, sliding_window=[6, None], dtype=torch.float32)
+    assert r.kv_layout == _hip.KV_SLOT_MAJOR and r.cache_k[0].is_contiguous() and tuple(r.cache_k[0].shape) == (3, 6, 4, 8)
+    with pytest.raises(ValueError):
+        _hip.kv_layout_of(torch.zeros(3, 6, 4, 16)[..., ::2])
+    with pytest.raises(AssertionError):
+        r.cache_k[1] = c.cache_k[1]
+        _ = r.kv_layout
+    # shapes whose two layouts coincide (one kv head, or one slot) count as the reference's
+    assert _hip.kv_layout_of(torch.zeros(2, 1, 5, 8).permute(0, 2, 1, 3)) == _hip.KV_SLOT_MAJOR
