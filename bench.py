@@ -117,13 +117,17 @@ def _pmc_traffic(kernel_substr: str, dims_ok: bool):
     return None, None
 
 
-def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
+def engine_roofline(model, cache, nxt, params: dict, iters: int, timed_us: float = None, timed_ctx: int = None, timed_steps: int = 0) -> dict:
     """The dominant kernel of the timed path is the persistent decode engine: ONE `decode_engine_kernel` launch per
     token streams every local layer's weights, the K/V rings and the LM head (and does the step's bookkeeping: position,
     embedding row, greedy sample - there is no other launch in a step).  Algorithmic bytes per launch = SURVEY.md 8(d)'s
-    bytes per token at this context; launch duration = HIP events on the launch stream around `iters` eager decode steps
-    = `iters` back-to-back engine launches, which is what `rocprofv3 --kernel-trace --stats` reports for the kernel
-    (profiles/)."""
+    bytes per token at this context; launch duration = HIP events on the launch stream around the K TIMED steps themselves
+    (`timed_us`, taken in timed_run: the graph-replayed greedy steps whose wall time is `ms_per_step`) - what
+    `rocprofv3 --kernel-trace --stats` reports for the kernel in that loop (profiles/).  Two eager loops of `iters` steps are
+    timed beside it to say where the difference to round 5's figure (an eager `forward()` loop) goes: `forward()` launches
+    carry no sample (no logits stash, no 256 -> 1 gather of the workgroups' (max, argmax, sum-exp) behind the LM head - the
+    kernel ends when workgroup 0 has finished that hop) and re-read one token id; the eager greedy session isolates that
+    epilogue from the cost of replaying a one-kernel hipGraph per step."""
     dev = model.device
     stream = torch.cuda.current_stream(dev)
     for _ in range(2):
@@ -136,8 +140,18 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
         model.forward(ids, [1], cache)   # same token id every step: no argmax kernel between the launches
     e1.record(stream)
     e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    bytes_per_launch = decode_bytes_per_token(params, ctx0 + iters // 2)
+    fwd_us = e0.elapsed_time(e1) * 1e3 / iters
+    sess = model.greedy_session(cache, ids, graph=False)  # the same steps as the timed loop, launched eagerly
+    sess.run(2)
+    e0.record(stream)
+    sess.run(iters)
+    e1.record(stream)
+    e1.synchronize()
+    sess.collect()
+    greedy_eager_us = e0.elapsed_time(e1) * 1e3 / iters
+    del sess
+    us, ctx_mid, n_timed = (timed_us, timed_ctx, timed_steps) if timed_us else (fwd_us, ctx0 + iters // 2, iters)
+    bytes_per_launch = decode_bytes_per_token(params, ctx_mid)
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
     dims_ok = ((model.args.dim, model.args.hidden_dim, model.args.n_layers) == (MISTRAL_7B["dim"], MISTRAL_7B["hidden_dim"], MISTRAL_7B["n_layers"])
                and not params.get("moe"))
@@ -146,7 +160,13 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int) -> dict:
     return {"bound": "hbm", "kernel": f"decode_engine_kernel<{group}> (persistent: all layers + LM head + sample of one decode step in one launch)",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_static": True, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch,
-            "avg_launch_us": round(us, 2), "launches_timed": iters}
+            "avg_launch_us": round(us, 2), "launches_timed": n_timed,
+            "timing": ("HIP events on the launch stream around the timed, graph-replayed greedy steps (one kernel per step)" if timed_us
+                       else "HIP events around an eager forward() loop"),
+            "other_loops_us": {"eager_forward_no_sample": round(fwd_us, 2), "eager_greedy_session": round(greedy_eager_us, 2),
+                               "iters": iters,
+                               "reading": "greedy - forward = the fused sample's hop behind the LM head; timed - eager greedy = "
+                                          "replaying a one-kernel hipGraph per step instead of queued plain launches"}}
 
 
 def dominant_kernel_roofline(model, iters: int) -> dict:
@@ -318,26 +338,35 @@ def port_baseline(params: dict, ctx: int, steps: int = 6) -> dict:
                       f"({per_layer * 1e3:.1f} ms/layer, {t_head * 1e3:.1f} ms head)"}
 
 
-def sub_measurement(model_key: str, prefill: int, steps: int, warmup: int, timeout_s: int = 900) -> dict:
+def sub_measurement(model_key: str, prefill: int, steps: int, warmup: int, timeout_s: int = 420, extra=()) -> dict:
     """Another BASELINE config measured by THIS script in a subprocess of its own (its own weights, its own timing bracket;
-    a crash or a time-out there costs the sub-object, never the headline line).  Returns the fields a reader needs."""
+    a crash, a time-out or an unexpected line there costs the sub-object, never the headline line).  Returns the fields a
+    reader needs.  `extra`: further command-line flags (`--layers 7`: one pipeline stage; `--batch 3`: the mistral-demo shape)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--model", model_key, "--prefill", str(prefill), "--steps", str(steps),
-           "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras"]
+           "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras", *extra]
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
         d = json.loads(r.stdout.strip().splitlines()[-1])
-    except Exception as e:  # noqa: BLE001  (reported, never hidden)
-        return {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-    rf = d.get("roofline", {})
-    return {"workload": d["config"]["workload"], "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-            "warmup": d["warmup"], "context_at_timing": d["config"]["context_at_timing"],
-            "bytes_per_token": d["hbm_roofline_step"]["bytes_per_token"], "hbm_roofline_frac": d["hbm_roofline_step"]["frac"],
-            "decode_launch": d["config"]["decode_launch"],
-            "dominant_kernel": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")},
-            "prefill_tokens": d["prefill"]["tokens"], "prefill_tokens_per_s": d["prefill"]["tokens_per_s"],
-            "prefill_mfma_frac": d["prefill"]["mfma_frac"], "wall_s": round(time.perf_counter() - t0, 1)}
+        rf = d.get("roofline", {})
+        out = {"workload": d["config"]["workload"], "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+               "warmup": d["warmup"], "context_at_timing": d["config"]["context_at_timing"],
+               "hbm_roofline_frac": d["hbm_roofline_step"]["frac"], "decode_launch": d["config"]["decode_launch"]}
+        if "bytes_per_token" in d["hbm_roofline_step"]:
+            out["bytes_per_token"] = d["hbm_roofline_step"]["bytes_per_token"]
+        else:  # --batch B: weights once + B ring windows per step
+            out["bytes_per_step"] = d["hbm_roofline_step"]["bytes_per_step"]
+            out["per_sequence_tokens_per_s"] = d.get("per_sequence_tokens_per_s")
+        if rf:
+            out["dominant_kernel"] = {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us")}
+        if "prefill" in d:
+            out.update(prefill_tokens=d["prefill"]["tokens"], prefill_tokens_per_s=d["prefill"]["tokens_per_s"],
+                       prefill_mfma_frac=d["prefill"]["mfma_frac"])
+        out["wall_s"] = round(time.perf_counter() - t0, 1)
+        return out
+    except Exception as e:  # noqa: BLE001  (reported, never hidden: a missing key is a failure of the sub-object only)
+        return {"error": f"{type(e).__name__}: {str(e)[:300]}", "wall_s": round(time.perf_counter() - t0, 1)}
 
 
 def parity_in_this_run() -> dict:
@@ -394,19 +423,25 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
                 sess.collect()
             sess.run(2)
             sync()
-            dt, left, collect_s = 0.0, K, 0.0
+            dt, left, collect_s, ev_ms = 0.0, K, 0.0, 0.0
+            stream = torch.cuda.current_stream(dev)  # (the stream mi_forward launches on and the captured step is replayed on)
             while left > 0:                      # (the session's history ring holds 1024 steps between collects)
                 n = min(left, sess.HIST - sess._pending)  # (the two warm-up steps above are still uncollected)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0 = time.perf_counter()
-                sess.run(n)
+                e0.record(stream)                # HIP events on the launch stream around the SAME steps the wall clock brackets:
+                sess.run(n)                      # on the persistent engine a step is one kernel, so this is the dominant kernel's
+                e1.record(stream)                # launch-to-launch time inside the timed loop (roofline.avg_launch_us)
                 sync()
                 t1 = time.perf_counter()
                 dt += t1 - t0
+                ev_ms += e0.elapsed_time(e1)
                 toks, _ = sess.collect()         # verifies that the device completed every step (and which path ran)
                 collect_s += time.perf_counter() - t1   # generate() pays this once per chunk (32 steps with an eos_id, else 1024)
                 left -= n
             nxt = toks[-1]
             timed_run.collect_s = collect_s
+            timed_run.event_us_per_step = ev_ms * 1e3 / K
         else:
             # the sampling loop's body (temperature > 0, or pipeline stages): forward() under the decode hipGraph + torch.argmax
             ctx = contextlib.nullcontext() if opt.no_graph else model.graphed_decode(cache)
@@ -597,7 +632,9 @@ def main() -> None:
             print(f"[bench] rank {rank}: interleaved measurement failed ({type(e).__name__}: {e}); reporting the single-stream relay only",
                   file=sys.stderr, flush=True)
             ok = 0
-        # every rank learns whether ALL ranks finished: a rank that raised alone must not leave the others with a number
+        # every rank learns whether ALL ranks finished.  This covers failures that every rank sees (a shape the throughput mode
+        # declines, an allocation that fails everywhere); a rank that raises ALONE inside interleaved_run leaves its peers in
+        # that function's collectives, and the job ends with the process group's time-out, not with a fallback line
         flag = torch.tensor([ok], device=dev, dtype=torch.int32)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if int(flag.item()) == 0:
@@ -668,7 +705,8 @@ def main() -> None:
         # the dominant kernel is timed on this rank's own layers (any N)
         if engine["engine_launches"] > 0 and world == 1:
             with torch.inference_mode():
-                out["roofline"] = engine_roofline(model, cache, nxt, params, iters=24)
+                ev = getattr(timed_run, "event_us_per_step", None) if opt.loop == "greedy" else None
+                out["roofline"] = engine_roofline(model, cache, nxt, params, iters=24, timed_us=ev, timed_ctx=ctx_len, timed_steps=K)
             if not params.get("moe"):
                 out["launch_path_gemv_w13"] = dominant_kernel_roofline(model, iters=2)
         elif not params.get("moe"):
@@ -693,13 +731,24 @@ def main() -> None:
         if out is not None:
             out["roofline_per_rank"] = per_rank
     if world == 1 and opt.model == "mistral-7b" and not opt.layers and not opt.no_extras:
-        # the other BASELINE configs and parity, in the one line the driver records (the headline fields above are final)
+        # the other BASELINE configs and parity, in the one line the driver records (the headline fields above are final -
+        # they go to stderr right away, so that a time-out or a crash in an extra cannot lose a measured headline)
+        print("[bench] headline measured (sub-objects follow): " + json.dumps(out), file=sys.stderr, flush=True)
         del model, cache, nxt
         torch.cuda.empty_cache()
         out["parity"] = parity_in_this_run()
+        if isinstance(out["parity"], dict):
+            out["parity"]["scope"] = ("BASELINE configs[0] only (2 layers, 48 tokens), in this process; depth parity of configs[1]-[4] "
+                                      "(32 layers vs the bf16 AND fp32 oracle, Nemo x 4 layers, Mixtral-8x7B x 4, 8x22B x 3) is "
+                                      "`pytest -m gpu` (tests/test_gpu_depth.py), not this object")
         torch.cuda.empty_cache()
         out["nemo"] = sub_measurement("nemo-12b", 8192, K, Wm)
         out["mixtral"] = sub_measurement("mixtral-8x7b", T0, K, Wm)
+        # BASELINE configs[4]: what EACH of the 8 pipeline stages of Mixtral-8x22B runs (7 of 56 layers, 35 GB; the last stage
+        # adds the LM head, which this stage measurement carries) - the per-GPU number of the 8-stage deployment
+        out["x22b_stage"] = sub_measurement("mixtral-8x22b", T0, K, Wm, extra=("--layers", "7"))
+        # the mistral-demo shape: three prompts decoded together (reference main.py:124,220), launch path
+        out["batch3"] = sub_measurement("mistral-7b", T0, max(K, 32), Wm, extra=("--batch", "3"))
     if world > 1 and not opt.no_mixtral and opt.model == "mistral-7b" and (not opt.layers or opt.mixtral_layers):
         # north_star: "Mixtral-8x7B pipeline-parallel tokens/sec reported at 1/2/4/8 GPUs" (BASELINE configs[3], and
         # configs[4] - Mixtral-8x22B over 8 stages - where 8 GPUs are present).  The N = 1 headline line is untouched; a

@@ -30,8 +30,9 @@ PER_FILE_FLAGS = {"decode_engine.hip": os.environ.get("MI_ENGINE_FLAGS", "-mllvm
 # scripts/build_variants.py engine_slots / scripts/engine_ab.py (profiles/EXPERIMENTS.md round 5)
 # (abort word read every 1024th spin; consumers at s_setprio 1; holders fetch from the K/V stage on; the loader's weight DMAs from
 #  inline asm in the SGPR-base form - which is what makes the build WITHOUT the debug stamp sites as fast as the one with them)
+# round 6: + the loader is not stopped during the hid sweep (ENG_NOSTOP=32: the ring is empty there; +0.1..0.7 % on six boxes)
 ENGINE_NEXT_FLAGS = ["-DENG_SUFFIX=_next", "-DENG_HEADLINE_ONLY=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1", "-DENG_HOLD_STAGE=2",
-                     "-DENG_SADDR=2", "-DENG_TRACE=0"]
+                     "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"]
 VARIANT_OBJECTS = {"decode_engine_next.o": ("decode_engine.hip", ENGINE_NEXT_FLAGS),
                    # (the wide build also takes the two round-5 switches: +0.7 % on the 8x22B stage; the 8-fill MoE build does NOT -
                    #  the same two switches make Mixtral-8x7B 4.5 % slower, profiles/EXPERIMENTS.md round 5; and the q|k|v holder

@@ -455,7 +455,12 @@ struct Loader {
   // (checked in the ISA) and is nevertheless 20-30 us per step slower than the builtin form (profiles/EXPERIMENTS.md).
   template <int N>
   __device__ __forceinline__ void dma_n(const void* src_lane, lchar* dst) {
-#if ENG_ASM_DMA || ENG_SADDR == 3  // (SADDR = 3, experiment: the K/V pieces - per-lane row addresses - from inline asm as well; +0.7 %)
+#if ENG_ASM_DMA || ENG_SADDR >= 2
+    // ENG_SADDR >= 2: NO builtin LDS-DMA is left in the loader.  The pieces that still carry per-lane addresses - K/V pieces of
+    // rings in the reference's layout and of splits that are not whole 16-slot groups (kv_runs) - are rare at the shapes this
+    // build serves, but as builtins they are what hipcc's wait-count pass tracks: it guards every LDS read and every rewrite
+    // of an address register that MAY follow one with `s_waitcnt vmcnt(0)`, e.g. in fill_begin - a drain of the DMA queue per
+    // fill, +30 % per step (scripts/engine_loader_waits.py finds such waits statically; tests/test_engine_build.py).
     unsigned keep;
     const uint32_t lds_addr = (uint32_t)reinterpret_cast<size_t>(dst);
     if constexpr (N == 1)
@@ -494,7 +499,18 @@ struct Loader {
   }
   __device__ __forceinline__ void piece_s(const char* sbase) {
     if ((g & (FILL - 1)) == 0) fill_begin();
+#if ENG_SADDR >= 2
+    unsigned keep;
+    const uint32_t lds_addr = (uint32_t)reinterpret_cast<size_t>(slot_of(g));
+    const unsigned long long b = reinterpret_cast<unsigned long long>(sbase);
+    const unsigned long long bu = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane16), "s"(bu), "s"(lds_addr) : "memory");
+#else
     dma_s<0>(sbase, slot_of(g));
+#endif
     ++g;
     if ((g & (FILL - 1)) == 0) fill_end();
   }

@@ -170,10 +170,20 @@ def generate(
                     gen_lp.append(lps[j])
                 need -= n
         max_tokens = 0  # the loop below is done
+    # Unfused loop under pipeline parallelism at temperature > 0: every stage samples the same broadcast logits and must draw
+    # the same variate whatever state its own CPU generator is in.  ONE seed per generation, agreed here - where the model and
+    # its pipeline communicator are known - over `model.pp_comm`; step i then uses (seed, offset i).  `sample()` itself issues
+    # no collective: a data-parallel job, or ranks that generate different things, never meet in it (the reference's sample()
+    # has none either, generate.py:151-159).
+    pp_seed: Optional[int] = None
+    if max_tokens > 0 and temperature > 0 and getattr(model, "num_pipeline_ranks", 1) > 1 and hasattr(model, "pp_comm"):
+        seed_t = torch.randint(0, 2 ** 62, (1,)).to(dev)
+        model.pp_comm.broadcast(seed_t, src=0)
+        pp_seed = int(seed_t.item())
     graphed = model.graphed_decode(cache) if hasattr(model, "graphed_decode") else contextlib.nullcontext()
     with graphed:  # decode steps replay a captured hipGraph (single rank; no-op otherwise)
-        for _ in range(max_tokens):
-            next_token = sample(last_token_prelogits, temperature=temperature, top_p=0.8)
+        for step in range(max_tokens):
+            next_token = sample(last_token_prelogits, temperature=temperature, top_p=0.8, seed=pp_seed, offset=step)
             if eos_id is not None:
                 is_finished = is_finished | (next_token == eos_id)
                 if bool(is_finished.all()):  # the one remaining per-token sync, only with an eos_id
@@ -211,22 +221,20 @@ def generate(
     return generated_tokens, logprobs
 
 
-def sample(logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
+def sample(logits: torch.Tensor, temperature: float, top_p: float, seed: Optional[int] = None, offset: int = 0) -> torch.Tensor:
     """Greedy for temperature 0, else nucleus sampling (reference generate.py:151-159).  fp32 logits on a HIP device: ONE
-    native launch (mi_sample_top_p: no sort of the vocabulary, no host sync), seeded from torch's default generator."""
+    native launch (mi_sample_top_p: no sort of the vocabulary, no host sync).
+
+    Seeding contract: `seed=None` draws one 62-bit seed per call from torch's DEFAULT (CPU) generator, i.e. `torch.manual_seed`
+    makes a generation reproducible; a seeded CUDA generator (what the reference's torch.multinomial consumes) does not enter.
+    A caller that needs several ranks to draw the same token (pipeline stages sampling the same broadcast logits) agrees on a
+    seed itself and passes it with a per-step `offset` - `generate()` does, over the model's pipeline communicator; this
+    function never communicates."""
     if temperature > 0 and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2:
         from . import _hip
-        # Seeding contract: one 62-bit seed per call from torch's DEFAULT (CPU) generator, i.e. `torch.manual_seed` makes a
-        # generation reproducible; a seeded CUDA generator (what the reference's torch.multinomial consumes) does not enter.
-        seed = torch.randint(0, 2 ** 62, (1,))
-        dist = torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # pipeline ranks sample the same broadcast logits: they must draw the same variate whatever state their own CPU
-            # generators are in - rank 0's seed for everybody (the fused session does the same once per generation)
-            box = seed.to(logits.device) if dist.get_backend() == "nccl" else seed
-            dist.broadcast(box, src=0)
-            seed = box.cpu()
-        tok, _ = _hip.sample_top_p(logits.contiguous(), temperature, top_p, seed=int(seed.item()))
+        if seed is None:
+            seed, offset = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+        tok, _ = _hip.sample_top_p(logits.contiguous(), temperature, top_p, seed=seed, offset=offset)
         return tok.reshape(-1)
     if temperature > 0:
         probs = torch.softmax(logits / temperature, dim=-1)

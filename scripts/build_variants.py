@@ -114,51 +114,12 @@ ENGINE_SLOTS = {
     "ns_hid": _NS + ("-DENG_NOSTOP=32",),
     "nst_hid_stage3": _AP + ("-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
     "nst_hid_hold4": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=32", "-DENG_SLP_HOLD=4"),
-    # round 6: the K/V phase of the loader (ENG_KVX bits: 1 asm SGPR-base K/V pieces, 2 piece-granular publication, 4 consumers take
-    # K/V pieces as they land, 8 fine publication through the first Wo pieces)
-    "ce": _N0 + _CE,                                                # the shipped flags + a modelled wait at the loader's entry
+    # round 6 (the K/V-phase experiments of this round - asm K/V pieces, fine / tight publication, a reordered stream - are kept as
+    # scripts/probes/decode_engine_round6_kv_experiments.patch; what shipped is the head-major ring layout)
+    "ce": _N0 + _CE,                                                # + a modelled wait at the loader's entry
     "ce_hid": _N0 + _CE + ("-DENG_NOSTOP=32",),
-    "t1": _N0 + ("-DENG_TIGHT=1",),                                 # one fill in flight for two fill ends behind the q|k|v rows
-    "t3": _N0 + ("-DENG_TIGHT=3",),                                 # ... and behind the K/V pieces
-    "t1_hid": _N0 + ("-DENG_TIGHT=1", "-DENG_NOSTOP=32"),
-    "t3_hid": _N0 + ("-DENG_TIGHT=3", "-DENG_NOSTOP=32"),
-    "t1_kv4_hid": _N0 + ("-DENG_TIGHT=1", "-DENG_KVX=4", "-DENG_NOSTOP=32"),
-    "t3_kv4_hid": _N0 + ("-DENG_TIGHT=3", "-DENG_KVX=4", "-DENG_NOSTOP=32"),
-    "ce_t1_hid": _N0 + _CE + ("-DENG_TIGHT=1", "-DENG_NOSTOP=32"),
-    "ce_t3_kv5_hid": _N0 + _CE + ("-DENG_TIGHT=3", "-DENG_KVX=5", "-DENG_NOSTOP=32"),
-    "ns_t1": _NS + ("-DENG_TIGHT=1",),
-    "ns_t3_kv4_hid": _NS + ("-DENG_TIGHT=3", "-DENG_KVX=4", "-DENG_NOSTOP=32"),
-    "r64": _N0 + ("-DENG_KVX=64",),                                 # K/V pieces streamed before each wave's last q|k|v unit
-    "r64_hid": _N0 + ("-DENG_KVX=64", "-DENG_NOSTOP=32"),
-    "r64_hid_q": _N0 + ("-DENG_KVX=64", "-DENG_NOSTOP=34"),
-    "r64_hid_s1": _AP + ("-DENG_HOLD_STAGE=1", "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_KVX=64", "-DENG_NOSTOP=32"),
-    "r64_hid_s3": _AP + ("-DENG_HOLD_STAGE=3", "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_KVX=64", "-DENG_NOSTOP=32"),
-    "ce_r64_hid": _N0 + _CE + ("-DENG_KVX=64", "-DENG_NOSTOP=32"),
-    "ce_r65_hid": _N0 + _CE + ("-DENG_KVX=65", "-DENG_NOSTOP=32"),
-    "ns_r64": _NS + ("-DENG_KVX=64",),
-    "ns_r64_hid": _NS + ("-DENG_KVX=64", "-DENG_NOSTOP=32"),
-    "kv_run4": _N0 + _CE + ("-DENG_KVX=257",),                      # timing ablation, WRONG results: K/V as 4-KiB runs (4 K pieces, 4 V pieces)
-    "kv_run4_hid": _N0 + _CE + ("-DENG_KVX=257", "-DENG_NOSTOP=32"),
-    "ns_kv_run4": _NS + _CE + ("-DENG_KVX=257",),
-    "kv1": _N0 + _CE + ("-DENG_KVX=1",),
-    "kv3": _N0 + _CE + ("-DENG_KVX=3",),
-    "kv5": _N0 + _CE + ("-DENG_KVX=5",),
-    "kv6": _N0 + _CE + ("-DENG_KVX=6",),
-    "kv7": _N0 + _CE + ("-DENG_KVX=7",),
-    "kv15": _N0 + _CE + ("-DENG_KVX=15",),
-    "kv7_hid": _N0 + _CE + ("-DENG_KVX=7", "-DENG_NOSTOP=32"),
-    "kv15_hid": _N0 + _CE + ("-DENG_KVX=15", "-DENG_NOSTOP=32"),
-    "kv7_q": _N0 + _CE + ("-DENG_KVX=7", "-DENG_NOSTOP=2"),
-    "kv7_hid_q": _N0 + _CE + ("-DENG_KVX=7", "-DENG_NOSTOP=34"),
-    "kv15_hid_q": _N0 + _CE + ("-DENG_KVX=15", "-DENG_NOSTOP=34"),
-    "kv7_stage1": _AP + _CE + ("-DENG_HOLD_STAGE=1", "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_KVX=7"),
-    "kv7_contig": _N0 + _CE + ("-DENG_KVX=23",),                    # timing ablation, WRONG results: K/V pieces as contiguous 1-KiB runs
-    "kv7_nont": _N0 + _CE + ("-DENG_KVX=39",),                      # K/V pieces with the default cache policy
     "ns_ce": _NS + _CE,                                             # (with the stamp sites: timelines)
-    "ns_kv7": _NS + _CE + ("-DENG_KVX=7",),
-    "ns_kv7_contig": _NS + _CE + ("-DENG_KVX=23",),
-    "ns_kv7_nont": _NS + _CE + ("-DENG_KVX=39",),
-    "ns_kv15_hid": _NS + _CE + ("-DENG_KVX=15", "-DENG_NOSTOP=32"),
+    "ns_hid": _NS + ("-DENG_NOSTOP=32",),
 }
 
 

@@ -1,5 +1,6 @@
 """bench.py's algorithmic byte / flop accounting against the figures of SURVEY.md section 8(d) (the numbers the roofline
 fractions are computed from)."""
+import json
 import os
 import sys
 
@@ -81,7 +82,28 @@ def test_sub_measurement_reports_an_error_instead_of_raising(monkeypatch):
         stdout, returncode = "not json\n", 1
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
     out = bench.sub_measurement("nemo-12b", 8192, 4, 2)
-    assert set(out) == {"error"}
+    assert set(out) == {"error", "wall_s"}
+
+    # a child that prints a JSON line with other keys than expected is an error of the sub-object too, not a
+    # KeyError in the parent (the field extraction sits inside the same try)
+    class R2:
+        stdout, returncode = json.dumps({"value": 1.0, "config": {}}) + "\n", 0
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R2())
+    out = bench.sub_measurement("nemo-12b", 8192, 4, 2)
+    assert "KeyError" in out["error"]
+
+    # a well-formed child line (batch form: bytes per STEP, no prefill object) is reduced to the sub-object's fields
+    class R3:
+        stdout, returncode = json.dumps({"value": 800.0, "ms_per_step": 3.7, "steps": 32, "warmup": 2, "per_sequence_tokens_per_s": 266.7,
+                                         "config": {"workload": "w", "context_at_timing": 4100, "decode_launch": "launch path"},
+                                         "hbm_roofline_step": {"frac": 0.52, "bytes_per_step": 123}}) + "\n", 0
+    seen = {}
+    def run3(cmd, **k):
+        seen["cmd"] = cmd
+        return R3()
+    monkeypatch.setattr(subprocess, "run", run3)
+    out = bench.sub_measurement("mistral-7b", 4096, 32, 2, extra=("--batch", "3"))
+    assert out["tokens_per_s"] == 800.0 and out["bytes_per_step"] == 123 and "error" not in out and seen["cmd"][-2:] == ["--batch", "3"]
 
     def boom(*a, **k):
         raise subprocess.TimeoutExpired("bench.py", 1)

@@ -291,3 +291,23 @@ def test_buffer_cache_head_major_storage_keeps_the_reference_shape(monkeypatch):
         _ = r.kv_layout
     # shapes whose two layouts coincide (one kv head, or one slot) count as the reference's
     assert _hip.kv_layout_of(torch.zeros(2, 1, 5, 8).permute(0, 2, 1, 3)) == _hip.KV_SLOT_MAJOR
+
+
+def test_sample_never_communicates_and_takes_an_agreed_seed():
+    """`sample()` must not issue a collective (the reference's has none, generate.py:151-159) - ranks of a
+    data-parallel job, or ranks that call it a different number of times, would hang or couple their seeds.  The pipeline's seed
+    agreement lives in generate(), over the model's own communicator; sample() only accepts the agreed (seed, offset)."""
+    import inspect
+    from mistral_inference import generate as G
+    src = inspect.getsource(G.sample)
+    assert "torch.distributed" not in src and ".broadcast(" not in src and "all_reduce" not in src and "dist." not in src
+    assert {"seed", "offset"} <= set(inspect.signature(G.sample).parameters)
+    gsrc = inspect.getsource(G.generate)
+    assert "model.pp_comm.broadcast" in gsrc and "num_pipeline_ranks" in gsrc
+    # greedy and the torch path keep the reference's behaviour on CPU
+    logits = torch.tensor([[0.1, 2.0, -1.0], [3.0, 0.0, 0.5]])
+    assert G.sample(logits, temperature=0.0, top_p=0.8).tolist() == [1, 0]
+    torch.manual_seed(0)
+    a = G.sample(logits, temperature=0.7, top_p=0.8)
+    torch.manual_seed(0)
+    assert torch.equal(a, G.sample(logits, temperature=0.7, top_p=0.8, seed=123, offset=4))  # (CPU path: torch's own generator)
