@@ -715,7 +715,9 @@ def main() -> None:
             out["roofline"] = {"bound": "hbm", "kernel": "decode step (launch path: router + expert GEMVs)", "achieved": round(step_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                "bytes_per_launch": step_bytes}
-        if world == 1 and not opt.no_cpu_baseline:
+        if not opt.no_cpu_baseline:
+            # rank 0 only, at every N (the other ranks wait at the barrier below): the reference's own CPU path on this box's
+            # host cores for the headline model - the whole model, whatever the number of stages the GPUs split it into
             out["cpu_baseline"] = cpu_baseline(params, T0)
         return out
 

@@ -181,6 +181,12 @@ class HipStackBackend:
             _hip.set_decode_engine(True)
         self._get_workspace(model, self.plan(model), B, B, max(cache.cache_sizes))  # (a decode step has T == B rows)
 
+    def session_rewind(self, steps: int) -> None:
+        """Set the workspace's decode-step counter (status word 5: the row of the greedy history ring and the Philox offset of the
+        NEXT step) - GreedySession's lock-step rollback re-runs steps whose samples must land where the first attempt's would."""
+        assert self._workspace is not None
+        self._workspace[20:24].view(torch.int32).fill_(int(steps) & 0x7FFFFFFF)
+
     def session_disable_engine(self) -> None:
         """After a raised engine status: clear the word (it poisons the workspace) and take the launch path for the rest of this
         generation; the next session probes the device again (prepare_session)."""
@@ -721,6 +727,7 @@ class GreedySession:
         self._base: Optional[int] = None   # value of the workspace's step counter when this session began
         self._pending = 0                  # steps enqueued and not yet collected
         self._n_collected = 0
+        self._first = self.buf.tok.clone()  # input of the session's step 0 (a rollback to step 0 needs it again)
 
     # -- one step, enqueued launch by launch
     def _step_eager(self) -> None:
@@ -823,16 +830,29 @@ class GreedySession:
         done_total = st["steps"] - self._base      # steps the device completed since the session began
         issued_total = self._issued()
         status = st["status"]
+        good_total = done_total
         if self.world > 1 and torch.distributed.is_initialized():
-            # a stage that stops while its neighbours wait in a hop would hang the job: everybody learns the worst status
-            flag = torch.tensor([status], device=m.device, dtype=torch.int64)
+            # a stage that stops while its neighbours wait in a hop would hang the job: everybody learns the worst status, whether
+            # any stage failed in another way than its residency gate, and the FEWEST steps any stage completed
+            flag = torch.tensor([status, status if status != 0x700 else 0, -done_total], device=m.device, dtype=torch.int64)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            worst = int(flag.item())
-            if worst != 0:
+            worst, other, good_total = int(flag[0].item()), int(flag[1].item()), -int(flag[2].item())
+            if other != 0:
                 be.session_disable_engine()
                 self._graphs, self._use_graph = {}, False
-                raise RuntimeError(f"persistent decode engine: status 0x{worst:x} on a pipeline stage; this generation is lost, "
+                raise RuntimeError(f"persistent decode engine: status 0x{other:x} on a pipeline stage; this generation is lost, "
                                    "the engine is now off for this process and later calls take the launch path")
+            if worst == 0x700:
+                # LOCK-STEP ROLLBACK.  A stage whose engine launch failed its residency gate wrote nothing from that step on
+                # (status 0x700, include/mistral_hip.h) and kept forwarding its stale activations; the other stages ran ahead
+                # on them.  Every stage knows from the reduction above how many steps completed EVERYWHERE: all stages rewind
+                # to that step - positions, step counter, the input id of stage 0 - and run the rest again on the launch
+                # path, hop by hop.  The steps that ran ahead only wrote ring slots (pos % W) of positions that are run again,
+                # and those slots are rewritten with the right rows before anything reads them.
+                logging.warning("persistent decode engine: residency gate failed on a pipeline stage after %d of %d steps; every "
+                                "stage re-runs the rest on the launch path", good_total, issued_total)
+                self._rollback(good_total)
+                status, done_total = 0, issued_total
         if status != 0:
             missing = issued_total - done_total
             if status != 0x700:
@@ -872,6 +892,31 @@ class GreedySession:
 
     def _issued(self) -> int:
         return self._n_collected + self._pending
+
+    def _rollback(self, good_total: int) -> None:
+        """Pipeline stages, after a residency failure somewhere: rewind THIS stage to the state after `good_total` steps of the
+        session (the number every stage completed) and run the remaining issued steps again on the launch path."""
+        m, cache, be = self.model, self.cache, self.model._backend
+        redo = self._issued() - good_total
+        assert redo > 0 and self._base is not None
+        be.session_disable_engine()                # clears the status word; this process takes the launch path from here on
+        self._graphs = {}                          # (they hold engine launches)
+        cache._seen = [p - redo for p in cache._seen]
+        assert cache.kv_seqlens is not None
+        cache.kv_seqlens.copy_(torch.tensor(cache._seen, dtype=torch.long))   # (stages that ran ahead advanced theirs)
+        be.session_rewind(self._base + good_total)  # history-ring row / Philox offset of the next step
+        # stage 0's next input id: the sample of step good_total - 1 (the last stage's history holds it), or the session's first
+        tok = self._first.clone() if good_total == 0 else self.buf.hist_tok[(self._base + good_total - 1) % self.HIST].clone()
+        if good_total > 0:
+            m.pp_comm.broadcast(tok, src=self.world - 1)
+        self.buf.tok.copy_(tok)
+        for _ in range(redo):
+            self._step_eager()
+            cache.advance_host([1] * self.B)
+        if m.device.type == "cuda":
+            torch.cuda.synchronize(m.device)
+        if be.session_status()["status"] != 0:
+            raise RuntimeError("decode steps failed again on the launch path after a pipeline rollback")
 
     def _recover(self, missing: int) -> None:
         """The device state is that of the first failed step (nothing was written since): clear the status, switch

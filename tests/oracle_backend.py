@@ -11,23 +11,33 @@ import mistral_oracle as mo
 class OracleStackBackend:
     HIST_BRANCH_DECODE = 2  # mi_branch MI_BRANCH_DECODE
 
-    def __init__(self):
+    def __init__(self, fail_from_step=None):
         self.steps = 0  # decode-branch calls so far: the workspace's step counter of the HIP backend (status word 5)
+        # sabotage (tests): from decode step `fail_from_step` on this stage behaves like an engine launch that failed its
+        # residency gate - it writes NOTHING (no activations, no ring row, no sample, no counter) and raises status 0x700
+        self.fail_from_step = fail_from_step
+        self.status = 0
 
     def invalidate(self):
         pass
 
     # -- the three hooks GreedySession needs from a backend (HipStackBackend: the workspace's control words)
     def session_status(self):
-        return {"steps": self.steps, "status": 0, "arrivals": 0, "engine_launches": 0}
+        return {"steps": self.steps, "status": self.status, "arrivals": 0, "engine_launches": 0}
+
+    def session_rewind(self, steps):
+        self.steps = steps
 
     def prepare_session(self, model, B, cache):
         pass
 
     def session_disable_engine(self):
-        pass
+        self.status, self.fail_from_step = 0, None
 
     def run_stack(self, model, h, input_ids, meta, cache, logits, greedy=None):
+        if meta.branch == self.HIST_BRANCH_DECODE and (self.status != 0 or (self.fail_from_step is not None and self.steps >= self.fail_from_step)):
+            self.status = 0x700   # (sticky: every later "launch" on this workspace leaves at once)
+            return
         a = model.args
         oargs = mo.OracleArgs(dim=a.dim, n_layers=a.n_layers, head_dim=a.head_dim, hidden_dim=a.hidden_dim,
                               n_heads=a.n_heads, n_kv_heads=a.n_kv_heads, norm_eps=a.norm_eps, vocab_size=a.vocab_size,

@@ -124,7 +124,9 @@ def test_bench_two_ranks_prints_one_json_line():
     assert pt["sequences_in_flight"] == 2 and pt["scaling"] == "weak" and pt["tokens_per_s"] > 0 and pt["tick_host_us"] > 0
     assert abs(pt["tokens_per_s_per_gpu"] * 2 - pt["tokens_per_s"]) < 0.02
     assert d["distributed"] == {"backend": "gloo", "world_size": 2, "transport": "TorchDistComm", "rccl_comm_ranks": None}
-    assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
+    assert d["roofline"]["bound"] == "hbm"
+    cb = d["cpu_baseline"]   # round 6: computed by rank 0 at every N (the whole headline model on the host cores)
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
     per_rank = d["roofline_per_rank"]
     assert [r["rank"] for r in per_rank] == [0, 1] and [r["lm_head"] for r in per_rank] == [False, True]
     assert all(0 < r["frac"] < 1 and r["layers"] == 2 for r in per_rank)

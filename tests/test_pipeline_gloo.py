@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, q, session=False):
+def _worker(rank, world, port, name, q, session=False, sabotage=None):
     for p in (os.path.join(ROOT, "mistral-inference_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -36,7 +36,9 @@ def _worker(rank, world, port, name, q, session=False):
             class SessionOnCpu(Transformer):
                 greedy_session_any_device = True
             cls = SessionOnCpu
-        m = cls(a, pipeline_rank=rank, num_pipeline_ranks=world, backend=OracleStackBackend())
+        # sabotage = (stage, decode step): that stage's "engine" fails its residency gate from that step on (writes nothing, 0x700)
+        fail = sabotage[1] if sabotage is not None and sabotage[0] == rank else None
+        m = cls(a, pipeline_rank=rank, num_pipeline_ranks=world, backend=OracleStackBackend(fail_from_step=fail))
         m.load_state_dict(case.weights(), assign=True)
         if session:
             comm = m.pp_comm
@@ -55,7 +57,7 @@ def _worker(rank, world, port, name, q, session=False):
             m._pp_comm = Recorder()
         prompts = case.prompts if rank == 0 else [[0] * len(p) for p in case.prompts]  # reference main.py:169-170
         toks, lps = generate(prompts, m, max_tokens=case.max_tokens, temperature=0.0, chunk_size=case.chunk_size)
-        q.put((rank, toks, lps, m.n_local_layers) + ((traffic,) if session else ()))
+        q.put((rank, toks, lps, m.n_local_layers) + ((traffic,) if session else ()) + ((m._backend.status, m._backend.steps, m._backend.fail_from_step),) * (sabotage is not None))
     finally:
         dist.destroy_process_group()
 
@@ -223,3 +225,35 @@ def test_interleaved_decoder_one_sequence_per_stage(world):
         sends = [s for s, _ in traffic if s is not None]
         assert len(sends) == (n_dec + 2) * world
         assert all(b == (8 if rank == world - 1 else 4 * D) and d == (rank + 1) % world for d, b in sends)
+
+
+@pytest.mark.parametrize("stage,step", [(1, 2), (0, 0), (0, 3)])
+def test_pipeline_rolls_back_in_lock_step_after_a_residency_failure(stage, step):
+    """A decode step whose engine launch fails its residency gate on ONE pipeline stage (status 0x700: nothing written from that
+    step on, the stage keeps forwarding stale activations) used to cost the whole generation under pipeline parallelism (round-5
+    DESIGN section 7 "known limitation").  Now collect() learns over the bootstrap group how many steps completed on EVERY stage,
+    all stages rewind to that step - positions, step counter, stage 0's input id - and re-run the rest on the launch path:
+    tokens and log-probabilities equal the single-process reference outputs on both ranks, whichever stage failed and whether
+    it failed at the session's very first step or later."""
+    from golden_util import Case
+    name = "dense_fp32"
+    case = Case(name)
+    assert case.max_tokens - 1 > step + 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 1500) + 7 * stage + step
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q, True, (stage, step))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, toks, lps, n_local, traffic, (status, steps, still_armed) in res:
+        assert still_armed is None               # the failure really happened and the rollback disarmed it (session_disable_engine)
+        assert toks == case.tokens(), (rank, toks, case.tokens())
+        gen = case.max_tokens
+        for a, b in zip(lps, case.logprobs()):
+            assert max(abs(x - y) for x, y in zip(a[-gen:], b[-gen:])) < 2e-5
+        assert status == 0                       # cleared by the rollback; the stage finished on the "launch path"
+        assert steps == case.max_tokens - 1      # the step counter ends where an undisturbed generation's would
