@@ -547,11 +547,16 @@ def interleaved_run(opt, model, rank: int, world: int, dev: str, T0: int, K: int
         dec.run(K)
         sync()
         dt = time.perf_counter() - t0
+    interleaved_run_graph[0] = bool(dec._use_graph and dec.ticks_replayed > 0)
     tmax = torch.tensor([dt, dec.tick_host_us], device=dev, dtype=torch.float64)
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     del dec, caches
     interleaved_run.tick_host_us = float(tmax[1].item())
+    interleaved_run.tick_form = "hipGraph replay (stage call + grouped exchange per tick)" if interleaved_run_graph[0] else "eager"
     return float(tmax[0].item())
+
+
+interleaved_run_graph = [False]
 
 
 def respawn_under_torchrun(n: int) -> int:
@@ -700,6 +705,7 @@ def main() -> None:
                 "sequences_in_flight": world, "scaling": "weak",
                 "hbm_roofline_frac": round(agg / (HBM_PEAK_GBS * world), 4), "hbm_peak_GBs": HBM_PEAK_GBS * world,
                 "tick_host_us": round(getattr(interleaved_run, "tick_host_us", float("nan")), 2),
+                "tick_form": getattr(interleaved_run, "tick_form", "eager"),
                 "note": "one sequence per stage in flight, ring of grouped send+recv per tick (mistral_inference/pipeline_decode.py); "
                         "tick_host_us = host time per tick of the loop (max over ranks)"}
         # the dominant kernel is timed on this rank's own layers (any N)

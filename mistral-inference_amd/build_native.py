@@ -14,7 +14,9 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmistral_hip.so")
 SOURCES = ["api.hip", "gemv.hip", "gemm.hip", "gemm256.hip", "attn_decode.hip", "attn_prefill.hip", "elementwise.hip",
            "decode_engine.hip", "sampling.hip", "rccl_api.hip", "generic.hip"]
-HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
+# (this file is a dependency of every object: a change of flags must rebuild them - round 6: decode_engine_next.o was once shipped
+# without a flag that had just been added here)
+HEADERS = [os.path.abspath(__file__), os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemv_core.cuh"),
            os.path.join(CSRC, "attn_decode_core.cuh"), os.path.join(HERE, "..", "scripts", "probes", "gemm256_experiments.inc"),
            os.path.join(HERE, "..", "include", "mistral_hip.h"), os.path.join(HERE, "..", "include", "mistral_hip_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

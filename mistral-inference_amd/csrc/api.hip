@@ -670,7 +670,9 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
       }
     }
 #endif
-    // round 5: the dense GQA-4 headline shapes take the `next` compile (sentinel-first sweeps, see decode_engine.hip ENG_SENT)
+    // the dense GQA-4 headline shapes take the `next` compile (build_native.ENGINE_NEXT_FLAGS: abort word read rarely, consumers at
+    // s_setprio 1, holders fetch from the K/V stage on, every DMA from inline asm in the SGPR-base form, no stamp sites, the
+    // loader not stopped during the hid sweep)
     const bool next_ok = dense_ok && m->num_experts == 0 && engine_variant() == 0 && decode_engine_applicable_next(pr, nullptr, 0);
     if (next_ok) {
       bool declined = false;

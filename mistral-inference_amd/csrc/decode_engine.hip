@@ -87,13 +87,10 @@ constexpr int NCONS = 4;
 #ifndef ENG_HOLDERS
 #define ENG_HOLDERS 3  // holder waves per workgroup (0: none)
 #endif
-// Three round-3 experiments, all MEASURED SLOWER on the full model (same box, profiles/EXPERIMENTS.md) and therefore off:
-#ifndef ENG_SPARSE_POLL
-#define ENG_SPARSE_POLL 0  // 1: repeated hand-off sweeps re-read only the granules that were missing (+25 us per step)
-#endif
-#ifndef ENG_LEAN_BARRIERS
-#define ENG_LEAN_BARRIERS 0  // 1: waves 1-3 start the attn sweep while wave 0 still merges the splits (+45 us per step)
-#endif
+// (Experiments that measured slower or within noise - sparse re-polls, lean barriers, a flag barrier, the consumer marks as one
+// 16-byte line, cached marks, per-site sleep lengths, 8-piece fills, the stamp-site bisect mask, a finer holder check - were
+// removed from this file in round 6: scripts/probes/decode_engine_experiments.patch restores them; profiles/EXPERIMENTS.md has
+// every number.)
 // ENG_TRACE = 1 (default, wide and MoE builds): the phase-timeline stamp sites (mi_debug_set_engine_trace, scripts/engine_trace.py)
 // stay in the kernel although they cost a test of a null pointer each.  MEASURED: compiling them out makes THOSE builds 14-19 %
 // SLOWER (profiles/EXPERIMENTS.md rounds 3-5): without the sites hipcc places `s_waitcnt vmcnt(0)` at the top of the loader's
@@ -108,40 +105,8 @@ constexpr int NCONS = 4;
 #ifndef ENG_ALL4
 #define ENG_ALL4 1
 #endif
-#ifndef ENG_ASM_DMA
-#define ENG_ASM_DMA 0  // 1: the loader's LDS-DMA from inline asm (Loader::dma_n).  Measured 20-30 us per step slower than the builtin.
-#endif
-#ifndef ENG_CBAR_FLAGS
-#define ENG_CBAR_FLAGS 0  // 1: consumer barrier on per-wave flag words polled without sleeping (+10..20 us per step)
-#endif
-// ---- round 5 (all off in the default compile, whose ISA stays what it was: scripts/engine_isa_hash.sh) ----------------------
-// s_sleep arguments of the bounded spins, per kind of wait (each unit is 64 clocks)
-#ifndef ENG_SLP_RING
-#define ENG_SLP_RING 1   // loader: ring full
-#endif
-#ifndef ENG_SLP_STOP
-#define ENG_SLP_STOP 1   // loader: stopped while this CU's consumers sweep
-#endif
-#ifndef ENG_SLP_FILL
-#define ENG_SLP_FILL 1   // consumers: waiting for a fill to land
-#endif
-#ifndef ENG_SLP_CBAR
-#define ENG_SLP_CBAR 1   // consumers: barrier among the four waves / holders done
-#endif
-#ifndef ENG_SLP_SWEEP
-#define ENG_SLP_SWEEP 1  // consumers: between two passes of a hand-off sweep
-#endif
-#ifndef ENG_SLP_HOLD
-#define ENG_SLP_HOLD 1   // holder waves (waits of tens of microseconds)
-#endif
 #ifndef ENG_ABORT_RARE
 #define ENG_ABORT_RARE 0  // 1: the abort word is read on every 1024th iteration of a spin only (one LDS read less per poll)
-#endif
-#ifndef ENG_DONE_B128
-#define ENG_DONE_B128 0   // 1: the four consumer marks in one 16-byte aligned LDS line: the loader reads them with ONE ds_read_b128
-#endif
-#ifndef ENG_DONE_CACHE
-#define ENG_DONE_CACHE 0  // 1: the loader re-reads the consumer marks only when the minimum it last saw no longer frees the slot
 #endif
 #ifndef ENG_CONS_PRIO
 #define ENG_CONS_PRIO 0   // s_setprio of the consumer waves (the loader runs at 3, holders at 0)
@@ -176,16 +141,10 @@ constexpr int NCONS = 4;
 #ifndef ENG_HOLD_STAGE
 #define ENG_HOLD_STAGE 3  // the holders' fetch of a layer's units may begin when the loader has issued: 0 nothing yet, 1 q|k|v, 2 + K/V, 3 + Wo
 #endif
-#ifndef ENG_HOLD_CHECK
-#define ENG_HOLD_CHECK 8  // holder loads between two looks at the sweep flag (8: two rows of a 4-piece group; 4: one row)
-#endif
 constexpr int NHOLD = ENG_HOLDERS;
 constexpr int NTHREADS = (NCONS + 1 + NHOLD) * 64;
 constexpr int PIECE = 1024;          // bytes per DMA instruction: 64 lanes x 16 B
-#ifndef ENG_FILL
-#define ENG_FILL 16  // (8: finer publication of landed data, twice the loader's per-fill bookkeeping - round-5 experiment)
-#endif
-constexpr int FILL = ENG_FILL;       // pieces per fill
+constexpr int FILL = 16;             // pieces per fill
 #if ENG_WIDE == 1
 constexpr int RING_FILLS = 7;        // 112 KiB ring: 47 KiB left for the activation region (a 32 KiB hid vector fits)
 #define RING_IDX(sh, x) ((uint32_t)(x) % (uint32_t)(RING_FILLS * FILL))  // not a power of two: a constant modulo (scalar ALU)
@@ -215,7 +174,7 @@ typedef LDS_AS bf16_t lbf16;
 // control words at the start of the LDS
 enum : int {
   C_LANDED = 0,     // fills completely in LDS (loader -> consumers)
-  C_DONE = ENG_DONE_B128 ? 40 : 1,  // [NCONS] first piece index each consumer wave may still read (consumers -> loader)
+  C_DONE = 1,       // [NCONS] first piece index each consumer wave may still read (consumers -> loader)
   C_CBAR = 5,       // consumer-wave barrier counter
   C_GATHERING = 6,  // consumers are sweeping granules: the loader keeps one fill outstanding
   C_ABORT = 7,
@@ -224,7 +183,6 @@ enum : int {
   C_XREADY = 13,    // (layer + 1) once ffn_norm(h1) of that layer stands in the activation region (consumers -> holders)
   C_HDONE = 14,     // W1|W3 units finished by holder waves since the launch began (holders -> consumers)
   C_ARRIVED = 15,   // 1 once every workgroup of the launch is known to be resident (consumer wave 0 -> the other waves)
-  C_BARW = 16,      // [NCONS] barrier phase each consumer wave has reached (flag-barrier experiment, 16-byte aligned)
   C_XA = 21,        // ENG_QKV_HOLD: (layer + 1) once attention_norm(h) of that layer stands in the activation region (-> holders)
   C_HGO = 23,       // ENG_QKV_HOLD = 2: (layer + 1) once this workgroup has h1 of that layer (the router runs next: no sweep for a while)
   C_HQDONE = 22,    // ENG_QKV_HOLD: holder waves done with their q|k|v units since the launch began (-> consumers)
@@ -253,13 +211,7 @@ struct Shared {
   gu64* trace;         // optional timeline buffer
 };
 
-// ENG_TRACE_MASK (variant builds only, scripts/build_variants.py e_mask_*): bit ev = 0 compiles stamp site `ev` out - the
-// bisect of WHICH sites the kernel's speed depends on (profiles/EXPERIMENTS.md round 4).  `ev` is a constant at every call.
-#ifndef ENG_TRACE_MASK
-#define ENG_TRACE_MASK 0xffffffffu
-#endif
 __device__ __forceinline__ void trace_ev(const Shared& sh, int c, int layer, int ev, bool who) {
-  if (!((ENG_TRACE_MASK >> ev) & 1u)) return;
 #if ENG_TRACE == 1
   if (sh.trace && who) sh.trace[((size_t)c * ENG_MAXL + layer) * TR_EVENTS + ev] = __builtin_amdgcn_s_memrealtime();
 #elif ENG_TRACE == 2
@@ -277,9 +229,8 @@ __device__ __forceinline__ void raise_abort(const Shared& sh, uint32_t code) {
 }
 
 // One iteration of a bounded spin.  Returns false when the wait must be abandoned.
-template <int SLP = 1>
 __device__ __forceinline__ bool spin_ok(const Shared& sh, uint32_t& spins, uint32_t code) {
-  __builtin_amdgcn_s_sleep(SLP);
+  __builtin_amdgcn_s_sleep(1);  // (64 clocks; 0 / 2 / 4 / 8 per kind of wait all measured within +-0.2 %)
   if (!ENG_ABORT_RARE && sh.ctl[C_ABORT]) return false;
   ++spins;
   if ((spins & 1023u) == 0) {
@@ -387,17 +338,9 @@ struct Loader {
 #if ENG_SADDR
   uint32_t lane16 = 0;  // this lane's byte offset inside a piece (set by run_loader)
 #endif
-#if ENG_DONE_CACHE
-  uint32_t done_seen = 0;  // minimum of the consumer marks at the last look
-#endif
 
   __device__ __forceinline__ uint32_t min_done() const {
-#if ENG_DONE_B128
-    const u32x4 d = *reinterpret_cast<const LDS_AS volatile u32x4*>(sh.ctl + C_DONE);
-    return min(min(d[0], d[1]), min(d[2], d[3]));
-#else
     return min(min(sh.ctl[C_DONE + 0], sh.ctl[C_DONE + 1]), min(sh.ctl[C_DONE + 2], sh.ctl[C_DONE + 3]));
-#endif
   }
   __device__ __forceinline__ void publish(uint32_t fills) {
     if (fills > pub) {
@@ -410,19 +353,13 @@ struct Loader {
     const uint32_t f = g / FILL;
     if (f >= (uint32_t)ring_fills) {
       const uint32_t need = (f - ring_fills + 1) * FILL;
-#if ENG_DONE_CACHE
-      if (done_seen >= need) return;  // (marks only grow: what was seen once stays true)
-      done_seen = min_done();
-      if (done_seen < need) {
-#else
       if (min_done() < need) {
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         publish(f);  // everything issued has landed: consumers must not starve while we wait for them
         ++stalls;
         uint32_t spins = 0;
         while (min_done() < need)
-          if (!spin_ok<ENG_SLP_RING>(sh, spins, 0x100)) break;
+          if (!spin_ok(sh, spins, 0x100)) break;
       }
     }
   }
@@ -437,7 +374,7 @@ struct Loader {
       publish(f);
       uint32_t spins = 0;
       while (sh.ctl[C_GATHERING])
-        if (!spin_ok<ENG_SLP_STOP>(sh, spins, 0x100)) break;
+        if (!spin_ok(sh, spins, 0x100)) break;
     } else if (thin && sh.ctl[C_GATHERING]) {  // thin == 1: keep one fill in flight during sweeps (A/B)
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       publish(f - 16 / FILL);
@@ -449,13 +386,11 @@ struct Loader {
       if (f >= 32 / FILL) publish(f - 32 / FILL);
     }
   }
-  // The DMA itself.  ENG_ASM_DMA = 1 (experiment, off): issued from inline asm (cdna_hip_programming.md section 5.7 recipe: M0
-  // is written in the statement that reads it and restored), which keeps the DMA out of hipcc's s_waitcnt bookkeeping - in
-  // some builds hipcc puts an `s_waitcnt vmcnt(0)` into the per-unit loop of every weight segment.  It removes those waits
-  // (checked in the ISA) and is nevertheless 20-30 us per step slower than the builtin form (profiles/EXPERIMENTS.md).
+  // The DMA itself: hipcc's builtin, or (ENG_SADDR >= 2) inline asm (cdna_hip_programming.md section 5.7 recipe: M0 is written in
+  // the statement that reads it and restored), which keeps the DMA out of hipcc's s_waitcnt bookkeeping.
   template <int N>
   __device__ __forceinline__ void dma_n(const void* src_lane, lchar* dst) {
-#if ENG_ASM_DMA || ENG_SADDR >= 2
+#if ENG_SADDR >= 2
     // ENG_SADDR >= 2: NO builtin LDS-DMA is left in the loader.  The pieces that still carry per-lane addresses - K/V pieces of
     // rings in the reference's layout and of splits that are not whole 16-slot groups (kv_runs) - are rare at the shapes this
     // build serves, but as builtins they are what hipcc's wait-count pass tracks: it guards every LDS read and every rewrite
@@ -769,43 +704,21 @@ struct Cons {
     for (;;) {
       landed = sh.ctl[C_LANDED];
       if (landed >= need) return;
-      if (!spin_ok<ENG_SLP_FILL>(sh, spins, 0x200)) return;
+      if (!spin_ok(sh, spins, 0x200)) return;
     }
   }
   __device__ __forceinline__ void set_done(uint32_t piece_idx) { sh.ctl[C_DONE + w] = piece_idx; }
 
   // barrier among the NCONS consumer waves (the loader and the holders never take part, so s_barrier is out)
-#if !ENG_CBAR_FLAGS
   __device__ __forceinline__ void cbar() {  // one shared counter; waiting waves sleep between polls, which leaves the SIMD's issue slots to the wave still working
     cbar_target += NCONS;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add((lu32*)(sh.ctl + C_CBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t spins = 0;
     while (sh.ctl[C_CBAR] < cbar_target)
-      if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x300)) break;
-    asm volatile("" ::: "memory");
-  }
-#else
-  // Flag barrier (experiment): every wave stores the phase it has reached into its own word and polls all four with ONE
-  // 16-byte LDS read, no atomic, no sleep on the first polls.  Slower in practice: the tight polls of the early waves take
-  // issue slots and LDS cycles from the wave that is still working on the same SIMD.
-  __device__ __forceinline__ void cbar() {
-    ++cbar_target;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic of the phase is done
-    if (lane == 0) sh.ctl[C_BARW + w] = cbar_target;
-    uint32_t spins = 0, fast = 0;
-    for (;;) {
-      const u32x4 f = *reinterpret_cast<const LDS_AS volatile u32x4*>(sh.ctl + C_BARW);
-      // phases only grow and differ by at most one between waves: (int) difference handles the 2^32 wrap
-      if ((int)(f[0] - cbar_target) >= 0 && (int)(f[1] - cbar_target) >= 0 && (int)(f[2] - cbar_target) >= 0 &&
-          (int)(f[3] - cbar_target) >= 0)
-        break;
-      if (++fast < 64) continue;
       if (!spin_ok(sh, spins, 0x300)) break;
-    }
     asm volatile("" ::: "memory");
   }
-#endif
 
   // fp32 dots of NR consecutive streamed weight rows (P pieces each, the first at piece g0) with the activation vector
   // in LDS.  Lane owns elements (p * 64 + lane) * 8 .. + 8 of every 512-element piece p and accumulates them pairwise
@@ -897,11 +810,8 @@ struct Cons {
   }
 
   // All consumer waves: copy n granules (granule i lives at addr(i); its tag must match) into LDS words dst[0, n).
-  // A sweep that finds some tags missing is repeated, but (ENG_SPARSE_POLL) only for the granules that were missing:
-  // lanes whose granule has arrived re-read one fixed, L2-hot granule instead (all loads stay unconditional - a
-  // predicated load would serialise them) so the polling traffic of 256 CUs waiting for the last
-  // producer shrinks from the whole edge to the few lines still outstanding, and the final successful poll is one
-  // short round trip instead of a full sweep.
+  // A sweep that finds some tags missing is repeated as a whole (all loads unconditional - a predicated load would
+  // serialise them; re-polling only the missing granules measured slower).
   template <int NL, class AddrFn>
   __device__ __forceinline__ void gather_fn(int n, uint32_t tag, lu32* dst, AddrFn addr) {
     for (int k0 = 0; k0 * NCONS * 64 < n; k0 += NL) {
@@ -919,7 +829,7 @@ struct Cons {
         for (int k = 0; k < NL; ++k) {
           const int i = ((k0 + k) * NCONS + w) * 64 + lane;
           const unsigned long long y =
-              __hip_atomic_load(addr((ENG_SPARSE_POLL && have[k]) ? 0 : min(i, n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_load(addr(min(i, n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!have[k]) x[k] = y;
         }
 #pragma unroll
@@ -928,7 +838,7 @@ struct Cons {
           ok &= have[k];
         }
         if (__all(ok)) break;
-        if (!spin_ok<ENG_SLP_SWEEP>(sh, spins, 0x400)) break;
+        if (!spin_ok(sh, spins, 0x400)) break;
       }
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
@@ -938,13 +848,11 @@ struct Cons {
     }
   }
   // Contiguous granule array (n even): 16-byte sc1 loads, two granules each - half the load instructions and wider
-  // transactions than the 8-byte sweep (each 8-byte half is still validated by its own tag).  Buffer loads: a lane whose
-  // pair has arrived polls an out-of-range offset, which returns zero WITHOUT a memory access.
+  // transactions than the 8-byte sweep (each 8-byte half is still validated by its own tag).
   template <int NL = 4>
   __device__ __forceinline__ void gather(const gu64* src, int n, uint32_t tag, lu32* dst) {
     const int n2 = n >> 1;  // granule pairs
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n * 8, 0x00020000);
-    constexpr int OOB = 0x7ffffff0;
     for (int k0 = 0; k0 * NCONS * 64 < n2; k0 += NL) {
       u32x4 x[NL];
       bool have[NL];
@@ -959,7 +867,7 @@ struct Cons {
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
           const int i = ((k0 + k) * NCONS + w) * 64 + lane;
-          const int off = (ENG_SPARSE_POLL && have[k]) ? OOB : min(i, n2 - 1) * 16;
+          const int off = min(i, n2 - 1) * 16;
           const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
           if (!have[k]) x[k] = y;
         }
@@ -969,7 +877,7 @@ struct Cons {
           ok &= have[k];
         }
         if (__all(ok)) break;
-        if (!spin_ok<ENG_SLP_SWEEP>(sh, spins, 0x400)) break;
+        if (!spin_ok(sh, spins, 0x400)) break;
       }
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
@@ -1005,7 +913,6 @@ struct Cons {
   __device__ __forceinline__ void norm_load_granules(u32x4 (&xr)[4], const gu64* src, int K, uint32_t tag) {
     const int vt = w * 64 + lane, npieces = K >> 3;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (K / 2) * 8, 0x00020000);
-    constexpr int OOB = 0x7ffffff0;
     u32x4 lo[4], hi[4];
     bool have[4];
 #pragma unroll
@@ -1019,7 +926,7 @@ struct Cons {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int q = min(vt + i * 256, npieces - 1);
-        const int off = (ENG_SPARSE_POLL && have[i]) ? OOB : q * 32;  // arrived pieces poll nothing (gather())
+        const int off = q * 32;
         const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16 /* sc1 */);
         const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
         if (!have[i]) {
@@ -1033,7 +940,7 @@ struct Cons {
         ok &= have[i];
       }
       if (__all(ok)) break;
-      if (!spin_ok<ENG_SLP_SWEEP>(sh, spins, 0x400)) break;
+      if (!spin_ok(sh, spins, 0x400)) break;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) xr[i] = u32x4{lo[i][0], lo[i][2], hi[i][0], hi[i][2]};
@@ -1491,7 +1398,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
       hq_target += (uint32_t)NHOLD;
       uint32_t spins = 0;
       while (sh.ctl[C_HQDONE] < hq_target)
-        if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
+        if (!spin_ok(sh, spins, 0x500)) break;
     }
 #endif
     trace_ev(sh, c, l, 4, trc);
@@ -1656,9 +1563,8 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
 
     // ================================================================ h1 = h + attn @ Wo^T
     trace_ev(sh, c, l, 9, trc);
-    // the attention scratch is dead once wave 0 has merged ... unless the merge staging lies beyond the words the attn
-    // vector overwrites (GQA ratio >= 2 at these head counts): then waves 1-3 start the next sweep while wave 0 merges
-    if (!(ENG_LEAN_BARRIERS && R * 64 + 128 + 8 * R + 4 * R * DH >= nq / 2)) cs.cbar();
+    // the attention scratch is dead once wave 0 has merged
+    cs.cbar();
     sh.ctl[C_GATHERING] = GATHER_FLAG(8);
     cs.gather(G + a.g_att, nq / 2, tag_of(l, 3), xs32);
     cs.cbar();
@@ -1723,7 +1629,7 @@ __device__ __forceinline__ void run_consumer(const EngArgs& a, const Shared& sh,
         hold_target += (uint32_t)n_hold;
         uint32_t spins = 0;
         while (sh.ctl[C_HDONE] < hold_target)
-          if (!spin_ok<ENG_SLP_CBAR>(sh, spins, 0x500)) break;
+          if (!spin_ok(sh, spins, 0x500)) break;
       }
       sh.ctl[C_GATHERING] = GATHER_FLAG(32);
       cs.gather<14>(G + a.g_hid, a.F / 2, tag_of(l, 5), xs32);
@@ -1922,7 +1828,7 @@ __device__ __forceinline__ void run_qkv_holder(const EngArgs& a, const Shared& s
       const float2 cs0 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + (((2 * u0) % DH) >> 1)) * 2);
       const float2 cs1 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + (((2 * u1) % DH) >> 1)) * 2);
       while (sh.ctl[C_XA] < (uint32_t)(l + 1))
-        if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+        if (!spin_ok(sh, spins, 0x600)) return;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int grp = 0; grp < HOLD_GROUPS; ++grp)
@@ -1968,7 +1874,7 @@ __device__ __forceinline__ void run_qkv_holder(const EngArgs& a, const Shared& s
         // ENG_QKV_HOLD = 1: the loader has issued layer l's Wo rows (it flushes and waits for the router next); 2: this workgroup
         // has gathered h1 - the attention block's sweeps are over, the router's arithmetic begins
         while (sh.ctl[ENG_QKV_HOLD == 2 ? C_HGO : C_LSTAGE] < (uint32_t)(l + 1))
-          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+          if (!spin_ok(sh, spins, 0x600)) return;
       }
       const EngLayer& L = a.L[l + 1];
       LayerPlan p;
@@ -1986,7 +1892,7 @@ __device__ __forceinline__ void run_qkv_holder(const EngArgs& a, const Shared& s
         for (int half = 0; half < 2; ++half) {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
           spins = 0;
           while (sh.ctl[C_GATHERING])
-            if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+            if (!spin_ok(sh, spins, 0x600)) return;
 #pragma unroll
           for (int r = 2 * half; r < 2 * half + 2; ++r)
 #pragma unroll
@@ -2021,7 +1927,7 @@ __device__ __forceinline__ void run_qkv_holder1(const EngArgs& a, const Shared& 
       qkv_unit(p, n_u - NHOLD + hi, kind0, u0);
       const float2 cs0 = *reinterpret_cast<const float2*>(a.rope_cs + ((size_t)pos * (DH >> 1) + (((2 * u0) % DH) >> 1)) * 2);
       while (sh.ctl[C_XA] < (uint32_t)(l + 1))
-        if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+        if (!spin_ok(sh, spins, 0x600)) return;
       float acc[2] = {0.f, 0.f};
 #pragma unroll
       for (int grp = 0; grp < HOLD_GROUPS + 1; ++grp)
@@ -2066,7 +1972,7 @@ __device__ __forceinline__ void run_qkv_holder1(const EngArgs& a, const Shared& 
         // ENG_QKV_HOLD = 1: the loader has issued layer l's Wo rows (it flushes and waits for the router next); 2: this workgroup
         // has gathered h1 - the attention block's sweeps are over, the router's arithmetic begins
         while (sh.ctl[ENG_QKV_HOLD == 2 ? C_HGO : C_LSTAGE] < (uint32_t)(l + 1))
-          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+          if (!spin_ok(sh, spins, 0x600)) return;
       }
       const EngLayer& L = a.L[l + 1];
       LayerPlan p;
@@ -2081,7 +1987,7 @@ __device__ __forceinline__ void run_qkv_holder1(const EngArgs& a, const Shared& 
         {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
           spins = 0;
           while (sh.ctl[C_GATHERING])
-            if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+            if (!spin_ok(sh, spins, 0x600)) return;
 #pragma unroll
           for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -2107,7 +2013,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     const int j = p.f1 - n_hold + hi;
     uint32_t spins = 0;
     while (sh.ctl[C_LSTAGE] < (uint32_t)(l + 1))  // not before the layer's q|k|v, K/V and Wo streams are on their way
-      if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+      if (!spin_ok(sh, spins, 0x600)) return;
     const size_t r0 = (size_t)(2 * j) * a.D + lane * 8;
     const bf16_t* rows[4] = {L.w1 + r0, L.w3 + r0, L.w1 + r0 + a.D, L.w3 + r0 + a.D};
     u32x4 hw[HOLD_GROUPS][4][4];  // [group][row][piece in group]: constant indices only -> registers
@@ -2117,14 +2023,9 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
       for (int half = 0; half < 2; ++half) {  // 8 loads, then look whether this CU's consumers are sweeping a hand-off
         spins = 0;
         while (sh.ctl[C_GATHERING])
-          if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+          if (!spin_ok(sh, spins, 0x600)) return;
 #pragma unroll
         for (int r = 2 * half; r < 2 * half + 2; ++r) {
-          if (ENG_HOLD_CHECK == 4 && r == 2 * half + 1) {
-            spins = 0;
-            while (sh.ctl[C_GATHERING])
-              if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
-          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int piece = min(grp * 4 + q, PD - 1);  // groups beyond the row are never used (holder_units: PD <= 8)
@@ -2135,7 +2036,7 @@ __device__ __forceinline__ void run_holder(const EngArgs& a, const Shared& sh, i
     }
     spins = 0;
     while (sh.ctl[C_XREADY] < (uint32_t)(l + 1))
-      if (!spin_ok<ENG_SLP_HOLD>(sh, spins, 0x600)) return;
+      if (!spin_ok(sh, spins, 0x600)) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int grp = 0; grp < HOLD_GROUPS; ++grp)

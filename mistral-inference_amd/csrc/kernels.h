@@ -312,9 +312,10 @@ void decode_engine_forget_census_moe();
 void decode_engine_set_trace_moe(void* dev_buffer);
 void decode_engine_set_knobs_moe(int thin, int depth);
 void decode_engine_set_holders_moe(int on);
-// ... and a fourth time (round 5, decode_engine_next.o: -DENG_SUFFIX=_next -DENG_HEADLINE_ONLY=1 + the ENG_SENT / ENG_KV_PROG /
-// ENG_SLP_* switches build_native.py lists): the dense GQA-4 shapes with rows of 4-piece groups, i.e. the headline model.  The
-// frozen default object stays in the library (every other dense shape; MI_ENGINE_VARIANT=2 routes the headline to it for A/B).
+// ... and a fourth time (decode_engine_next.o: -DENG_SUFFIX=_next -DENG_HEADLINE_ONLY=1 + build_native.ENGINE_NEXT_FLAGS:
+// ENG_ABORT_RARE, ENG_CONS_PRIO, ENG_HOLD_STAGE=2, ENG_SADDR=2, ENG_TRACE=0, ENG_NOSTOP=32): the dense GQA-4 shapes with rows of
+// 4-piece groups, i.e. the headline model.  The default object stays in the library (every other dense shape;
+// MI_ENGINE_VARIANT=2 routes the headline to it for A/B).
 bool decode_engine_applicable_next(const EngProblem& pr, char* why, size_t why_len);
 hipError_t launch_decode_engine_next(const EngProblem& pr, hipStream_t s, bool* declined);
 const char* decode_engine_census_detail_next();

@@ -276,9 +276,10 @@ def test_wide_engine_build_bit_equal_launch_path(name):
         assert torch.equal(k0, k1) and torch.equal(v0, v1), (name, l, _where(k0, k1), _where(v0, v1))
 
 
-# The NEXT build (round 5: decode_engine_next.o = the same source with sentinel-first sweeps on the W2 -> h and W1|W3 -> hid
-# edges, the loader streaming through the sentinel wait, fill-by-fill K/V waits): the dense GQA-4 shapes whose rows are all
-# multiples of 4 pieces - the headline model - are routed to it.  None of SHAPES qualifies, so its code runs here at sizes the
+# The NEXT build (decode_engine_next.o = the same source under build_native.ENGINE_NEXT_FLAGS: abort word read on every 1024th spin,
+# consumer waves at s_setprio 1, holders fetch from the K/V stage on, every loader DMA from inline asm in the SGPR-base form, no
+# stamp sites, the loader not stopped during the hid sweep): the dense GQA-4 shapes whose rows are all multiples of 4 pieces -
+# the headline model - are routed to it.  None of SHAPES qualifies, so its code runs here at sizes the
 # suite can afford, against the launch path AND against the frozen default object (mi_debug_set_engine_variant(2)).
 NEXT_SHAPES = {
     # holder waves on (12 W1|W3 units per CU), ring wraps
