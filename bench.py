@@ -141,15 +141,19 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int, timed_us: float
     e1.record(stream)
     e1.synchronize()
     fwd_us = e0.elapsed_time(e1) * 1e3 / iters
-    sess = model.greedy_session(cache, ids, graph=False)  # the same steps as the timed loop, launched eagerly
-    sess.run(2)
-    e0.record(stream)
-    sess.run(iters)
-    e1.record(stream)
-    e1.synchronize()
-    sess.collect()
-    greedy_eager_us = e0.elapsed_time(e1) * 1e3 / iters
-    del sess
+    def session_us(**kw):
+        sess = model.greedy_session(cache, ids, **kw)
+        if kw.get("graph"):
+            sess.engine_graph = True   # (keep the one-kernel hipGraph: what generate() did until round 5)
+        sess.run(3)
+        e0.record(stream)
+        sess.run(iters)
+        e1.record(stream)
+        e1.synchronize()
+        sess.collect()
+        return e0.elapsed_time(e1) * 1e3 / iters
+    greedy_eager_us = session_us(graph=False)  # the same steps as the timed loop, launched plainly
+    greedy_graph_us = session_us(graph=True)   # ... and replayed from a one-kernel hipGraph per step
     us, ctx_mid, n_timed = (timed_us, timed_ctx, timed_steps) if timed_us else (fwd_us, ctx0 + iters // 2, iters)
     bytes_per_launch = decode_bytes_per_token(params, ctx_mid)
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
@@ -161,12 +165,13 @@ def engine_roofline(model, cache, nxt, params: dict, iters: int, timed_us: float
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_static": True, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(us, 2), "launches_timed": n_timed,
-            "timing": ("HIP events on the launch stream around the timed, graph-replayed greedy steps (one kernel per step)" if timed_us
+            "timing": ("HIP events on the launch stream around the TIMED greedy steps themselves (one kernel per step)" if timed_us
                        else "HIP events around an eager forward() loop"),
-            "other_loops_us": {"eager_forward_no_sample": round(fwd_us, 2), "eager_greedy_session": round(greedy_eager_us, 2),
-                               "iters": iters,
-                               "reading": "greedy - forward = the fused sample's hop behind the LM head; timed - eager greedy = "
-                                          "replaying a one-kernel hipGraph per step instead of queued plain launches"}}
+            "other_loops_us": {"eager_forward_no_sample": round(fwd_us, 2), "greedy_session_plain_launches": round(greedy_eager_us, 2),
+                               "greedy_session_one_kernel_hipgraph": round(greedy_graph_us, 2), "iters": iters,
+                               "reading": "greedy - forward = the fused sample's hop behind the LM head; hipgraph - plain = what "
+                                          "replaying a one-kernel hipGraph per step costs over queued plain launches (why engine "
+                                          "sessions launch plainly since round 6)"}}
 
 
 def dominant_kernel_roofline(model, iters: int) -> dict:
@@ -440,6 +445,7 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
                 collect_s += time.perf_counter() - t1   # generate() pays this once per chunk (32 steps with an eos_id, else 1024)
                 left -= n
             nxt = toks[-1]
+            timed_run.used_graph = bool(sess._use_graph)
             timed_run.collect_s = collect_s
             timed_run.event_us_per_step = ev_ms * 1e3 / K
         else:
@@ -514,7 +520,7 @@ def batch_run(opt, params: dict, B: int, dev: str, T0: int, K: int, Wm: int) -> 
                                    f"batch-{B} greedy decode, sliding_window={params.get('sliding_window')}",
                        "batch": B, "prefill_tokens": T0, "context_at_timing": ctx_len,
                        "decode_launch": ("persistent decode engine" if st["engine_launches"] > 0 else "6 launches per layer (launch path)")
-                       + ", greedy sample fused into the step, " + ("eager" if opt.no_graph else "hipGraph replay")},
+                       + ", greedy sample fused into the step, " + ("hipGraph replay" if sess._use_graph else "plain launches")},
             "hbm_roofline_step": {"bytes_per_step": step_bytes, "weights_once_plus_kv_per_sequence": [w_bytes - kv_one, kv_one],
                                   "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)},
             "per_sequence_tokens_per_s": round(K / dt, 2)}
@@ -657,7 +663,9 @@ def main() -> None:
             kind += " (one session per stage; the sample returns to stage 0 as 8 bytes per token, no logits broadcast)"
         from mistral_inference.distributed import RcclComm
         eager = opt.no_graph or (world > 1 and not isinstance(model.pp_comm, RcclComm))
-        return kind + (", eager" if eager else ", hipGraph replay")
+        if opt.loop == "greedy":  # what the session really did: an engine step is one kernel and is launched plainly
+            eager = eager or not getattr(timed_run, "used_graph", True)
+        return kind + (", plain launches queued back to back (no hipGraph)" if eager else ", hipGraph replay")
 
     def report() -> dict:
         ctx_len = T0 + Wm + K // 2

@@ -35,7 +35,12 @@ PER_FILE_FLAGS = {"decode_engine.hip": os.environ.get("MI_ENGINE_FLAGS", "-mllvm
 # round 6: + the loader is not stopped during the hid sweep (ENG_NOSTOP=32: the ring is empty there; +0.1..0.7 % on six boxes)
 ENGINE_NEXT_FLAGS = ["-DENG_SUFFIX=_next", "-DENG_HEADLINE_ONLY=1", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1", "-DENG_HOLD_STAGE=2",
                      "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"]
+# round 6: Mistral-Nemo dims (dim 5120: rows of 10 pieces, contiguous units) on the 8-fill ring with every DMA from inline asm
+ENGINE_NEMO_FLAGS = ["-DENG_SUFFIX=_nemo", "-DENG_HEADLINE_ONLY=2", "-DENG_WIDE=2", "-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=1",
+                     "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32", "-DENG_CLEAN_ENTRY=1"]  # (without the clean entry: 52 leaked
+# `vmcnt(4)` guards inside this build's loader loops - scripts/engine_loader_waits.py)
 VARIANT_OBJECTS = {"decode_engine_next.o": ("decode_engine.hip", ENGINE_NEXT_FLAGS),
+                   "decode_engine_nemo.o": ("decode_engine.hip", ENGINE_NEMO_FLAGS),
                    # (the wide build also takes the two round-5 switches: +0.7 % on the 8x22B stage; the 8-fill MoE build does NOT -
                    #  the same two switches make Mixtral-8x7B 4.5 % slower, profiles/EXPERIMENTS.md round 5; and the q|k|v holder
                    #  waves, one unit each at rows of 12 pieces: +1.2 % on the 8x22B stage)

@@ -61,6 +61,14 @@ constexpr size_t TICKET_BYTES = 4096;  // first words: control block of the pers
 // 1 (default): batch-1 decode steps of dense models run on the persistent engine (decode_engine.hip) when the shapes
 // allow it; 0: always the launch path.  MI_DECODE_ENGINE sets the initial value, mi_set_decode_engine changes it.
 int g_engine_mode = -1;
+bool nemo_engine_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MI_ENGINE_NEMO");
+    on = e ? atoi(e) != 0 : 0;  // measured (round 6): 5.15-5.17 ms per step against 4.94-4.95 on the launch path at the Nemo-12B dims
+  }
+  return on != 0;
+}
 int g_engine_variant = -1;  // 0 (default): the shipped engine build first (MoE: the wide build first); 1: wide first; 2: shipped first
 int engine_variant() {
   if (g_engine_variant < 0) {
@@ -517,6 +525,7 @@ int mi_debug_engine_sabotage(void* workspace, int launches, mi_stream_t stream) 
 
 int mi_decode_engine_census(int forget) {
   if (forget) decode_engine_forget_census_next();
+  if (forget) decode_engine_forget_census_nemo();
   if (forget) decode_engine_forget_census_wide();
   if (forget) decode_engine_forget_census_moe();
   if (forget) decode_engine_forget_census();
@@ -533,6 +542,7 @@ size_t mi_debug_engine_trace_bytes(void) { return decode_engine_trace_bytes(devi
 int mi_debug_set_engine_knobs(int thin, int depth) {
   decode_engine_set_knobs(thin, depth);
   decode_engine_set_knobs_next(thin, depth);
+  decode_engine_set_knobs_nemo(thin, depth);
 #ifdef MI_SLOT_LIST
   for (const EngSlot& sl : g_slots) sl.set_knobs(thin, depth);
 #endif
@@ -543,6 +553,7 @@ int mi_debug_set_engine_knobs(int thin, int depth) {
 int mi_debug_set_engine_holders(int on) {
   decode_engine_set_holders(on);
   decode_engine_set_holders_next(on);
+  decode_engine_set_holders_nemo(on);
 #ifdef MI_SLOT_LIST
   for (const EngSlot& sl : g_slots) sl.set_holders(on);
 #endif
@@ -552,7 +563,7 @@ int mi_debug_set_engine_holders(int on) {
 }
 int mi_debug_set_engine_variant(int variant) {
   const int prev = engine_variant();
-  g_engine_variant = variant < 0 || variant > 2 ? 0 : variant;
+  g_engine_variant = variant < 0 || variant > 3 ? 0 : variant;
   return prev;
 }
 #ifdef MI_SLOT_LIST
@@ -569,6 +580,7 @@ int mi_debug_set_prefill_kernels(int attn_waves, int gemm_tail) {
 int mi_debug_set_engine_trace(void* dev_buffer) {
   decode_engine_set_trace(dev_buffer);
   decode_engine_set_trace_next(dev_buffer);
+  decode_engine_set_trace_nemo(dev_buffer);
 #ifdef MI_SLOT_LIST
   for (const EngSlot& sl : g_slots) sl.set_trace(dev_buffer);
 #endif
@@ -683,6 +695,21 @@ int mi_forward(const mi_model_t* m, const mi_batch_t* bt, mi_stream_t stream) {
         return MI_OK;
       }
       snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail_next());  // informational
+    }
+    // large dims whose rows are not multiples of 4 pieces (Mistral-Nemo): the `nemo` compile - bit-equal, in a clean regime
+    // (scripts/engine_loader_waits.py) and still 4 % slower than the launch path at those dims (contiguous 20- / 40-piece units:
+    // four consumer waves cannot all hold one in the 128-piece ring), so it is opt-in: MI_ENGINE_NEMO=1 or engine variant 3 (tests)
+    const bool nemo_ok = dense_ok && m->num_experts == 0 && (engine_variant() == 3 || (engine_variant() == 0 && nemo_engine_enabled())) &&
+                         decode_engine_applicable_nemo(pr, nullptr, 0);
+    if (nemo_ok) {
+      bool declined = false;
+      MI_TRY(hip_rc(launch_decode_engine_nemo(pr, s, &declined), "decode engine"));
+      if (!declined) {
+        if (m->final_norm && !bt->logits) MI_TRY(hip_rc(launch_rmsnorm(h, h, m->final_norm, T, D, m->norm_eps, s), "final norm"));
+        if (want_topp) MI_TRY(sample_step());
+        return MI_OK;
+      }
+      snprintf(g_detail, sizeof(g_detail), "decode engine declined: %s", decode_engine_census_detail_nemo());  // informational
     }
     const bool moe_ok = dense_ok && m->num_experts > 0 && engine_variant() == 0 && decode_engine_applicable_moe(pr, nullptr, 0);
     const bool wide_ok = !moe_ok && dense_ok && decode_engine_applicable_wide(pr, nullptr, 0);

@@ -48,6 +48,8 @@
 // ENG_WIDE = 2: the same additions with the shipped 8-fill ring, MoE models only (decode_engine_moe.o): at dim 4096 the four
 // consumer waves' W1|W3 units span exactly 8 fills, and the 7-fill ring of ENG_WIDE = 1 costs Mixtral-8x7B 6 % of its W1|W3
 // streaming rate (25.6 vs 27.2 GB/s per CU, profiles/r04_engine_trace_8x7b_*) - as much as the batched router saves.
+// ENG_HEADLINE_ONLY = 2 (round 6, decode_engine_nemo.o: + ENG_WIDE = 2, ENG_SADDR = 2): only decode_engine_kernel<4, dense, rows NOT
+// all multiples of 4 pieces> on the 8-fill ring - Mistral-Nemo (dim 5120 = rows of 10 pieces, streamed as contiguous units).
 // ENG_SUFFIX (round 5): further compiles of this source under their own entry-point names - `_next` (decode_engine_next.o: the
 // dense GQA-4 headline shape with the round-5 switches below: ENG_ABORT_RARE, ENG_CONS_PRIO, ENG_HOLD_STAGE, ENG_SADDR = 2 and
 // ENG_TRACE = 0 - build_native.py: ENGINE_NEXT_FLAGS) and the `_x<N>` slots of an experiment library (scripts/build_variants.py
@@ -504,6 +506,19 @@ struct Loader {
   // n pieces that are contiguous in memory (and land contiguously in the ring): four per address computation wherever the
   // stream position allows it
   __device__ __forceinline__ void seg(const bf16_t* base, int n) {
+#if ENG_SADDR
+    const char* sb = reinterpret_cast<const char*>(base);  // (wave-uniform base; the lane's offset is in lane16)
+    int i = 0;
+    while (i < n) {
+      if ((g & 3) == 0 && n - i >= 4) {
+        piece4_s(sb + (size_t)i * PIECE);
+        i += 4;
+      } else {
+        piece_s(sb + (size_t)i * PIECE);
+        ++i;
+      }
+    }
+#else
     const char* src = reinterpret_cast<const char*>(base) + lane * 16;
     int i = 0;
     while (i < n) {
@@ -515,6 +530,7 @@ struct Loader {
         ++i;
       }
     }
+#endif
   }
 #endif
   template <int NR>
@@ -2162,20 +2178,26 @@ bool decode_engine_applicable(const EngProblem& pr, char* why, size_t why_len) {
   // waves): 7.6-8.0 ms per step on the engine against 5.0 ms on the launch path (profiles/EXPERIMENTS.md) - such models
   // take the launch path.  Small dims (the parity tests) stay on the engine.
 #if !ENG_WIDE
+#if ENG_HEADLINE_ONLY != 2
   if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
+#endif
 #else
   // The wide build streams such rows as contiguous units (Loader::unit) - the third form tried for the Nemo dims, and still
   // slower than the launch path there: 5.47 vs 4.94 ms per step at an 8192-token context (profiles/EXPERIMENTS.md round 4;
   // 2-piece groups: 7.6-8.0 ms, 4 + 4 + 2 groups: 5.62 ms).  Declined unless the caller forces the wide build (traces, tests).
+#if ENG_HEADLINE_ONLY != 2  // (the `nemo` build exists for exactly these dims)
   if (pr.D > 3072 && ((pr.D >> 9) & 3) != 0 && !pr.forced) return no("dim > 3072 and not a multiple of 2048: the launch path is faster (Nemo dims)");
+#endif
   if (((pr.D >> 9) & 1) && pr.D > 3072) return no("odd number of 512-element pieces per row at a large dim");
 #endif
   if (pr.V % 2) return no("odd vocab");
-#if ENG_HEADLINE_ONLY
+#if ENG_HEADLINE_ONLY == 1
   if (pr.E || pr.H != 4 * pr.Hkv || pr.D % 2048 || (pr.H * DH) % 2048 || pr.F % 2048)
     return no("this build instantiates the dense GQA-4 kernel for rows of 4-piece groups only");
-#endif
-#if ENG_WIDE == 2
+#elif ENG_HEADLINE_ONLY == 2
+  if (pr.E || pr.H != 4 * pr.Hkv || !(pr.D % 2048 || (pr.H * DH) % 2048 || pr.F % 2048) || pr.D <= 3072)
+    return no("this build instantiates the dense GQA-4 kernel for large dims whose rows are not all 4-piece groups only (Mistral-Nemo)");
+#elif ENG_WIDE == 2
   if (!pr.E) return no("the 8-fill MoE build takes MoE models only");
 #endif
   const int kmax = pr.D > pr.F ? (pr.D > pr.H * DH ? pr.D : pr.H * DH) : (pr.F > pr.H * DH ? pr.F : pr.H * DH);
@@ -2372,8 +2394,10 @@ hipError_t launch_decode_engine(const EngProblem& pr, hipStream_t s, bool* decli
   (moe ? (all4 ? (const void*)decode_engine_kernel<RR, true, true> : (const void*)decode_engine_kernel<RR, true, false>) \
        : (all4 ? (const void*)decode_engine_kernel<RR, false, true> : (const void*)decode_engine_kernel<RR, false, false>))
     switch (a.R) {
-#if ENG_HEADLINE_ONLY
+#if ENG_HEADLINE_ONLY == 1
       case 4: fn = (!moe && all4) ? (const void*)decode_engine_kernel<4, false, true> : nullptr; break;
+#elif ENG_HEADLINE_ONLY == 2
+      case 4: fn = (!moe && !all4) ? (const void*)decode_engine_kernel<4, false, false> : nullptr; break;
 #elif ENG_WIDE == 2
       case 4: fn = !moe ? nullptr : (all4 ? (const void*)decode_engine_kernel<4, true, true> : (const void*)decode_engine_kernel<4, true, false>); break;
 #elif ENG_WIDE

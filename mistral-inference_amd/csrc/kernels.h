@@ -323,6 +323,17 @@ void decode_engine_forget_census_next();
 void decode_engine_set_trace_next(void* dev_buffer);
 void decode_engine_set_knobs_next(int thin, int depth);
 void decode_engine_set_holders_next(int on);
+// ... and a fifth time (round 6, decode_engine_nemo.o: build_native.ENGINE_NEMO_FLAGS): dense GQA-4 models of a large dim whose
+// rows are not multiples of 4 pieces - Mistral-Nemo (dim 5120).  Rounds 4-5 measured such dims slower on the wide build than on
+// the launch path; round 6 found that build's dense kernels in the slow regime (hipcc drains the builtin-DMA queue in
+// fill_begin: scripts/engine_loader_waits.py) - this build issues every DMA from inline asm.
+bool decode_engine_applicable_nemo(const EngProblem& pr, char* why, size_t why_len);
+hipError_t launch_decode_engine_nemo(const EngProblem& pr, hipStream_t s, bool* declined);
+const char* decode_engine_census_detail_nemo();
+void decode_engine_forget_census_nemo();
+void decode_engine_set_trace_nemo(void* dev_buffer);
+void decode_engine_set_knobs_nemo(int thin, int depth);
+void decode_engine_set_holders_nemo(int on);
 
 // ---------------------------------------------------------------------------------------------- generic storage dtype
 // generic.hip: the operator sequence of the hot path for fp32 / fp16 storage (and for bf16 shapes the tuned kernels

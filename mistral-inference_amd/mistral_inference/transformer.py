@@ -675,7 +675,8 @@ class GreedySession:
     * the LM head's epilogue produces the sample (persistent engine: in the same launch; launch path: one more small
       kernel) and writes it (a) into the id buffer the NEXT step reads - `mi_batch_t.input_ids` may alias
       `greedy_token` - and (b) into a history ring on the device;
-    * a step is captured once in a hipGraph and replayed; on the persistent engine that graph is a single kernel;
+    * on the launch path a step (~165 launches) is captured once in a hipGraph and replayed; on the persistent engine a step
+      is a single kernel and is launched plainly (a one-kernel graph costs more per replay than a queued launch, round 6);
     * `run(n)` enqueues n steps without touching the host again; `collect(n)` reads the n samples back in one copy,
       which is also where a device-side failure is noticed: an engine step whose residency census failed (status
       0x700, include/mistral_hip.h) wrote nothing, so the missing steps are re-run on the launch path.
@@ -757,10 +758,19 @@ class GreedySession:
             # size the workspace exactly as run_stack will BEFORE reading its step counter: a re-allocation inside the first
             # step would restart the counter at zero and collect() would index the wrong history rows
             m._backend.prepare_session(m, self.B, cache)
-            self._base = self._steps_now()
+            st0 = m._backend.session_status()
+            self._base = st0["steps"]
             self.buf.offset = -self._base  # (mod 2^64) a generation's variates do not depend on what ran on the workspace before
             self._step_eager()
             self._warm = True
+            if self._use_graph and os.environ.get("MI_ENGINE_GRAPH", "0") != "1" and not getattr(self, "engine_graph", False):
+                # Did this step run on the persistent engine?  Then a step is ONE kernel and plain launches, which the host
+                # enqueues ~50x faster than the GPU retires them, run back to back - whereas replaying a one-kernel hipGraph per
+                # step costs ~28 us more per token than a queued plain launch (round 6: bench.py roofline.other_loops_us,
+                # 2624 vs 2596 us per step = 1.1 %).  The hipGraph stays for the launch path (~165 launches per step).
+                # One synchronisation per session; MI_ENGINE_GRAPH=1 keeps the replayed form (A/B).
+                if m._backend.session_status()["engine_launches"] > st0["engine_launches"]:
+                    self._use_graph = False
             return
         if self._use_graph:
             g = self._captured(1)

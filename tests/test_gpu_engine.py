@@ -107,6 +107,14 @@ SHAPES = {
     # attention work
     "rows_of_6_and_3_pieces": dict(dim=3072, n_layers=2, head_dim=128, hidden_dim=1536, n_heads=24, n_kv_heads=6, norm_eps=1e-5,
                                    vocab_size=768, sliding_window=64),
+    # THE NEMO BUILD (round 6: decode_engine_nemo.o - dense GQA-4 models of a large dim whose rows are not multiples of 4 pieces,
+    # every loader DMA from inline asm): Mistral-Nemo's rows (dim 5120 = 10 pieces, streamed as contiguous units; n_heads * 128
+    # = 4096 = 8 pieces for Wo; hidden 3584 = 7 pieces for W2) at 2 layers, over a ring that wraps
+    "nemo_rows_of_10_pieces": dict(dim=5120, n_layers=2, head_dim=128, hidden_dim=3584, n_heads=32, n_kv_heads=8, norm_eps=1e-5,
+                                   vocab_size=1000, sliding_window=48),
+    # ... and over a ring longer than the LDS ring holds at once (272-slot splits: the streamed K/V mode), contiguous K/V runs
+    "nemo_rows_long_ring": dict(dim=5120, n_layers=1, head_dim=128, hidden_dim=2048, n_heads=16, n_kv_heads=4, norm_eps=1e-5,
+                                vocab_size=640, sliding_window=None),
     # HOLDER WAVES at a size the whole suite can afford: they need dim % 2048 == 0 and >= 11 W1|W3 units per CU
     # (decode_engine.hip holder_units): hidden_dim 5632 = 11 units x 256 CUs exactly
     "holders_mid_size": dict(dim=2048, n_layers=2, head_dim=128, hidden_dim=5632, n_heads=16, n_kv_heads=4, norm_eps=1e-5,
@@ -205,11 +213,18 @@ def test_engine_bit_equal_launch_path(name):
         prompt_len = 57  # + 12 steps crosses the 64-slot ring
     if name == "two_launches_34_layers":
         prompt_len = 33  # + 12 steps crosses the 40-slot ring
-    if name == "ring_longer_than_lds":
+    if name in ("ring_longer_than_lds", "nemo_rows_long_ring"):
         prompt_len, steps = 8290, 6
     ids = torch.randint(0, p["vocab_size"], (prompt_len + steps,), generator=torch.Generator().manual_seed(3)).cuda()
-    ref, ref_rings, st0 = _run(m, ids, prompt_len, steps, engine=False)
-    got, got_rings, st1 = _run(m, ids, prompt_len, steps, engine=True)
+    from mistral_inference import _hip
+    # (the `nemo` build is opt-in - it measured slower than the launch path at the Nemo-12B dims -: engine variant 3 routes to it)
+    prev = _hip.lib().mi_debug_set_engine_variant(3) if name.startswith("nemo_") else None
+    try:
+        ref, ref_rings, st0 = _run(m, ids, prompt_len, steps, engine=False)
+        got, got_rings, st1 = _run(m, ids, prompt_len, steps, engine=True)
+    finally:
+        if prev is not None:
+            _hip.lib().mi_debug_set_engine_variant(prev)
     assert st1["status"] == 0 and st1["abort"] == 0, st1
     assert st1["engine_launches"] >= steps and st0["engine_launches"] < st1["engine_launches"]  # the engine really ran
     for i, (a, b) in enumerate(zip(ref, got)):
