@@ -427,12 +427,15 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
             if W > 2:
                 sess.collect()
             sess.run(2)
-            sync()
             dt, left, collect_s, ev_ms = 0.0, K, 0.0, 0.0
             stream = torch.cuda.current_stream(dev)  # (the stream mi_forward launches on and the captured step is replayed on)
+            # (events are created BEFORE the bracket's synchronisation: whatever the host does between that synchronisation and the
+            # first launch is idle GPU time inside the timed region)
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K // sess.HIST + 2)]
+            sync()
             while left > 0:                      # (the session's history ring holds 1024 steps between collects)
                 n = min(left, sess.HIST - sess._pending)  # (the two warm-up steps above are still uncollected)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = events.pop()
                 t0 = time.perf_counter()
                 e0.record(stream)                # HIP events on the launch stream around the SAME steps the wall clock brackets:
                 sess.run(n)                      # on the persistent engine a step is one kernel, so this is the dominant kernel's

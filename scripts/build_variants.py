@@ -112,6 +112,7 @@ ENGINE_SLOTS = {
     "nst_hid_attn": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=40"),
     "nst_hid_h": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=33"),
     "ns_hid": _NS + ("-DENG_NOSTOP=32",),
+    "ns_ce_hid": _NS + _CE + ("-DENG_NOSTOP=32",),                  # the shipped flags WITH stamp sites, clean by the static check: timelines
     "nst_hid_stage3": _AP + ("-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
     "nst_hid_hold4": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=32", "-DENG_SLP_HOLD=4"),
     # round 6 (the K/V-phase experiments of this round - asm K/V pieces, fine / tight publication, a reordered stream - are kept as
