@@ -112,6 +112,14 @@ ENGINE_SLOTS = {
     "nst_hid_attn": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=40"),
     "nst_hid_h": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=33"),
     "ns_hid": _NS + ("-DENG_NOSTOP=32",),
+    # a sweep of the remaining knobs on top of the shipped flags with the head-major rings (the K/V issue is 2.2 us now, not 5)
+    "hid_q": _N0 + ("-DENG_NOSTOP=34",),
+    "hid_attn": _N0 + ("-DENG_NOSTOP=40",),
+    "hid_h1": _N0 + ("-DENG_NOSTOP=48",),
+    "hid_merge": _N0 + ("-DENG_NOSTOP=36",),
+    "hid_stage1": _AP + ("-DENG_HOLD_STAGE=1", "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
+    "hid_stage3": _AP + ("-DENG_HOLD_STAGE=3", "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
+    "hid_prio2": ("-DENG_ABORT_RARE=1", "-DENG_CONS_PRIO=2", "-DENG_HOLD_STAGE=2", "-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
     "ns_ce_hid": _NS + _CE + ("-DENG_NOSTOP=32",),                  # the shipped flags WITH stamp sites, clean by the static check: timelines
     "nst_hid_stage3": _AP + ("-DENG_SADDR=2", "-DENG_TRACE=0", "-DENG_NOSTOP=32"),
     "nst_hid_hold4": _NS + ("-DENG_TRACE=0", "-DENG_NOSTOP=32", "-DENG_SLP_HOLD=4"),
