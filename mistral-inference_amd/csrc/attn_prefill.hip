@@ -18,8 +18,9 @@
 //                    <-> key mapping of the B operand is permuted to match the C layout, and the A operand
 //                    (V^T, staged transposed in LDS) is read with the same permutation.
 // K tile: row-major in LDS, 16-byte slots XOR-swizzled by (key & 15) -> conflict-free ds_read_b128.
-// V tile: transposed on the way in (4 keys x 8 d per thread, register transpose, ds_write_b64), row
-// stride 136 B -> conflict-free ds_read_b64.
+// V tile: transposed on the way in (2 or 4 keys x 8 d per thread, register transpose), the 4-key quads of every 16-key
+// group stored in the order 0, 2, 1, 3 so that a lane's 8 keys of one MFMA are one ds_read_b128; row stride 144 B ->
+// conflict-free (see VT_STRIDE).
 #include <cstdlib>
 #include <type_traits>
 
@@ -48,15 +49,36 @@ __device__ __forceinline__ uint32_t attn_h_pack2(float lo, float hi) {
 #define ATTN_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #endif
 
+#ifndef ATT_FASTLOAD
+#define ATT_FASTLOAD 1  // 0 = every tile through the general (per-lane source selection) staging path: the round 1-5 form
+#endif
 #ifndef ATT_PRIO
 #define ATT_PRIO 0  // experiment switch: 1 = s_setprio(1) around the two MFMA clusters, 2 = static priority 1 for waves 4..7
+#endif
+
+#ifndef ATT_TRACE
+#define ATT_TRACE 0  // 1 = (probe builds only) every block records {start, end} of s_memrealtime, its XCC / CU ids: scripts/attn_prefill_trace.py
+#endif
+#if ATT_TRACE
+__device__ unsigned long long g_attn_trace[16384 * 4];
+extern "C" int mi_probe_attn_trace(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
 #endif
 
 namespace {
 
 constexpr int DH = 128;
 constexpr int KT = 64;         // keys per tile
-constexpr int VT_STRIDE = 136; // bytes per d-row of the transposed V tile
+#ifndef ATT_VB128
+#define ATT_VB128 1  // 0 = V^T rows in key order, 136-byte stride, fragments as two 8-byte reads (rounds 1-6: hipcc fuses them to ds_read2_b64)
+#endif
+// bytes per d-row of the transposed V tile.  ATT_VB128: inside every 16-key group the four 4-key quads are stored in the order
+// 0, 2, 1, 3, so that the 8 keys one lane feeds to a P.V MFMA ({0..3, 8..11} + 4 * half) are 16 CONTIGUOUS bytes: one
+// ds_read_b128 (4 LDS cycles per wave, conflict-free at a 144-byte row stride) instead of a ds_read2_b64, which the LDS
+// serves in 16 cycles (cdna_hip_programming.md, LDS: "16 bytes cost 16 as ds_read2_b64 and 4 as ds_read_b128") - the V^T
+// fragments were 2048 of the ~4300 cycles a key tile takes on a CU.
+constexpr int VT_STRIDE = ATT_VB128 ? 144 : 136;
 constexpr int KS_BYTES = KT * DH * 2;
 constexpr int VT_BYTES = DH * VT_STRIDE;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -69,6 +91,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
   constexpr int NT = NW * 64, QB = NW * 32;  // threads, queries per block
 
   const int tid = threadIdx.x, lane = tid & 63;
+#if ATT_TRACE
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // provably wave-uniform: everything derived from it (this wave's query range, `skip`, `full`) becomes scalar control
   // flow; with a VGPR-derived wave id hipcc predicated the 32-score masking code lane by lane on every tile.
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,18 +196,54 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
       rv[j] = ld16(vb + key_off(kpv) + v_ds * 8);
     }
   };
+#if ATT_FASTLOAD
+  // The common tile - 64 consecutive rows of ONE source (activation rows, or ring slots that do not wrap), none past kp_hi -
+  // needs no per-lane selection at all: a wave-uniform base (row of the tile's first key) on the scalar side, one multiply-add
+  // per lane for (key in tile, 16-byte column) and the loads.  The general path above costs ~110 VALU + ~80 SALU
+  // instructions per tile (divergent selects, v_mul_lo_u32, a scalar modulo) - 40 % of the loop's VALU issue - and stays for
+  // the tiles that straddle the ring / activation seam, wrap, or end at kp_hi.  The ring slot of a tile's first key is
+  // carried from tile to tile (gload is called with it = 0, 1, 2, ... in order) instead of a modulo per tile.
+  int ld_slot = __builtin_amdgcn_readfirstlane(kp_lo % W);
+  auto gload = [&](int it) {
+    const int t_lo = kp_lo + it * KT;
+    const int slot_lo = ld_slot;
+    ld_slot += KT;
+    if (ld_slot >= W) ld_slot -= W;  // (exact when W >= KT; the !big_w path does not use it)
+    const bool all_act = t_lo >= p_b;
+    const bool all_ring = t_lo + KT - 1 < p_b && slot_lo + KT - 1 < W;
+    if (big_w && t_lo + KT - 1 <= kp_hi && (all_act || all_ring)) {
+      const int stride = all_act ? a.ld : ring_stride;
+      const size_t first = all_act ? (size_t)(row0 + t_lo - p_b) * a.ld : (size_t)slot_lo * ring_stride;
+      const bf16_t* kb = (all_act ? act_k0 : ring_k0) + first;
+      const bf16_t* vb = (all_act ? act_v0 : ring_v0) + first;
+      const uint32_t ko = (uint32_t)(k_key0 * stride + k_slot * 8);
+      const uint32_t vo = (uint32_t)(v_kg * KPT * stride + v_ds * 8);
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        rk[j] = ld16(kb + (size_t)((NT / 16) * j) * stride + ko);
+        rv[j] = ld16(vb + (size_t)j * stride + vo);
+      }
+    } else if (big_w) {
+      gload_impl(it, std::true_type{});
+    } else {
+      gload_impl(it, std::false_type{});
+    }
+  };
+#else
   auto gload = [&](int it) {  // one scalar branch per tile instead of one per load
     if (big_w) gload_impl(it, std::true_type{});
     else gload_impl(it, std::false_type{});
   };
-  auto lstore = [&](char* buf) {
-    char* Ks = buf;
-    char* Vt = buf + KS_BYTES;
+#endif
+  auto lstore = [&](char* Ks, char* Vt) {
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int key = k_key0 + (NT / 16) * j;
       st16(Ks + key * (DH * 2) + ((k_slot ^ (key & 15)) << 4), rk[j]);
     }
+    // byte offset of this thread's first key inside a V^T row (ATT_VB128: quads of a 16-key group in the order 0, 2, 1, 3)
+    const int vk0 = v_kg * KPT;
+    const int v_pos = ATT_VB128 ? ((vk0 & ~15) | (((vk0 >> 2) & 1) << 3) | (((vk0 >> 3) & 1) << 2) | (vk0 & 3)) * 2 : vk0 * 2;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       // d = v_ds*8 + 2c (low halves) and 2c+1 (high halves); KPT keys packed per row
@@ -192,26 +253,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
         lo[1] = (rv[2][c] & 0xffffu) | (rv[3][c] << 16);
         hi[0] = (rv[0][c] >> 16) | (rv[1][c] & 0xffff0000u);
         hi[1] = (rv[2][c] >> 16) | (rv[3][c] & 0xffff0000u);
-        *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_kg * 8) = lo;
-        *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_kg * 8) = hi;
+        *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_pos) = lo;
+        *reinterpret_cast<u32x2*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_pos) = hi;
       } else {
         const uint32_t lo = (rv[0][c] & 0xffffu) | (rv[1][c] << 16);
         const uint32_t hi = (rv[0][c] >> 16) | (rv[1][c] & 0xffff0000u);
-        *reinterpret_cast<uint32_t*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_kg * 4) = lo;
-        *reinterpret_cast<uint32_t*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_kg * 4) = hi;
+        *reinterpret_cast<uint32_t*>(Vt + (v_ds * 8 + 2 * c) * VT_STRIDE + v_pos) = lo;
+        *reinterpret_cast<uint32_t*>(Vt + (v_ds * 8 + 2 * c + 1) * VT_STRIDE + v_pos) = hi;
       }
     }
   };
 
   // Split staging (guide T14) into a double-buffered LDS image: tile it+1's global loads are issued before tile it's
-  // math and sit in registers (rk/rv) until the math is done; they are then written to the other buffer - whose last
+  // math and sit in registers (rk/rv) until the math is done; they are then written to the OTHER buffer - whose last
   // readers passed the barrier that ended tile it-1 - and the barrier that ends tile it publishes them.
   gload(0);
-  lstore(smem);
+  lstore(smem, smem + KS_BYTES);
   __syncthreads();
   if (ATT_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(1);
+#if ATT_TRACE == 2
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#define ATT_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define ATT_STAMP(i)
+#endif
   for (int it = 0; it < n_tiles; ++it) {
     if (it + 1 < n_tiles) gload(it + 1);
+    ATT_STAMP(0)
     const char* Ks = smem + (it & 1) * BUF_BYTES;
     const char* Vt = Ks + KS_BYTES;
 
@@ -249,6 +317,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
             st[mb] = ATTN_MFMA(kf[k4][mb], qf[kh * 4 + k4], st[mb], 0, 0, 0);
         if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       }
+      ATT_STAMP(1)
       // ---- mask, online softmax (this lane: query ql, keys of its half).  Scores stay RAW (unscaled): the
       // 1/sqrt(d) * log2(e) factor is folded into the exponent's fma, p = exp2(s * sc - m * sc).
       const bool full = a.causal ? (t_hi <= qp_w_lo && t_lo > qp_w_hi - W && t_lo + KT - 1 <= kp_hi) : (t_lo + KT - 1 <= kp_hi);
@@ -288,6 +357,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
       }
+      ATT_STAMP(2)
       const float nm = -m_run * sc;
       float psum = 0.f;
       uint32_t pb[2][2][4];
@@ -309,22 +379,49 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
         for (int kb = 0; kb < 2; ++kb) {
           u32x4 pw = {pb[mb][kb][0], pb[mb][kb][1], pb[mb][kb][2], pb[mb][kb][3]};
           const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-          const int kbase = mb * 32 + kb * 16 + 4 * hf;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            const char* vrow = Vt + (dt * 32 + ql) * VT_STRIDE + kbase * 2;
+#if ATT_VB128
+            const u32x4 vw = *reinterpret_cast<const u32x4*>(Vt + (dt * 32 + ql) * VT_STRIDE + (mb * 32 + kb * 16 + 8 * hf) * 2);
+#else
+            const char* vrow = Vt + (dt * 32 + ql) * VT_STRIDE + (mb * 32 + kb * 16 + 4 * hf) * 2;
             const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
             const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
-            u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
+            const u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
+#endif
             acc[dt] = ATTN_MFMA(__builtin_bit_cast(bf16x8, vw), pf, acc[dt], 0, 0, 0);
           }
         }
       if (ATT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
-    if (it + 1 < n_tiles) lstore(smem + ((it + 1) & 1) * BUF_BYTES);
+    ATT_STAMP(3)
+    if (it + 1 < n_tiles) lstore(smem + ((it + 1) & 1) * BUF_BYTES, smem + ((it + 1) & 1) * BUF_BYTES + KS_BYTES);
+    ATT_STAMP(4)
     __syncthreads();
+    ATT_STAMP(5)
   }
+#if ATT_TRACE == 2
+  if (lane == 0 && (wid == 0 || wid == 7)) {
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (bid < 1024)
+      for (int i = 0; i < 6; ++i) g_attn_trace[4096 * 4 + (bid * 2 + (wid ? 1 : 0)) * 6 + i] = ph[i];
+  }
+#endif
 
+#if ATT_TRACE
+  if (tid == 0) {
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (bid < 16384) {
+      unsigned hw = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_attn_trace[bid * 4 + 0] = tr_t0;
+      g_attn_trace[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+      g_attn_trace[bid * 4 + 2] = ((unsigned long long)xcc << 32) | hw;
+      g_attn_trace[bid * 4 + 3] = (unsigned long long)n_tiles;
+    }
+  }
+#endif
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*128 + d]
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);  // (once per block: not worth a permlane)
   if (wave_active && qi < s_b) {
@@ -347,7 +444,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_prefill_kernel(
 
 template <int NW>
 static hipError_t launch_nw(const AttnPrefillArgs& a, hipStream_t s) {
-  // 2 x 33 KiB of dynamic LDS: above the 64 KiB default limit.  The opt-in is per function AND per device.
+  // 2 x 34 KiB of dynamic LDS: above the 64 KiB default limit.  The opt-in is per function AND per device.
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -375,8 +472,10 @@ hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
     const char* e = getenv("MI_ATTN_PREFILL_WAVES");
     force = e ? atoi(e) : 0;
   }
-  // 256-query blocks once they still give every CU a block (one 8-wave block per CU), else 128-query blocks
+  // 256-query blocks (one 8-wave block per CU) once they come in at least two rounds of the chip, else 128-query blocks (two
+  // 4-wave blocks per CU, each other's prologue / epilogue cover): 2048 tokens x 32 heads = one round of 256-query blocks
+  // measured 75.9 us, as 128-query blocks 70.6; 4096 tokens (two rounds) 180 against 183 (round 6, scripts/attn_prefill_probe.py)
   const long blocks8 = (long)((a.max_q_len + 255) / 256) * a.H * (a.causal ? a.B : 1);
-  const bool eight = force ? force == 8 : blocks8 >= device_cus();
+  const bool eight = force ? force == 8 : blocks8 >= 2 * device_cus();
   return eight ? launch_nw<8>(a, s) : launch_nw<4>(a, s);
 }

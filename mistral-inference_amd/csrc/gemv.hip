@@ -60,10 +60,11 @@ namespace {
 
 using namespace gemv_core;
 
-template <int TT, int MODE, int ROWS>
+// DMA: the activation rows go to LDS by LDS-DMA (gemv_core.cuh; instantiated for 2..8 tokens, picked when they do not fit the registers)
+template <int TT, int MODE, int ROWS, bool DMA>
 __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemv_body<TT, MODE, ROWS>(a, smem, blockIdx.x, gridDim.x, blockIdx.y);
+  gemv_body<TT, MODE, ROWS, DMA>(a, smem, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // MoE down-projection + combine for one token per blockIdx.y (moe.py:28-32 at decode):
@@ -131,16 +132,15 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
       }
     }
   };
+  // stage the TOPK hidden rows of this token (rows of a.x are [T*TOPK, K], slot-major per token) by LDS-DMA, one row per sorted
+  // position: all pieces in flight at once (it was a load -> store loop of K / 2048 L2 round trips), issued BEFORE the two weight
+  // batches so that vmcnt(16) = "the rows have landed" leaves the weights in flight
+#pragma unroll
+  for (int k = 0; k < TOPK; ++k)
+    dma_rows_to_lds(a.x + ((size_t)t * TOPK + slot_of[k]) * a.ldx, 0, 1, 1, a.K >> 3, reinterpret_cast<char*>(xs + (size_t)k * a.K));
   issue(bufA);
   issue(bufB);
-  // stage the TOPK hidden rows of this token (rows of a.x are [T*TOPK, K], slot-major per token)
-  for (int p = tid; p < (a.K >> 3) * TOPK; p += 256) {
-    const int k = p / (a.K >> 3), pp = p % (a.K >> 3);
-    int so = slot_of[0];
-#pragma unroll
-    for (int kk = 1; kk < TOPK; ++kk) so = (k == kk) ? slot_of[kk] : so;
-    st16(xs + (size_t)k * a.K + pp * 8, ld16(a.x + ((size_t)t * TOPK + so) * a.ldx + pp * 8));
-  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __syncthreads();
 
   Acc<1> acc;
@@ -179,31 +179,41 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
   }
 }
 
-template <int TT, int MODE, int ROWS>
+template <int TT, int MODE, int ROWS, bool DMA>
 hipError_t launch_tt(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024) {  // more than the default dynamic-LDS limit: an opt-in per function AND per device
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<TT, MODE, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<TT, MODE, ROWS, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)GEMV_LDS_BUDGET + 1024);
       if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((gemv_kernel<TT, MODE, ROWS>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gemv_kernel<TT, MODE, ROWS, DMA>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
+}
+// Rows that fit the prologue's register set (gemv_core.cuh: 4 x 256 pieces with a fused RMSNorm, 8 x 256 without) are staged
+// through registers; 2..8 rows that do not, by LDS-DMA.
+template <int TT, int MODE, int ROWS>
+hipError_t launch_stage(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if constexpr (TT > 1) {
+    constexpr bool norm_mode = MODE == GEMV_QKV_ROPE || MODE == GEMV_SWIGLU || MODE == GEMV_LOGITS || MODE == GEMV_MOE_W13;  // (gemv_body's kNormMode)
+    if ((size_t)TT * (a.K >> 3) > (norm_mode ? 4u : 8u) * 256u) return launch_tt<TT, MODE, ROWS, true>(a, grid, lds, s);
+  }
+  return launch_tt<TT, MODE, ROWS, false>(a, grid, lds, s);
 }
 template <int MODE, int ROWS>
 hipError_t launch_mode(const GemvArgs& a, int TT, dim3 grid, size_t lds, hipStream_t s) {
   switch (TT) {
-    case 1: return launch_tt<1, MODE, ROWS>(a, grid, lds, s);
-    case 2: return launch_tt<2, MODE, ROWS>(a, grid, lds, s);
-    case 3: return launch_tt<3, MODE, ROWS>(a, grid, lds, s);
-    case 4: return launch_tt<4, MODE, ROWS>(a, grid, lds, s);
-    case 6: return launch_tt<6, MODE, ROWS>(a, grid, lds, s);
-    default: return launch_tt<8, MODE, ROWS>(a, grid, lds, s);
+    case 1: return launch_stage<1, MODE, ROWS>(a, grid, lds, s);
+    case 2: return launch_stage<2, MODE, ROWS>(a, grid, lds, s);
+    case 3: return launch_stage<3, MODE, ROWS>(a, grid, lds, s);
+    case 4: return launch_stage<4, MODE, ROWS>(a, grid, lds, s);
+    case 6: return launch_stage<6, MODE, ROWS>(a, grid, lds, s);
+    default: return launch_stage<8, MODE, ROWS>(a, grid, lds, s);
   }
 }
 
@@ -264,7 +274,8 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
   if (a.mode == GEMV_MOE_W13) TT = 1;
   if (TT == 5) TT = 6;
   if (TT == 7) TT = 8;
-  const size_t lds = (size_t)TT * a.K * 2 + 4 * TT * sizeof(float);
+  // [TT][K] activations, 4 x TT partial sums, and (norm modes at TT > 1: the DMA staging path of gemv_core.cuh) K norm weights
+  const size_t lds = (size_t)TT * a.K * 2 + 4 * TT * sizeof(float) + ((TT > 1 && a.norm_w) ? (size_t)a.K * 2 : 0);
   if (lds > 80 * 1024 && blocks > cus) {  // one such block fits a CU: one block per CU, every wave the same number of units
     const int k = (units + 4 * cus - 1) / (4 * cus);
     blocks = (units + 4 * k - 1) / (4 * k);

@@ -68,11 +68,50 @@ struct XRegs {
   u32x4 w[NW > 0 ? NW : 1];
 };
 
-// Issues exactly NX + NW loads (clamped / dummy where there is nothing to load).
-template <int TT, int NX, int NW>
-__device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w) {
+// Activations that do not fit the register set (batches of >= 3 tokens; W2 rows of >= 2 tokens) go to LDS by LDS-DMA
+// (global_load_lds_dwordx4: a wave-instruction moves 64 consecutive 16-byte pieces, no registers, all of them in flight at
+// once), the norm weights behind them; x_finish waits ONCE and runs the RMSNorm passes on LDS.  Before round 6 this case was
+// a load -> wait -> store loop per 256 pieces: up to 21 dependent L2 round trips in front of the first FMA of every GEMV of a
+// batch-3 decode step (q|k|v 19.3 us against 13.0 at batch 1).  Piece q of `rows` rows goes to dst + q * 16; rows >= T are zeros.
+__device__ __forceinline__ void dma_rows_to_lds(const bf16_t* src, int ld, int rows, int T, int npieces, char* dst) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int total = rows * npieces;
+  for (int q0 = wid * 64; q0 < total; q0 += 256) {
+    const int q = q0 + lane;
+    const int t = q / npieces, pc = q - t * npieces;
+    if (q < total) {
+      if (t < T) {
+        // from inline asm (M0 = the wave's LDS base, saved and restored): hipcc does not track it, so it neither drains the
+        // weight loads at the prologue's barriers (as it does behind the builtin) nor counts it - the waits behind these DMAs are
+        // the caller's (x_finish: vmcnt(16) with exactly the two weight batches issued after them)
+        unsigned keep;
+        const bf16_t* sp = src + (size_t)t * ld + pc * 8;
+        const uint32_t lds_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(dst + (size_t)q0 * 16);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sp), "s"(lds_addr) : "memory");
+      } else {
+        st16(dst + (size_t)q * 16, u32x4{0u, 0u, 0u, 0u});
+      }
+    }
+  }
+}
+
+// Issues exactly NX + NW loads (clamped / dummy where there is nothing to load); when the rows do not fit them, the DMAs above.
+// xs: the LDS image [TT][K]; ws: K norm weights behind it (used by the DMA path of the norm modes only).
+// DMA is a property of the INSTANTIATION (launch_gemv picks it when the rows cannot fit the registers): with an LDS-DMA anywhere in
+// a function hipcc waits vmcnt(0) at every barrier and gives up the counted waits of the register path.
+template <int TT, int NX, int NW, bool DMA>
+__device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w, bf16_t* xs,
+                                        bf16_t* ws) {
   const int npieces = K >> 3;
   const int total = TT * npieces;
+  if constexpr (DMA) {
+    dma_rows_to_lds(x, ldx, TT, T, npieces, reinterpret_cast<char*>(xs));
+    if (norm_w) dma_rows_to_lds(norm_w, 0, 1, 1, npieces, reinterpret_cast<char*>(ws));
+    return false;
+  }
   const bool fits = total <= NX * 256 && (norm_w == nullptr || total <= NW * 256);
   const bf16_t* wsrc = norm_w ? norm_w : x;
 #pragma unroll
@@ -85,8 +124,8 @@ __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int 
   return fits;
 }
 
-template <int TT, int NX, int NW>
-__device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red,
+template <int TT, int NX, int NW, bool DMA>
+__device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red, const bf16_t* ws,
                                          const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w, float eps) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int npieces = K >> 3;
@@ -113,6 +152,27 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t
         if (!norm_w) st16(xs + (size_t)q * 8, xr.x[i]);  // [t][K] row-major == q * 8
       }
     }
+  } else if constexpr (DMA) {
+    // the rows (and norm weights) were sent to LDS by x_issue's DMAs.  vmcnt retires in order and EXACTLY the two weight batches
+    // (2 x BATCH unconditional loads: gemv_body) were issued behind them: vmcnt(2 * BATCH) = the DMAs have landed, the weights
+    // stay in flight under the passes below, which read LDS only.
+    static_assert(BATCH == 8, "the wait below counts the two weight batches");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+    if (norm_w != nullptr) {
+      for (int p = tid; p < npieces; p += 256) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + p * 8);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float a = bf_lo(v[c]), b = bf_hi(v[c]);
+            ss[t] = fmaf(a, a, ss[t]);
+            ss[t] = fmaf(b, b, ss[t]);
+          }
+        }
+      }
+    }
   } else {
     for (int p = tid; p < npieces; p += 256) {
 #pragma unroll
@@ -131,7 +191,7 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t
     }
   }
   if (norm_w == nullptr) {
-    __syncthreads();
+    if (!DMA) __syncthreads();  // (the DMA path has had its barrier)
     return;
   }
 #pragma unroll
@@ -168,7 +228,7 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t
     }
   } else {
     for (int p = tid; p < npieces; p += 256) {
-      const u32x4 wv = ld16(norm_w + p * 8);
+      const u32x4 wv = DMA ? *reinterpret_cast<const u32x4*>(ws + p * 8) : ld16(norm_w + p * 8);
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (size_t)t * K + p * 8);
@@ -211,10 +271,11 @@ __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf1
 // ROWS = rows per unit (2 everywhere except the plain/residual/logits modes on small N, where single-row units
 // double the number of waves so that a 4096-row matrix still fills 256 CUs x 16 waves).
 // Order: activation loads first (L2 hits), then two weight batches, and the prologue finishes under them.
-template <int TT, int MODE, int ROWS>
+template <int TT, int MODE, int ROWS, bool DMA>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int block_id, int n_blocks, int problem) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)TT * a.K * 2);
+  bf16_t* ws = reinterpret_cast<bf16_t*>(smem + (size_t)TT * a.K * 2 + 16 * TT);  // (launch_gemv reserves it for TT > 1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: unit loops become scalar
   const int nwaves = n_blocks * 4;
@@ -243,7 +304,18 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   constexpr int NX = kNormMode ? 4 : 8, NW = kNormMode ? 4 : 0;
   XRegs<NX, NW> xr;
   bool in_regs = false;
-  in_regs = x_issue<TT, NX, NW>(xr, x, a.ldx, T, a.K, a.norm_w);
+  // q|k|v epilogue operands that depend on nothing: the token's position (RoPE row, ring slot) and its sequence (ring row) are the
+  // FIRST loads of the wave.  Loaded behind the weight batches (rounds 1-6), the position - which the first RoPE prefetch needs
+  // for its address - made hipcc wait vmcnt(0) in front of the first FMA: both weight batches drained, then two dependent L2
+  // round trips (position, RoPE entry), and a third per unit for the sequence in the epilogue.  As the oldest loads they are
+  // waited for with a counted vmcnt that leaves the weights in flight.
+  const int tl = lane < T ? lane : 0;
+  int ep_pos = 0, ep_seq = 0;
+  if (MODE == GEMV_QKV_ROPE) {
+    ep_pos = a.tok_pos[tl];
+    ep_seq = a.tok_seq ? a.tok_seq[tl] : tl;
+  }
+  in_regs = x_issue<TT, NX, NW, DMA>(xr, x, a.ldx, T, a.K, a.norm_w, xs, ws);
 
   // load cursor over the flattened (unit, batch) sequence of this wave: always two batches ahead of the math
   int u = block_id * 4 + wid;
@@ -269,7 +341,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   };
   issue(bufA);
   issue(bufB);
-  x_finish<TT, NX, NW>(in_regs, xr, xs, red, x, a.ldx, T, a.K, a.norm_w, a.eps);
+  x_finish<TT, NX, NW, DMA>(in_regs, xr, xs, red, ws, x, a.ldx, T, a.K, a.norm_w, a.eps);
 
   Acc<TT> acc;
 #pragma unroll
@@ -278,9 +350,6 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
 
   // Epilogue operands are fetched EARLY (token position once, the unit's RoPE entry / residual pair when the unit
   // starts) so that the end of a unit is arithmetic + one store instead of a chain of dependent loads.
-  const int tl = lane < T ? lane : 0;
-  int ep_pos = 0;
-  if (MODE == GEMV_QKV_ROPE) ep_pos = a.tok_pos[tl];
   float2 ep_cs = make_float2(1.f, 0.f);
   uint32_t ep_res = 0;
   auto prefetch_epilogue = [&](int uu) {
@@ -342,8 +411,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
             }
             if (a.write_kv && r0 >= a.n0) {  // cache.py:83-92: ring slot pos % W of this sequence's row
               const int kv_dim = a.n1 - a.n0;
-              const int seq = a.tok_seq ? a.tok_seq[t] : t;
-              const size_t off = kv_offset(a.kv_layout, a.W, kv_dim, a.head_dim, (size_t)seq, pos % a.W, (r0 < a.n1) ? r0 - a.n0 : r0 - a.n1);
+              const size_t off = kv_offset(a.kv_layout, a.W, kv_dim, a.head_dim, (size_t)ep_seq, pos % a.W, (r0 < a.n1) ? r0 - a.n0 : r0 - a.n1);
               bf16_t* ring = ((r0 < a.n1) ? reinterpret_cast<bf16_t*>(a.cache_k) : reinterpret_cast<bf16_t*>(a.cache_v)) + off;
               *reinterpret_cast<uint32_t*>(ring) = pack_bf2(y0, y1);
             }

@@ -75,6 +75,10 @@ FILE_VARIANTS = {
     "l_gemv_mmc": ("gemv.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
     "l_attn_mmc": ("attn_decode.hip", ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause")),
     "l_gemv_ilp": ("gemv.hip", ("-mllvm", "-amdgpu-sched-strategy=max-ilp")),
+    "a_vb0": ("attn_prefill.hip", ("-DATT_VB128=0",)),          # V^T fragments as two 8-byte reads (rounds 1-6)
+    "a_fast0": ("attn_prefill.hip", ("-DATT_FASTLOAD=0",)),    # every tile through the general staging path (rounds 1-5)
+    "a_trace2": ("attn_prefill.hip", ("-DATT_TRACE=2",)),      # + cycles per phase of waves 0 and 7
+    "a_trace": ("attn_prefill.hip", ("-DATT_TRACE=1",)),       # per-block timeline: scripts/attn_prefill_trace.py
     "a_prio1": ("attn_prefill.hip", ("-DATT_PRIO=1",)),
     "a_prio2": ("attn_prefill.hip", ("-DATT_PRIO=2",)),
     "g_abl_nodma": ("gemm256.hip", ("-DG256_ABL=1",)),      # timing ablations: WRONG results by construction
