@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
       r1 = bf_round(r1 + bf_round(w * bf_round(y1)));
       if (++kc == TOPK) {
         kc = 0;
-        if (lane == 0) {
+        if (lane == 0 && u < units) {
           const int n = 2 * u;
           const bf16_t* rs = a.residual + (size_t)t * a.ldo + n;
           bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (size_t)t * a.ldo + n;
@@ -173,9 +173,11 @@ __global__ __launch_bounds__(256) void moe_w2_kernel(GemvArgs a) {
       }
     }
   };
-  while (u < units) {
-    step(bufA);
-    if (u < units) step(bufB);
+  if (u < units) {  // both steps per trip: see gemv_core.cuh (a step past the last unit stores nothing)
+    do {
+      step(bufA);
+      step(bufB);
+    } while (u < units);
   }
 }
 

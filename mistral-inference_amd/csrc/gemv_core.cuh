@@ -435,14 +435,20 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
     issue(buf);
     if (++jc == nb) {
       jc = 0;
-      finish_unit();
+      if (u < units) finish_unit();
       u += nwaves;
       if (u < units) prefetch_epilogue(u);
     }
   };
-  while (u < units) {
-    step(bufA);
-    if (u < units) step(bufB);
+  // ALWAYS both steps per trip (a step past the wave's last unit multiplies dummy lines and stores nothing).  With the second
+  // step under `if (u < units)` - rounds 1-6 - hipcc's wait-count pass merged the skip edge into the loop header and guarded
+  // the FIRST step's operands with vmcnt(6..0) instead of vmcnt(14..8): every trip drained both batches before its first FMA
+  // and the "two batches in flight" of the design was one.
+  if (u < units) {
+    do {
+      step(bufA);
+      step(bufB);
+    } while (u < units);
   }
 }
 

@@ -89,23 +89,33 @@ class TorchDistComm:
     """The reference's own transport (torch.distributed send / recv / broadcast): CPU tests over gloo, and the fallback
     selected with MI_PP_TRANSPORT=torch."""
 
+    @staticmethod
+    def _order_behind_stream(t: torch.Tensor) -> None:
+        """Test rigs only (ranks sharing one GPU over gloo): gloo reads and writes a device tensor from the host without ordering
+        itself behind the stream that produces / still reads it, so a hop could pick up a hidden state its kernel had not finished
+        (round 6: run-to-run different log-probabilities in tests/test_gpu_pipeline.py, one 0.08 outlier).  The stream is drained
+        first; under NCCL (= RCCL) the transfer is stream-ordered and nothing is done here."""
+        if t.is_cuda and torch.distributed.get_backend() != "nccl":
+            torch.cuda.current_stream(t.device).synchronize()
+
     def send(self, t: torch.Tensor, dst: int) -> None:
+        self._order_behind_stream(t)
         torch.distributed.send(t, dst=dst)
 
     def recv(self, t: torch.Tensor, src: int) -> None:
+        self._order_behind_stream(t)
         torch.distributed.recv(t, src=src)
 
     def broadcast(self, t: torch.Tensor, src: int) -> None:
+        self._order_behind_stream(t)
         torch.distributed.broadcast(t, src=src)
 
     def exchange(self, send_t: Optional[torch.Tensor], dst: int, recv_t: Optional[torch.Tensor], src: int) -> None:
         """Grouped send + recv (`batch_isend_irecv`: one NCCL group on a GPU, two non-blocking requests over gloo)."""
         dist = torch.distributed
         t = send_t if send_t is not None else recv_t
-        if t is not None and t.is_cuda and dist.get_backend() != "nccl":
-            # test rigs only (two ranks sharing one GPU over gloo): gloo moves device tensors without ordering itself behind the
-            # stream that produces them - the data of this tick must be complete before it is read
-            torch.cuda.current_stream(t.device).synchronize()
+        if t is not None:
+            self._order_behind_stream(t)
         ops = []
         if send_t is not None:
             ops.append(dist.P2POp(dist.isend, send_t, dst))

@@ -93,9 +93,14 @@ def test_two_stage_pipeline_on_hip(name, backend, transport, tmp_path):
     assert comm0 == comm1 == ("RcclComm" if transport == "rccl" else "TorchDistComm")
     for b, (mine, ref) in enumerate(zip(t0, ref_toks)):
         n = next((i for i, (x, y) in enumerate(zip(mine, ref)) if x != y), len(ref))
-        assert n >= 1, (name, b, mine, ref)
+        # every greedy token of the reference (round 6: the gloo hops of this rig are ordered behind the producing stream -
+        # distributed.TorchDistComm; before, a stage could read a hidden state its kernel had not finished and the sequences
+        # left the reference's after 2-3 tokens, differently from run to run)
+        assert n == len(ref), (name, b, mine, ref)
         npl = len(case.prompts[b]) - 1 + n
-        assert max(abs(x - y) for x, y in zip(lp0[b][:npl], ref_lps[b][:npl])) <= 6e-2
+        dev = max(abs(x - y) for x, y in zip(lp0[b][:npl], ref_lps[b][:npl]))
+        print(f"{name} [{backend}/{transport}] sequence {b}: tokens agree for {n}/{len(ref)}, max |logprob - reference| {dev:.4f} over {npl}", flush=True)
+        assert dev <= 6e-2
 
 
 def test_bench_two_ranks_prints_one_json_line():
