@@ -20,3 +20,10 @@ MI_DECODE_ENGINE=0 python bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-
 timeout 300 python scripts/engine_trace.py > gpurun_out/engine_trace.log 2>&1; tail -48 gpurun_out/engine_trace.log | tee -a $LOG
 timeout 300 python scripts/engine_trace.py --model mixtral-8x7b --layers 8 > gpurun_out/engine_trace_8x7b.log 2>&1
 timeout 300 python scripts/engine_trace.py --model mixtral-8x22b --layers 7 > gpurun_out/engine_trace_8x22b_stage7.log 2>&1
+# round 6 additions: batch 2-4 lines, the batch-3 kernel table, the prefill attention probe + scaling
+for b in 3 2 4; do python bench.py --batch $b --steps 32 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | tail -1 | tee gpurun_out/bench_batch$b.json.log | cut -c1-300 | tee -a $LOG; done
+export TMPDIR=/tmp; REPO=$PWD; rm -rf gpurun_out/prof_b3
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_b3 -o decode -- python $REPO/bench.py --batch 3 --steps 16 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/prof_b3.log 2>&1)
+find gpurun_out/prof_b3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats_batch3.csv
+find gpurun_out/prof_b3 -name "*kernel_trace.csv" -delete
+python scripts/attn_prefill_probe.py 5 2>&1 | grep -v amdgpu.ids | tee gpurun_out/attn_prefill_probe.log | tee -a $LOG

@@ -50,7 +50,7 @@ with open(os.path.join(PROF, f"{tag}_pmc_fetch_write_size.csv"), "w") as f:
     f.write("kernel,counter,dispatches,mean_KiB,min_KiB,max_KiB\n")
     for k, c, n, m, lo, hi in rows:
         f.write(f'"{k}",{c},{n},{m:.1f},{lo:.1f},{hi:.1f}\n')
-dom = [k for k in per if "decode_engine_kernel" in k] or [k for k in per if "gemv_kernel<1, 2, 2>" in k]
+dom = [k for k in per if "decode_engine_kernel" in k] or [k for k in per if "gemv_kernel<1, 2, 2" in k]
 if dom:
     k = dom[0]
     fetch, write = per[k].get("FETCH_SIZE", 0.0), per[k].get("WRITE_SIZE", 0.0)
