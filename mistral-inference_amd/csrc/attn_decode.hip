@@ -117,6 +117,80 @@ __global__ __launch_bounds__(256, SMALL ? 3 : 1) void attn_decode_kernel(AttnDec
   }
 }
 
+// ALL-IN form (round 6; batches of >= 3 sequences on rings of <= 4096 slots: 128 slots per block = 8 per lane group): the block's
+// whole K/V share - 16 loads per lane - is issued at once and the query heads are served in passes of two over the SAME registers
+// (heads do not interact in reduce_slot, a lane group still visits its slots in ascending order: bit-identical results).  The
+// SMALL form above walks the same slots in four dependent steps with two in flight: three memory round trips where this has
+// one (batch 3: 16.9 us per layer for 50 MB).  Fits 3 blocks per CU.
+template <int R>
+__global__ __launch_bounds__(256, 3) void attn_decode_allin_kernel(AttnDecodeArgs a) {
+  static_assert(R == 2 || R == 4, "passes of two query heads");
+  __shared__ float sm_m[4 * R];
+  __shared__ float sm_l[4 * R];
+  __shared__ float sm_acc[4 * R * DH];
+  constexpr int NS = 8;  // slots per lane group: 4 waves x 4 groups x 8 = 128 slots per block
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, dl = lane & 15;
+  const int kvh = blockIdx.x % a.Hkv, split = blockIdx.x / a.Hkv, b = blockIdx.y;
+  const int pos = a.tok_pos[b];
+  const int kv_len = min(pos + 1, a.W);
+  const int chunk = split_chunk(a.W, a.n_splits);  // <= 128 (launch_r)
+  const int s_begin = split * chunk;
+  const int s_end = min(s_begin + chunk, kv_len);
+
+  u32x4 qraw[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) qraw[r] = ld16(a.q + (size_t)b * a.ldq + (size_t)(kvh * R + r) * DH + dl * 8);
+
+  const int kv_real = kvh / a.kv_groups;
+  const int hkv_real = a.Hkv / a.kv_groups;
+  const size_t row_stride = a.kv_layout ? (size_t)DH : (size_t)hkv_real * DH;
+  const size_t ring0 = kv_offset(a.kv_layout, a.W, hkv_real * DH, DH, (size_t)b, 0, kv_real * DH) + dl * 8;
+  const bf16_t* kbase = a.cache_k + ring0;
+  const bf16_t* vbase = a.cache_v + ring0;
+  const int s_first = s_begin + wid * 4 + g;
+  const int s_clamp = max(kv_len - 1, 0);
+  u32x4 kk[NS], vv[NS];  // ALWAYS 2 * NS unconditional loads (slots past the block's range: clamped, masked below)
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int sl = min(s_first + 16 * j, s_clamp);
+    kk[j] = ld16_nt(kbase + (size_t)sl * row_stride);
+    vv[j] = ld16_nt(vbase + (size_t)sl * row_stride);
+  }
+#pragma unroll
+  for (int rp = 0; rp < R; rp += 2) {
+    if (rp > 0) {  // the passes run one after the other on the RAW rows: shared, hipcc keeps every row's 16 converted floats live (145 spills)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) asm volatile("" : "+v"(kk[j]), "+v"(vv[j]));
+    }
+    float qf[2][8];
+    const u32x4 qpair[2] = {qraw[rp], qraw[rp + 1]};
+    load_q<2>(qf, qpair);
+    State<2> st;
+    init_state<2>(st);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) reduce_slot<2>(st, qf, kk[j], vv[j], (s_first + 16 * j) < s_end);
+    wave_state_to_lds_heads<2, R>(st, wid, lane, rp, sm_m, sm_l, sm_acc);
+  }
+  __syncthreads();
+
+  const int bh = b * a.Hkv + kvh;
+  float* p_acc = a.partial + ((size_t)bh * a.n_splits + split) * R * DH;
+  float* p_ml = a.partial + (size_t)a.B * a.Hkv * a.n_splits * R * DH + ((size_t)bh * a.n_splits + split) * R * 2;
+  for (int idx = tid; idx < R * DH; idx += 256) {
+    float A, M, L;
+    split_partial<R>(idx, sm_m, sm_l, sm_acc, A, M, L);
+    p_acc[idx] = A;
+    if (idx % DH == 0) {
+      p_ml[(idx / DH) * 2] = M;
+      p_ml[(idx / DH) * 2 + 1] = L;
+    }
+  }
+}
+
 // Second launch: one block per (sequence, q head), one thread per output element.  All of a
 // thread's loads (the head's (m, l) pairs - same address across the block, so one transaction each - and its own
 // accumulator column) are independent and issued together: one memory round trip instead of a chain.
@@ -143,8 +217,20 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(AttnDecodeArgs
 template <int R>
 void launch_r(const AttnDecodeArgs& a, hipStream_t s) {
   dim3 grid(a.n_splits * a.Hkv, a.B), block(256);
+  static int allin = -1;  // MI_ATTN_ALLIN=0: the stepping form for batches >= 3 (A/B testing)
+  if (allin < 0) {
+    const char* e = getenv("MI_ATTN_ALLIN");
+    allin = e ? atoi(e) : 1;
+  }
+  if constexpr (R == 2 || R == 4) {
+    if (a.B >= 3 && allin && attn_core::split_chunk(a.W, a.n_splits) <= 128) {
+      hipLaunchKernelGGL((attn_decode_allin_kernel<R>), grid, block, 0, s, a);
+      goto combine;
+    }
+  }
   if (R <= 4 && a.B >= 3) hipLaunchKernelGGL((attn_decode_kernel<R, (R <= 4)>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((attn_decode_kernel<R, false>), grid, block, 0, s, a);
+combine:
   if (a.n_splits <= 16) hipLaunchKernelGGL((attn_decode_combine_kernel<16>), dim3(a.H, a.B), dim3(128), 0, s, a);
   else hipLaunchKernelGGL((attn_decode_combine_kernel<32>), dim3(a.H, a.B), dim3(128), 0, s, a);  // n_splits <= 32
 }
