@@ -171,7 +171,41 @@ __global__ __launch_bounds__(1024) void greedy_rows_kernel(const float* logits, 
   const float* row = logits + (size_t)b * ld;
   float M = -INFINITY, S = 0.f;
   int I = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += 1024) {  // ascending indices per thread: `>` keeps the first maximum
+  int i0 = threadIdx.x;
+  if ((V & 3) == 0 && (reinterpret_cast<size_t>(row) & 15) == 0) {
+    // 16 logits per trip from four independent 16-byte loads (round 6: the scalar loop below was one dependent 4-byte load per
+    // trip - V / 1024 L2 round trips: 46.6 us per step at Mistral-Nemo's 131072 logits, 14.4 at 32768).  Ascending indices per
+    // thread, `>` on the trip's maximum and the first position holding it: the FIRST maximum, as before.
+    const int V4 = V >> 2;
+    for (int q = threadIdx.x; q < V4; q += 4096) {
+      float x[16];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int qk = q + k * 1024;
+        const float4 v = *reinterpret_cast<const float4*>(row + (size_t)min(qk, V4 - 1) * 4);  // (unconditional load, masked value)
+        const bool in = qk < V4;
+        x[4 * k + 0] = in ? v.x : -INFINITY;
+        x[4 * k + 1] = in ? v.y : -INFINITY;
+        x[4 * k + 2] = in ? v.z : -INFINITY;
+        x[4 * k + 3] = in ? v.w : -INFINITY;
+      }
+      float cm = x[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) cm = fmaxf(cm, x[e]);
+      if (cm > M) {
+        S *= __expf(M - cm);  // (M = -inf at the start: exp(-inf) = 0 and S = 0)
+        M = cm;
+        int first = 15;
+#pragma unroll
+        for (int e = 14; e >= 0; --e) first = (x[e] == cm) ? e : first;
+        I = (q + (first >> 2) * 1024) * 4 + (first & 3);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S += __expf(x[e] - M);
+    }
+    i0 = V;  // nothing left for the scalar loop
+  }
+  for (int i = i0; i < V; i += 1024) {  // ascending indices per thread: `>` keeps the first maximum
     const float x = row[i];
     if (x > M) {
       S = S * __expf(M - x) + 1.f;
