@@ -164,6 +164,34 @@ struct Sel {
   uint32_t key, cnt;
   unsigned long long above;
 };
+// Every logit of the row once, in no particular order across threads: 16 values per trip from four independent 16-byte
+// loads (round 6: each pass was a loop of one 4-byte load per trip - V / 1024 dependent L2 round trips; a draw at 32768
+// logits 110 -> 79 us, at 131072 364 -> 240 us.  What remains are ~9 passes of ONE block over the row - at 131072 logits a
+// CU's L2 read of 512 KB per pass - with ~8 block barriers each; timing ablations: the histogram's LDS atomics as plain adds, or
+// spread over lane-dependent bins (no same-address contention), changed nothing, and fusing the total-mass pass into the
+// first histogram pass did not either).
+template <class F>
+__device__ __forceinline__ void for_logits(const Row& r, F&& f) {
+  if ((r.V & 3) == 0 && (reinterpret_cast<size_t>(r.x) & 15) == 0) {
+    const int V4 = r.V >> 2;
+    for (int q = threadIdx.x; q < V4; q += 4 * ST) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(r.x + (size_t)min(q + k * ST, V4 - 1) * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (q + k * ST < V4) {
+          f(v[k].x);
+          f(v[k].y);
+          f(v[k].z);
+          f(v[k].w);
+        }
+    }
+  } else {
+    for (int i = threadIdx.x; i < r.V; i += ST) f(r.x[i]);
+  }
+}
+
 __device__ Sel select_pos(const Row& r, uint32_t lo, uint32_t hi, unsigned long long target, uint32_t cnt0, Scratch& sc) {
   unsigned long long above = 0;  // mass of all keys > hi
   uint32_t cnt = cnt0;           // tokens tied at lo when the range is a single key already
@@ -178,15 +206,14 @@ __device__ Sel select_pos(const Row& r, uint32_t lo, uint32_t hi, unsigned long 
       sc.cnt[i] = 0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < r.V; i += ST) {
-      const float xv = r.x[i];
+    for_logits(r, [&](float xv) {
       const uint32_t k = key_of(xv);
       if (k >= lo && k <= hi) {
         const uint32_t b = (k - lo) >> shift;
         atomicAdd(&sc.mass[b], r.q(xv));
         atomicAdd(&sc.cnt[b], 1u);
       }
-    }
+    });
     __syncthreads();
     // thread t looks at bin nb - 1 - t (descending values): above(bin) = above + sum of the masses of higher bins
     const int t = threadIdx.x;
@@ -241,15 +268,14 @@ __global__ __launch_bounds__(ST) void sample_top_p_kernel(const float* logits, i
   // ---- pass 1: maxima and key range
   float M = -INFINITY;
   uint32_t klo = 0xffffffffu, khi = 0u;
-  for (int i = threadIdx.x; i < V; i += ST) {
-    const float xv = r.x[i];
+  for_logits(r, [&](float xv) {
     if (xv == xv) {
       M = fmaxf(M, xv);
       const uint32_t k = key_of(xv);
       klo = min(klo, k);
       khi = max(khi, k);
     }
-  }
+  });
   M = block_max(M, sc);
   block_minmax_u32(klo, khi, sc);
   if (klo > khi) {  // a row of NaN: nothing to draw from (torch.multinomial raises); token 0, logprob NaN
@@ -263,11 +289,10 @@ __global__ __launch_bounds__(ST) void sample_top_p_kernel(const float* logits, i
   // ---- pass 2: total mass (fixed point) and the log-sum-exp of the UNSCALED logits (generate.py:134)
   unsigned long long S = 0;
   float S1 = 0.f;
-  for (int i = threadIdx.x; i < V; i += ST) {
-    const float xv = r.x[i];
+  for_logits(r, [&](float xv) {
     S += r.q(xv);
     if (xv == xv) S1 += expf(xv - M);
-  }
+  });
   S = block_sum_u64(S, sc);
   S1 = block_sum_f(S1, sc);
   // ---- the nucleus: last position with mass-before <= p * total (generate.py:166 `probs_sum - probs_sort > p` is dropped)
@@ -303,7 +328,18 @@ __global__ __launch_bounds__(ST) void sample_top_p_kernel(const float* logits, i
   const int per = (V + ST - 1) / ST;
   const int i0 = threadIdx.x * per, i1 = min(V, i0 + per);
   unsigned long long mine = 0;
-  for (int i = i0; i < i1; ++i) mine += (key_of(r.x[i]) == pick.key);
+  if ((per & 15) == 0 && i1 - i0 == per && (reinterpret_cast<size_t>(r.x) & 15) == 0) {  // (whole, 16-byte aligned ranges)
+    for (int i = i0; i < i1; i += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(r.x + i + 4 * k);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        mine += (key_of(v[k].x) == pick.key) + (key_of(v[k].y) == pick.key) + (key_of(v[k].z) == pick.key) + (key_of(v[k].w) == pick.key);
+    }
+  } else {
+    for (int i = i0; i < i1; ++i) mine += (key_of(r.x[i]) == pick.key);
+  }
   unsigned long long total;
   const unsigned long long before = block_exscan_u64(mine, total, sc);
   rank = rank >= total ? total - 1ull : rank;  // (total >= 1: the key was found in the row)
