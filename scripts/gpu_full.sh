@@ -27,3 +27,4 @@ export TMPDIR=/tmp; REPO=$PWD; rm -rf gpurun_out/prof_b3
 find gpurun_out/prof_b3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats_batch3.csv
 find gpurun_out/prof_b3 -name "*kernel_trace.csv" -delete
 python scripts/attn_prefill_probe.py 5 2>&1 | grep -v amdgpu.ids | tee gpurun_out/attn_prefill_probe.log | tee -a $LOG
+python scripts/sampling_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/sampling_probe.log | tee -a $LOG
