@@ -67,6 +67,14 @@ __global__ __launch_bounds__(256, (TT == 1 ? 4 : (TT <= 3 ? 3 : 2))) void gemv_k
   gemv_body<TT, MODE, ROWS, DMA>(a, smem, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
+// Blocks of 5 .. 7 waves for the plain modes at one token (gemv_core.cuh NWV): row counts that 4-wave blocks cannot split evenly
+// over the CUs.
+template <int MODE, int NWV>
+__global__ __launch_bounds__(NWV * 64, 4) void gemv_kernel_nw(GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemv_body<1, MODE, 2, false, NWV>(a, smem, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
 // MoE down-projection + combine for one token per blockIdx.y (moe.py:28-32 at decode):
 // out[t] = bf16(h[t] + R),  R = sum over the token's experts in ascending id of bf16(w_e * bf16(W2_e . g_e)),
 // accumulated in bf16 starting from zero.
@@ -219,6 +227,17 @@ hipError_t launch_mode(const GemvArgs& a, int TT, dim3 grid, size_t lds, hipStre
   }
 }
 
+template <int MODE>
+hipError_t launch_nw(const GemvArgs& a, int nw, dim3 grid, size_t lds, hipStream_t s) {
+  switch (nw) {
+    case 5: hipLaunchKernelGGL((gemv_kernel_nw<MODE, 5>), grid, dim3(320), lds, s, a); break;
+    case 6: hipLaunchKernelGGL((gemv_kernel_nw<MODE, 6>), grid, dim3(384), lds, s, a); break;
+    case 7: hipLaunchKernelGGL((gemv_kernel_nw<MODE, 7>), grid, dim3(448), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 int g_gemv_max_blocks = 0;
 
 }  // namespace
@@ -256,6 +275,27 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
     const int b = (units + 4 * k - 1) / (4 * k);
     if (b <= 4 * cus && b % cus == 0 && b * 4 * k == units && (b <= g_gemv_max_blocks || k == 1)) blocks = b;
   }
+  int nw = 4;  // waves per block
+  if (!blocks) {
+    // No even split over 4-wave blocks (Mistral-Nemo's Wo / W2: 5120 rows = 2560 pairs = 256 CUs x 10).  The fallback below
+    // gives 320 blocks - 64 CUs with two blocks, 192 with one - and the doubly loaded CUs set the kernel's time at their own
+    // ingest rate (W2: 30 us for 147 MB).  One token, plain modes: blocks of 5 .. 7 waves that DO split evenly, all resident.
+    static int nw_ok = -1;  // MI_GEMV_NW=0: 4-wave blocks only (A/B testing)
+    if (nw_ok < 0) {
+      const char* e = getenv("MI_GEMV_NW");
+      nw_ok = e ? atoi(e) : 1;
+    }
+    const bool plain1 = nw_ok && a.T == 1 && (a.mode == GEMV_STORE || a.mode == GEMV_RESIDUAL) && !single && a.norm_w == nullptr &&
+                        (size_t)a.K * 2 <= 48 * 1024;
+    for (int w = 5; plain1 && w <= 7 && nw == 4; ++w)
+      for (int k = 1; k <= 16 && nw == 4; ++k) {
+        const int b = units / (w * k);
+        if (b >= cus && b % cus == 0 && b * w * k == units && b * w <= 16 * cus) {
+          nw = w;
+          blocks = b;
+        }
+      }
+  }
   if (!blocks) {
     const int k = (units + 4 * g_gemv_max_blocks - 1) / (4 * g_gemv_max_blocks);
     blocks = (units + 4 * k - 1) / (4 * k);
@@ -283,6 +323,7 @@ hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
     blocks = (units + 4 * k - 1) / (4 * k);
   }
   dim3 grid(blocks, a.mode == GEMV_MOE_W13 ? a.T * a.top_k : 1);
+  if (nw != 4) return a.mode == GEMV_STORE ? launch_nw<GEMV_STORE>(a, nw, grid, lds, s) : launch_nw<GEMV_RESIDUAL>(a, nw, grid, lds, s);
   switch (a.mode) {
     case GEMV_STORE:
       return single ? launch_mode<GEMV_STORE, 1>(a, TT, grid, lds, s) : launch_mode<GEMV_STORE, 2>(a, TT, grid, lds, s);

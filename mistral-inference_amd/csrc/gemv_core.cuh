@@ -102,7 +102,7 @@ __device__ __forceinline__ void dma_rows_to_lds(const bf16_t* src, int ld, int r
 // xs: the LDS image [TT][K]; ws: K norm weights behind it (used by the DMA path of the norm modes only).
 // DMA is a property of the INSTANTIATION (launch_gemv picks it when the rows cannot fit the registers): with an LDS-DMA anywhere in
 // a function hipcc waits vmcnt(0) at every barrier and gives up the counted waits of the register path.
-template <int TT, int NX, int NW, bool DMA>
+template <int TT, int NX, int NW, bool DMA, int NT = 256>
 __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w, bf16_t* xs,
                                         bf16_t* ws) {
   const int npieces = K >> 3;
@@ -112,11 +112,11 @@ __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int 
     if (norm_w) dma_rows_to_lds(norm_w, 0, 1, 1, npieces, reinterpret_cast<char*>(ws));
     return false;
   }
-  const bool fits = total <= NX * 256 && (norm_w == nullptr || total <= NW * 256);
+  const bool fits = total <= NX * NT && (norm_w == nullptr || total <= NW * NT);
   const bf16_t* wsrc = norm_w ? norm_w : x;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int q = min((int)threadIdx.x + i * 256, total - 1);
+    const int q = min((int)threadIdx.x + i * NT, total - 1);
     const int t = q / npieces, p = q - t * npieces;
     xr.x[i] = ld16(x + (size_t)min(t, T - 1) * ldx + p * 8);
     if (i < NW) xr.w[i] = ld16(wsrc + p * 8);
@@ -124,7 +124,7 @@ __device__ __forceinline__ bool x_issue(XRegs<NX, NW>& xr, const bf16_t* x, int 
   return fits;
 }
 
-template <int TT, int NX, int NW, bool DMA>
+template <int TT, int NX, int NW, bool DMA, int NT = 256>
 __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t* xs, float* red, const bf16_t* ws,
                                          const bf16_t* x, int ldx, int T, int K, const bf16_t* norm_w, float eps) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t
     const int total = TT * npieces;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < total) {
         const int t = q / npieces;
         if (t >= T) xr.x[i] = u32x4{0u, 0u, 0u, 0u};
@@ -174,7 +174,7 @@ __device__ __forceinline__ void x_finish(bool in_regs, XRegs<NX, NW>& xr, bf16_t
       }
     }
   } else {
-    for (int p = tid; p < npieces; p += 256) {
+    for (int p = tid; p < npieces; p += NT) {
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const u32x4 ld = ld16(x + (size_t)min(t, T - 1) * ldx + p * 8);
@@ -271,14 +271,16 @@ __device__ __forceinline__ RowPair unit_rows(const GemvArgs& a, int u, const bf1
 // ROWS = rows per unit (2 everywhere except the plain/residual/logits modes on small N, where single-row units
 // double the number of waves so that a 4096-row matrix still fills 256 CUs x 16 waves).
 // Order: activation loads first (L2 hits), then two weight batches, and the prologue finishes under them.
-template <int TT, int MODE, int ROWS, bool DMA>
+// NWV = waves per block: 4; 5 .. 8 for the plain modes (no fused RMSNorm: its passes are written for 256 threads) when the row
+// count has no even split over 4-wave blocks - Mistral-Nemo's 5120 rows are 2560 pairs = 256 CUs x 10 (launch_gemv).
+template <int TT, int MODE, int ROWS, bool DMA, int NWV = 4>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int block_id, int n_blocks, int problem) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)TT * a.K * 2);
   bf16_t* ws = reinterpret_cast<bf16_t*>(smem + (size_t)TT * a.K * 2 + 16 * TT);  // (launch_gemv reserves it for TT > 1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: unit loops become scalar
-  const int nwaves = n_blocks * 4;
+  const int nwaves = n_blocks * NWV;
   constexpr bool kPairOut = !(MODE == GEMV_SWIGLU || MODE == GEMV_MOE_W13);
   const int units = kPairOut ? (ROWS == 2 ? (a.N + 1) >> 1 : a.N) : a.N;
   constexpr int U = BATCH / ROWS;
@@ -302,6 +304,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   // 1. activation (and norm weight) loads first, 2. two weight batches, 3. finish the prologue under them
   constexpr bool kNormMode = MODE == GEMV_QKV_ROPE || MODE == GEMV_SWIGLU || MODE == GEMV_LOGITS || MODE == GEMV_MOE_W13;
   constexpr int NX = kNormMode ? 4 : 8, NW = kNormMode ? 4 : 0;
+  static_assert(NWV == 4 || (!kNormMode && !DMA), "other block sizes: plain modes on the register staging path");
   XRegs<NX, NW> xr;
   bool in_regs = false;
   // q|k|v epilogue operands that depend on nothing: the token's position (RoPE row, ring slot) and its sequence (ring row) are the
@@ -315,10 +318,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
     ep_pos = a.tok_pos[tl];
     ep_seq = a.tok_seq ? a.tok_seq[tl] : tl;
   }
-  in_regs = x_issue<TT, NX, NW, DMA>(xr, x, a.ldx, T, a.K, a.norm_w, xs, ws);
+  in_regs = x_issue<TT, NX, NW, DMA, NWV * 64>(xr, x, a.ldx, T, a.K, a.norm_w, xs, ws);
 
   // load cursor over the flattened (unit, batch) sequence of this wave: always two batches ahead of the math
-  int u = block_id * 4 + wid;
+  int u = block_id * NWV + wid;
   int ul = u, jl = 0;
   RowPair rpl = unit_rows<MODE, ROWS>(a, min(ul, units - 1), e1, e3);
   u32x4 bufA[BATCH], bufB[BATCH];
@@ -341,7 +344,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, char* smem, int blo
   };
   issue(bufA);
   issue(bufB);
-  x_finish<TT, NX, NW, DMA>(in_regs, xr, xs, red, ws, x, a.ldx, T, a.K, a.norm_w, a.eps);
+  x_finish<TT, NX, NW, DMA, NWV * 64>(in_regs, xr, xs, red, ws, x, a.ldx, T, a.K, a.norm_w, a.eps);
 
   Acc<TT> acc;
 #pragma unroll
