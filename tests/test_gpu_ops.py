@@ -410,7 +410,7 @@ def test_moe_router(T):
 # leaf entry points of the fused decode operators (SURVEY.md section 8b minimum export set)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T", [1, 3, 8])
-@pytest.mark.parametrize("H,Hkv,D", [(4, 2, 512), (32, 8, 4096), (8, 8, 1024)])
+@pytest.mark.parametrize("H,Hkv,D", [(4, 2, 512), (32, 8, 4096), (8, 8, 1024), (8, 2, 2560), (32, 8, 5120)])  # (the last two: rows of 5 / 10 chunks = the 10-load batches at T = 1)
 def test_qkv_rope_kvwrite_leaf(T, H, Hkv, D):
     """mi_qkv_rope_kvwrite = RMSNorm + q|k|v GEMV + RoPE + ring write vs the oracle's pieces (transformer_layers.py:66-70,
     rope.py:13-23, cache.py:83-92).  Projections are compared to 1 bf16 ulp of the pre-rotation value (summation order),
