@@ -420,13 +420,17 @@ def timed_run(opt, params: dict, rank: int, world: int, dev: str, T0: int, K: in
             # the device - replayed from a hipGraph.  Nothing of the step is skipped: logits [1, V] are written every step.
             sess = model.greedy_session(cache, nxt, graph=not opt.no_graph)
             W = max(Wm, 2)
-            # W untimed steps; the health check of the first ones (collect = a device->host copy and some Python) sits
-            # BEFORE the last two, so that the GPU is still busy when the bracket's synchronisation begins: a GPU that
-            # idled for a millisecond runs its first kernel ~0.4 ms slow (clock ramp), which would be charged to the K steps
-            sess.run(W - 2)
+            # W untimed steps; the health check (collect = a synchronisation, a device->host copy and some Python: the GPU idles
+            # for milliseconds) sits behind the FIRST one, so that the rest of the warm-up runs back to back into the bracket's
+            # synchronisation.  scripts/first_step_probe.py: behind >= ~2 ms of idle time the first FOUR steps run slow (2793,
+            # 2958, 2788, 2695 us against 2615: the clocks ramp over ~10 ms), behind <= 1 ms only the first, by 25 us.  Rounds 5-6
+            # had the check before the last two steps: ~0.3 ms of that ramp was charged to the K timed steps (15 us per step at K = 20).
             if W > 2:
+                sess.run(1)
                 sess.collect()
-            sess.run(2)
+                sess.run(W - 1)
+            else:
+                sess.run(W)
             dt, left, collect_s, ev_ms = 0.0, K, 0.0, 0.0
             stream = torch.cuda.current_stream(dev)  # (the stream mi_forward launches on and the captured step is replayed on)
             # (events are created BEFORE the bracket's synchronisation: whatever the host does between that synchronisation and the
@@ -501,8 +505,9 @@ def batch_run(opt, params: dict, B: int, dev: str, T0: int, K: int, Wm: int) -> 
         del logits
         sess = model.greedy_session(cache, nxt, graph=not opt.no_graph)
         W = max(Wm, 2)
-        sess.run(W)
+        sess.run(1)        # (the health check behind the first warm-up step, the rest back to back into the bracket: timed_run)
         sess.collect()
+        sess.run(W - 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sess.run(K)
