@@ -93,3 +93,33 @@ def test_full_size_prompt_logprobs_equal_forward(full_model):
     # the last row goes through the GEMV kernels instead of the GEMM: same bf16 values up to one ulp of summation order
     d = (last[0] - last_ref).abs()
     assert float((d / last_ref.abs().clamp(min=1e-2)).max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.2
+
+
+def test_full_size_greedy_soak_engine_equals_launch_path(full_model):
+    """300 greedy steps behind a 4096-token prompt (the 4096-slot rings wrap from the first step on), the generate() loop body
+    (reference generate.py:120-140 at temperature 0) once on the persistent engine and once on the launch path: every token and
+    the last logits row identical, log-probabilities equal up to the log-sum-exp's fp32 summation order, status words clean.
+    (scripts/soak_fullsize.py runs the same for 2000 steps and for the other BASELINE configs: profiles/r06b_soak_fullsize_*.)"""
+    from mistral_inference import _hip
+    m = full_model
+    T, steps = 4096, 300
+    prompt = torch.randint(0, m.args.vocab_size, (T,), generator=torch.Generator().manual_seed(5)).cuda()
+    out = {}
+    for engine in (True, False):
+        prev = _hip.set_decode_engine(engine)
+        try:
+            c = _cache(m, T + steps + 8)
+            last = m.forward(prompt, [T], c)[-1:]
+            sess = m.greedy_session(c, torch.argmax(last, dim=-1))
+            sess.run(steps)
+            toks, lps = sess.collect()
+            st = _hip.decode_engine_status(m._backend._workspace)
+            assert st["status"] == 0 and st["abort"] == 0 and st["bad_id"] == 0, st
+            out[engine] = (toks.cpu(), lps.cpu(), sess.logits.clone().cpu(), st["engine_launches"])
+        finally:
+            _hip.set_decode_engine(prev)
+    assert out[True][3] >= steps and out[False][3] == out[True][3]  # (the engine ran the first loop; the second launched none)
+    assert torch.equal(out[True][0], out[False][0]), int((out[True][0] != out[False][0]).any(dim=1).nonzero()[0, 0])
+    assert torch.equal(out[True][2], out[False][2])
+    assert float((out[True][1] - out[False][1]).abs().max()) < 2e-5
+    assert out[True][0].unique().numel() > 50  # (a real continuation, not a fixed point)
