@@ -766,13 +766,16 @@ def main() -> None:
                                       "(32 layers vs the bf16 AND fp32 oracle, Nemo x 4 layers, Mixtral-8x7B x 4, 8x22B x 3) is "
                                       "`pytest -m gpu` (tests/test_gpu_depth.py), not this object")
         torch.cuda.empty_cache()
-        out["nemo"] = sub_measurement("nemo-12b", 8192, K, Wm)
-        out["mixtral"] = sub_measurement("mixtral-8x7b", T0, K, Wm)
+        # (the sub-objects time their own brackets of >= 64 steps behind >= 8 warm-up steps - this script's defaults - whatever the
+        #  headline's K / W are, and say so in their `steps` / `warmup` fields: a 20-step bracket carries ~0.2 ms of bracket edges)
+        Ks, Ws = max(K, 64), max(Wm, 8)
+        out["nemo"] = sub_measurement("nemo-12b", 8192, Ks, Ws)
+        out["mixtral"] = sub_measurement("mixtral-8x7b", T0, Ks, Ws)
         # BASELINE configs[4]: what EACH of the 8 pipeline stages of Mixtral-8x22B runs (7 of 56 layers, 35 GB; the last stage
         # adds the LM head, which this stage measurement carries) - the per-GPU number of the 8-stage deployment
-        out["x22b_stage"] = sub_measurement("mixtral-8x22b", T0, K, Wm, extra=("--layers", "7"))
+        out["x22b_stage"] = sub_measurement("mixtral-8x22b", T0, Ks, Ws, extra=("--layers", "7"))
         # the mistral-demo shape: three prompts decoded together (reference main.py:124,220), launch path
-        out["batch3"] = sub_measurement("mistral-7b", T0, max(K, 32), Wm, extra=("--batch", "3"))
+        out["batch3"] = sub_measurement("mistral-7b", T0, Ks, Ws, extra=("--batch", "3"))
     if world > 1 and not opt.no_mixtral and opt.model == "mistral-7b" and (not opt.layers or opt.mixtral_layers):
         # north_star: "Mixtral-8x7B pipeline-parallel tokens/sec reported at 1/2/4/8 GPUs" (BASELINE configs[3], and
         # configs[4] - Mixtral-8x22B over 8 stages - where 8 GPUs are present).  The N = 1 headline line is untouched; a
